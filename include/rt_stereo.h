@@ -1,0 +1,180 @@
+/*
+ * rt_stereo.h -- thin C ABI over the MI355X (gfx950) HIP kernels of the Stereo DNN hot path.
+ *
+ * This is the drop-in boundary "host C++ calls HIP through": every plugin `enqueue` in
+ * redtail_amd/csrc/host/plugins.cpp and every TensorRT-native layer of the shim executor ends in
+ * exactly one of these entry points.  Plain pointers, ints and an opaque stream handle only -- no
+ * torch, HIP or C++ types -- so the same functions bind from C++, ctypes, cgo, JNI ...
+ * (see INTEGRATION.md).  Each entry cites the reference interface it replaces
+ * (paths relative to /root/reference/stereoDNN).
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers; tensors are dense, row-major, batch outermost;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - return value 0 = success; >0 = hipError_t from the runtime; <0 = RT_E_* argument errors.
+ *     rt_last_error_string() describes the last failure of the calling thread
+ *     (reference convention: enqueue returns 0 / non-zero, lib/cost_volume_plugin.cpp:138);
+ *   - dtype: RT_F32 everywhere; RT_F16 where noted (fp16 storage, fp32 accumulate, as the
+ *     reference does in lib/kernels.cu:218-223).
+ */
+#ifndef RT_STEREO_H
+#define RT_STEREO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rtStream;
+
+enum { RT_F32 = 0, RT_F16 = 1 };                     /* nvinfer1::DataType kFLOAT / kHALF            */
+enum { RT_NCHW = 0, RT_NC2HW2 = 1 };                 /* nvinfer1::PluginFormat                       */
+enum { RT_ACT_NONE = 0, RT_ACT_ELU = 1, RT_ACT_SIGMOID = 2 };
+enum { RT_E_BADARG = -1, RT_E_UNSUPPORTED = -2, RT_E_NODEVICE = -3, RT_E_NOMEM = -4 };
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char* rt_last_error_string(void);
+const char* rt_backend_name(void);                   /* "hip:gfx950 (<device name>)"                 */
+int rt_device_count(void);
+int rt_set_device(int ordinal);
+
+/* Device memory, copies, streams and timing, so that a host library needs no HIP headers
+ * (replaces the cudaMalloc / cudaMemcpy / cudaStream / cudaEvent calls in
+ * sample_app/main.cpp:295-315 and lib/conv3d_plugin.cpp:122-133). */
+int rt_malloc(void** dptr, size_t bytes);
+int rt_free(void* dptr);
+int rt_memcpy_h2d(void* dst, const void* src, size_t bytes, rtStream stream);
+int rt_memcpy_d2h(void* dst, const void* src, size_t bytes, rtStream stream);
+int rt_memcpy_d2d(void* dst, const void* src, size_t bytes, rtStream stream);
+int rt_memset(void* dst, int value, size_t bytes, rtStream stream);
+int rt_stream_create(rtStream* stream);
+int rt_stream_destroy(rtStream stream);
+int rt_stream_sync(rtStream stream);
+int rt_event_create(void** ev);
+int rt_event_destroy(void* ev);
+int rt_event_record(void* ev, rtStream stream);
+int rt_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+
+/* ---- element-wise ------------------------------------------------------------------------ */
+/* ELU, alpha = 1: y = x > 0 ? x : exp(x) - 1.  Replaces EluPlugin::enqueue ->
+ * cudnnActivationForward (lib/elu_plugin.cpp:123-135).  n = element count (any layout: for
+ * kNC2HW2 pass the padded count, lib/elu_plugin.cpp:165-168).  In-place allowed. */
+int rt_elu(const void* x, void* y, int64_t n, int dtype, rtStream stream);
+
+/* y = act(a + b) -- TensorRT addElementWise(kSUM) (+ a following ELU plugin when fused),
+ * e.g. sample_app/resnet18_2D_513x257_net.cpp:95-103.  In-place allowed. */
+int rt_add_act(const void* a, const void* b, void* y, int64_t n, int act, int dtype, rtStream stream);
+
+/* y = act(x) for RT_ACT_SIGMOID / RT_ACT_ELU -- addActivation(kSIGMOID),
+ * sample_app/resnet18_2D_513x257_net.cpp:766. */
+int rt_activation(const void* x, void* y, int64_t n, int act, int dtype, rtStream stream);
+
+/* ---- cost volumes ------------------------------------------------------------------------ */
+/* Correlation cost volume: cv[n,d,y,x] = sum_c L[n,c,y,x] * R[n,c,y,x-d], 0 for x < d.
+ * left/right (N,C,H,W) -> cv (N,D,H,W).  Replaces CudaKernels::computeCorrCostVolume /
+ * corrCostVolumeKernel (lib/kernels.cu:168-200,252-287).  RT_F16 + RT_NC2HW2 follows
+ * corrCostVolumeFP16NC2HW2Kernel (lib/kernels.cu:203-250): channel pairs packed in 32-bit
+ * words, fp32 accumulate, output planes packed in disparity pairs. */
+int rt_corr_cost_volume(const void* left, const void* right, void* cost_vol, int batch, int C, int H, int W,
+                        int max_disp, int dtype, int format, rtStream stream);
+
+/* Default (concatenation) cost volume: cv[n,d,0:C]=L ; cv[n,d,C:2C,y,x]=R[n,:,y,x-d] (0 for x<d).
+ * (N,C,H,W) x2 -> (N,D,2C,H,W).  Replaces CudaKernels::computeCostVolume (lib/kernels.cu:50-97,136-161). */
+int rt_cost_volume(const void* left, const void* right, void* cost_vol, int batch, int C, int H, int W,
+                   int max_disp, int dtype, rtStream stream);
+
+/* Soft-argmax (is_min = 0) / soft-argmin (1): out[n,y,x] = sum_d d * softmax_d(+-vol[n,d,y,x]).
+ * vol (N,D,H,W) -> out (N,1,H,W), one pass, no workspace.  Replaces SoftargmaxPlugin::enqueue
+ * (5 cuDNN/memcpy passes over a 2x workspace, lib/softargmax_plugin.cpp:167-205). */
+int rt_softargmax(const void* vol, void* out, int batch, int D, int H, int W, int is_min, int dtype,
+                  rtStream stream);
+
+/* Fused correlation cost volume + soft-argmax/min: the D-volume never reaches HBM.
+ * out element (n,y,x) is written at out + n*out_batch_stride + y*W + x (elements), which lets the
+ * caller place the result directly in a channel of a concatenation buffer
+ * (sample_app/resnet18_2D_513x257_net.cpp:601-615). */
+int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,
+                       int max_disp, int is_min, int64_t out_batch_stride, int dtype, rtStream stream);
+
+/* ---- layout glue of the 3-D models ------------------------------------------------------- */
+/* 4-D permute of a (N, d0,d1,d2,d3) tensor: out dim i = in dim order[i].  Replaces
+ * TransformPlugin::enqueue -> cudnnTransformTensor (lib/transform_plugin.cpp:94-108). */
+int rt_permute4d(const void* x, void* y, int batch, int d0, int d1, int d2, int d3, const int order[4],
+                 int dtype, rtStream stream);
+/* (N,D,inner) -> (N,D+pad_end,inner): copy + zero tail.  PaddingPlugin::enqueue (lib/padding_plugin.cpp:79-94). */
+int rt_pad_d(const void* x, void* y, int batch, int D, int64_t inner, int pad_end, int dtype, rtStream stream);
+/* (N,D,inner) -> (N,end-start,inner).  SlicePlugin::enqueue (lib/slice_plugin.cpp:80-92). */
+int rt_slice_d(const void* x, void* y, int batch, int D, int64_t inner, int start, int end, int dtype,
+               rtStream stream);
+/* Copy `C` channels of x (N,C,inner) into channels [c_off, c_off+C) of y (N,Ctot,inner):
+ * TensorRT addConcatenation, sample_app/resnet18_2D_513x257_net.cpp:612-615. */
+int rt_concat_channels(const void* x, void* y, int batch, int C, int Ctot, int c_off, int64_t inner, int dtype,
+                       rtStream stream);
+
+/* ---- convolutions (MFMA implicit GEMM) ----------------------------------------------------- */
+/* A plan owns the device copy of the (re-packed) weights, bias and gather tables of one layer,
+ * like Conv3DPlugin::configure owns kernel_weights_d_ (lib/conv3d_plugin.cpp:122-133). */
+typedef struct rtConvPlan rtConvPlan;
+
+typedef struct rtConv2dDesc {
+    int Cin, Cout;          /* channels                                                          */
+    int Hin, Win;           /* input plane                                                       */
+    int KH, KW;             /* 3x3 or 5x5                                                        */
+    int stride;             /* 1 or 2 (same in H and W)                                          */
+    int pad_h, pad_w;       /* symmetric zero padding (TRT setPadding)                           */
+    int act;                /* RT_ACT_* fused after bias (+ residual)                            */
+    int has_residual;       /* enqueue takes a residual tensor shaped like the output            */
+    int dtype;              /* RT_F32 | RT_F16: storage type of activations AND weights          */
+} rtConv2dDesc;
+
+/* 2-D convolution (cross-correlation), weights KCRS, bias K (may be NULL): TensorRT
+ * addConvolution as called at sample_app/resnet18_2D_513x257_net.cpp:48-53 (no source in the
+ * reference: TensorFlow conv2d semantics, scripts/tensorrt_model_builder.py:149-228).
+ * x (N,Cin,Hin,Win) -> y (N,Cout,Hout,Wout), Hout = (Hin + 2*pad - KH)/stride + 1. */
+int rt_conv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const void* weights_host,
+                          const void* bias_host);
+/* 2-D transposed convolution, weights (Cin,Cout,R,S), stride 2, 3x3: TensorRT addDeconvolution
+ * (sample_app/resnet18_2D_513x257_net.cpp:722-727) = TF conv2d_transpose
+ * (scripts/tensorrt_model_builder.py:230-288).  Hout = (Hin-1)*stride - 2*pad + KH. */
+int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const void* weights_host,
+                            const void* bias_host);
+
+typedef struct rtConv3dDesc {
+    int C, K;               /* conv: input channels C, output channels K.  Transposed op: K = INPUT   */
+                            /* channels (tensor KDHW), C = OUTPUT channels (tensor DCHW)             */
+    int D, H, W;            /* conv: input dims (D,C,H,W); transposed: OUTPUT dims (D,C,H,W)         */
+    int kernel[3];          /* (V,R,S): filter is (K,V,C,R,S); R = S in {1,3}                        */
+    int stride[3];          /* (d,h,w), h == w                                                      */
+    int pad_start[3];       /* (d,h,w) -- what the reference hands to cuDNN                         */
+    int pad_end[3];         /* validated like lib/conv3d_plugin.cpp:43-49, otherwise unused          */
+    int act;                /* RT_ACT_* (0 at the plugin boundary; used by the fusing executor)     */
+    int out_dchw;           /* conv only: write (Do,K,Ho,Wo) instead of (K,Do,Ho,Wo)                */
+    int has_residual;
+    int dtype;
+} rtConv3dDesc;
+
+/* TensorFlow-compatible 3-D convolution.  x (N, D,C,H,W) , w (K,V,C,R,S) 3x3x3 -> y (N, K,Do,Ho,Wo).
+ * Replaces Conv3DPlugin::enqueue -> cudnnConvolutionForward on the (D*C)-merged descriptor +
+ * cudnnAddTensor bias (lib/conv3d_plugin.cpp:187-216, lib/conv_utils.cpp:27-32,58-72). */
+int rt_conv3d_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const void* weights_host,
+                          const void* bias_host);
+/* TensorFlow-compatible 3-D transposed convolution.  y (N, K,Dy,Hy,Wy), w (K,V,C,R,S) -> x (N, D,C,H,W),
+ * bias per C.  Replaces Conv3DTransposePlugin::enqueue -> cudnnConvolutionBackwardData +
+ * addDBiasTo3DConvKernel (lib/conv3d_transpose_plugin.cpp:205-243, lib/kernels.cu:292-335).
+ * in_dims = (Dy,Hy,Wy) of the input. */
+int rt_conv3d_transpose_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const int in_dims[3],
+                                    const void* weights_host, const void* bias_host);
+
+/* Output dims of a plan: 2-D -> (Cout,Hout,Wout,1); 3-D -> 4 dims in the order they are written. */
+int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]);
+/* Run: x, y (and residual, shaped like y, or NULL) are device pointers for `batch` samples. */
+int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
+                    rtStream stream);
+int rt_conv_plan_destroy(rtConvPlan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_STEREO_H */

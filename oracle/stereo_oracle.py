@@ -1,0 +1,394 @@
+"""CPU oracle for the Stereo DNN inference hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module restates, on the CPU (torch fp32/fp64 + numpy), the arithmetic of the
+reference's ``stereoDNN/lib`` plugin layer and of the TensorRT-native 2-D layers the
+generated networks call.  Nothing in the product path (``redtail_amd/``) may import
+it; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg do, and only as the checker / the timed CPU baseline.
+
+Parity status: PINNED for every plugin op -- ``tests/test_oracle_golden.py`` checks
+each function below against the reference's own TF-generated tensors
+(``stereoDNN/tests/data/*.bin`` re-packed by ``tests/golden/make_golden.py``).
+The TensorRT-native 2-D layers (conv/deconv/add/concat/sigmoid) have no reference
+fixture and no end-to-end golden disparity exists: for those,
+parity is pinned only by TF semantics ("parity unpinned" by reference vectors).
+
+Every function cites the reference file:line whose semantics it follows
+(paths relative to /root/reference/stereoDNN).
+"""
+import struct
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# Plugin-level ops (layouts exactly as the plugins see them; leading dim = batch)
+# --------------------------------------------------------------------------------------
+def elu(x):
+    """ELU, alpha = 1 (lib/elu_plugin.cpp:93,132; scripts/test_data_generator.py:41-60)."""
+    return torch.where(x > 0, x, torch.expm1(x))
+
+
+def corr_cost_volume(left, right, max_disp):
+    """Correlation cost volume (lib/kernels.cu:168-200; test_data_generator.py:242-259).
+
+    left/right: (N, C, H, W)  ->  (N, D, H, W);  cv[d,y,x] = sum_c L[c,y,x] * R[c,y,x-d],
+    zero where x < d; disparities ordered min -> max.
+    """
+    n, c, h, w = left.shape
+    out = left.new_zeros((n, max_disp, h, w))
+    for d in range(min(max_disp, w)):
+        out[:, d, :, d:] = (left[:, :, :, d:] * right[:, :, :, : w - d]).sum(1)
+    return out
+
+
+def cost_volume(left, right, max_disp):
+    """Default (concatenation) cost volume (lib/kernels.cu:50-97,136-161;
+    test_data_generator.py:223-240).  (N,C,H,W) x2 -> (N, D, 2C, H, W):
+    cv[d, 0:C] = L ; cv[d, C:2C, y, x] = R[:, y, x-d] (0 for x < d)."""
+    n, c, h, w = left.shape
+    out = left.new_zeros((n, max_disp, 2 * c, h, w))
+    for d in range(max_disp):
+        out[:, d, :c] = left
+        if d < w:
+            out[:, d, c:, :, d:] = right[:, :, :, : w - d]
+    return out
+
+
+def softargmax(vol, is_min):
+    """Soft-argmax / soft-argmin over the disparity axis (lib/softargmax_plugin.cpp:167-205;
+    test_data_generator.py:300-315).  vol: (N, D, H, W) [a (N,D,1,H,W) input is squeezed,
+    softargmax_plugin.cpp:66-72] -> (N, 1, H, W) = sum_d d * softmax_d(+-vol)."""
+    if vol.dim() == 5:
+        assert vol.shape[2] == 1
+        vol = vol[:, :, 0]
+    p = torch.softmax(-vol if is_min else vol, dim=1)
+    idx = torch.arange(vol.shape[1], dtype=vol.dtype).view(1, -1, 1, 1)
+    return (p * idx).sum(1, keepdim=True)
+
+
+def conv3d_tf(x, w, bias, stride, pad_start, pad_end):
+    """Conv3DPlugin, Conv3DType::kTensorFlow (lib/conv3d_plugin.cpp:187-216 with the
+    descriptor reshape of lib/conv_utils.cpp:27-32,58-72).
+
+    x: (N, D, C, H, W)   w: (K, V, C, R, S)   bias: (K,) or None
+    stride/pad_*: (d, h, w).  cuDNN is given pad_start only (conv3d_plugin.cpp:86-87), so
+    the (TF-asymmetric) extra end padding in D must already be in x (PaddingPlugin) --
+    exactly like the reference.  Returns (N, K, Do, Ho, Wo).
+    """
+    xt = x.permute(0, 2, 1, 3, 4)            # N C D H W
+    wt = w.permute(0, 2, 1, 3, 4)            # K C V R S
+    return F.conv3d(xt, wt, bias, stride=tuple(stride), padding=tuple(pad_start))
+
+
+def conv3d_transpose_tf(y, w, bias, out_dims, stride, pad_start, pad_end):
+    """Conv3DTransposePlugin (lib/conv3d_transpose_plugin.cpp:205-243): cuDNN backward-data
+    of the conv above.  y: (N, K, Dy, Hy, Wy)  w: (K, V, C, R, S)  bias: (C,) or None
+    out_dims: (Dx, C, Hx, Wx) as passed to createConv3DTransposePlugin.  Returns
+    (N, Dx, C, Hx, Wx).  Bias is per C of the output (kernels.cu:292-308)."""
+    dx, c, hx, wx = out_dims
+    wt = w.permute(0, 2, 1, 3, 4)            # (K=in, C=out, V, R, S)
+    k = wt.shape[2:]
+    got = [(y.shape[2 + i] - 1) * stride[i] - 2 * pad_start[i] + k[i] for i in range(3)]
+    opad = [t - g for t, g in zip((dx, hx, wx), got)]
+    assert all(0 <= o < s for o, s in zip(opad, stride)), (got, out_dims)
+    x = F.conv_transpose3d(y, wt, bias, stride=tuple(stride), padding=tuple(pad_start),
+                           output_padding=tuple(opad))
+    return x.permute(0, 2, 1, 3, 4).contiguous()
+
+
+def transform(x, order=(1, 0, 2, 3)):
+    """TransformPlugin (lib/transform_plugin.cpp:94-108,135-165); only {1,0,2,3} is used."""
+    return x.permute(0, *[o + 1 for o in order]).contiguous()
+
+
+def pad_d(x, n_end=1):
+    """PaddingPlugin: append zero slices at the end of the outermost non-batch dim
+    (lib/padding_plugin.cpp:79-94)."""
+    z = x.new_zeros((x.shape[0], n_end) + tuple(x.shape[2:]))
+    return torch.cat([x, z], 1)
+
+
+def slice_d(x, start, end):
+    """SlicePlugin: keep [start, end) of the outermost non-batch dim (lib/slice_plugin.cpp:80-92)."""
+    return x[:, start:end].contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# TensorRT-native 2-D layers used by the generated nets (no source in the reference;
+# semantics = TensorFlow's, see scripts/tensorrt_model_builder.py:140-288)
+# --------------------------------------------------------------------------------------
+def tf_same_pad(n, k, s):
+    """scripts/tensorrt_model_builder.py:140-147."""
+    pad = max(k - s, 0) if n % s == 0 else max(k - (n % s), 0)
+    return pad // 2, pad - pad // 2
+
+
+def conv2d(x, w, b, stride, pad):
+    """addConvolution: cross-correlation, weights KCRS (tensorrt_model_builder.py:149-228)."""
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+def deconv2d(x, w, b, stride, pad):
+    """addDeconvolution: weights (Cin, Cout, R, S) = TF conv2d_transpose/Conv2DBackpropInput
+    (tensorrt_model_builder.py:230-288)."""
+    return F.conv_transpose2d(x, w, b, stride=stride, padding=pad)
+
+
+# --------------------------------------------------------------------------------------
+# Weight files (scripts/tensorrt_model_builder.py:52-60; reader sample_app/main.cpp:111-134)
+# --------------------------------------------------------------------------------------
+def read_weights(path, fp16=False):
+    raw = open(path, "rb").read()
+    off, out = 0, {}
+    dt = np.dtype("<f2") if fp16 else np.dtype("<f4")
+    while off < len(raw):
+        end = raw.index(b"\0", off)
+        name = raw[off:end].decode()
+        (cnt,) = struct.unpack_from("<I", raw, end + 1)
+        off = end + 5
+        out[name] = np.frombuffer(raw, dtype=dt, count=cnt, offset=off).astype(np.float32)
+        off += cnt * dt.itemsize
+    return out
+
+
+def write_weights(path, weights, fp16=False):
+    with open(path, "wb") as f:
+        for name, v in weights.items():
+            f.write(name.encode() + b"\0")
+            flat = np.asarray(v).reshape(-1)
+            f.write(struct.pack("<I", flat.size))
+            f.write(flat.astype("<f2" if fp16 else "<f4").tobytes())
+
+
+def _he(rng, shape, fan_in, gain=1.0):
+    return (rng.standard_normal(shape) * gain * np.sqrt(2.0 / fan_in)).astype(np.float32)
+
+
+def _add_conv(w, rng, name, cout, cin, k, gain=1.0):
+    w[name + "_k"] = _he(rng, (cout, cin) + k, cin * int(np.prod(k)), gain).reshape(-1)
+    w[name + "_b"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+
+
+def synth_weights_resnet18_2d(seed=7):
+    """Seeded He-normal weights with the tensor names/shapes of
+    sample_app/resnet18_2D_513x257_net.cpp (both sides share weights, as the real file does)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for s in ("left", "right"):
+        w[s + "_scale_shift"] = np.zeros(1, np.float32)
+        w[s + "_scale_scale"] = np.ones(1, np.float32)
+        w[s + "_scale_power"] = np.ones(1, np.float32)
+    enc = {}
+    _add_conv(enc, rng, "conv1", 32, 3, (5, 5))
+    for i in range(1, 9):
+        _add_conv(enc, rng, "resblock%d_conv1" % i, 32, 32, (3, 3))
+        _add_conv(enc, rng, "resblock%d_conv2" % i, 32, 32, (3, 3), gain=0.5)
+    _add_conv(enc, rng, "encoder2D_out", 32, 32, (3, 3), gain=0.7)
+    for s in ("left", "right"):
+        for k, v in enc.items():
+            w[s + "_" + k] = v.copy()
+    for name, co, ci in (("conv2D_1", 32, 33), ("conv2D_2", 32, 32), ("conv2D_3ds", 64, 32),
+                         ("conv2D_4", 64, 64), ("conv2D_5", 64, 64), ("conv2D_6ds", 128, 64),
+                         ("conv2D_7", 128, 128), ("conv2D_8", 128, 128)):
+        _add_conv(w, rng, name, co, ci, (3, 3))
+    # deconv kernels are stored (Cin, Cout, R, S)
+    for name, ci, co in (("deconv2D_1", 128, 64), ("deconv2D_2", 64, 32), ("deconv2D_3", 32, 1)):
+        w[name + "_k"] = _he(rng, (ci, co, 3, 3), ci * 9 / 4.0).reshape(-1)
+        w[name + "_b"] = rng.uniform(-0.1, 0.1, co).astype(np.float32)
+    return w
+
+
+# 3-D models: (name, K, C, stride) for conv3D_*, (name, K_in, C_out) for deconv3D_*
+NVSMALL_3D = dict(
+    feat=32, enc2d=("conv1", "conv2", "conv3", "conv4", "conv5"),
+    conv3d=[("conv3D_1", 32, 64, 1), ("conv3D_2", 32, 32, 1), ("conv3D_3ds", 64, 32, 2),
+            ("conv3D_4", 64, 64, 1), ("conv3D_5", 64, 64, 1), ("conv3D_6ds", 128, 64, 2),
+            ("conv3D_7", 128, 128, 1), ("conv3D_8", 128, 128, 1)],
+    deconv3d=[("deconv3D_1", 128, 64, "conv3D_5"), ("deconv3D_2", 64, 32, "conv3D_2"),
+              ("deconv3D_3", 32, 1, None)])
+NVTINY_3D = dict(
+    feat=8, enc2d=("conv1", "conv2", "conv3", "conv4", "conv5"),
+    conv3d=[("conv3D_1", 16, 16, 1), ("conv3D_2", 16, 16, 1), ("conv3D_3ds", 32, 16, 2),
+            ("conv3D_4", 32, 32, 1), ("conv3D_5", 32, 32, 1), ("conv3D_6ds", 64, 32, 2),
+            ("conv3D_7", 64, 64, 1), ("conv3D_8", 64, 64, 1)],
+    deconv3d=[("deconv3D_1", 64, 32, "conv3D_5"), ("deconv3D_2", 32, 16, "conv3D_2"),
+              ("deconv3D_3", 16, 1, None)])
+RESNET18_3D = dict(
+    feat=32, enc2d="resnet",
+    conv3d=[("conv3D_1a", 32, 64, 1), ("conv3D_1b", 32, 32, 1), ("conv3D_1ds", 64, 32, 2),
+            ("conv3D_2a", 64, 64, 1), ("conv3D_2b", 64, 64, 1), ("conv3D_2ds", 64, 64, 2),
+            ("conv3D_3a", 64, 64, 1), ("conv3D_3b", 64, 64, 1), ("conv3D_3ds", 64, 64, 2),
+            ("conv3D_4a", 64, 64, 1), ("conv3D_4b", 64, 64, 1), ("conv3D_4ds", 128, 64, 2),
+            ("conv3D_5a", 128, 128, 1), ("conv3D_5b", 128, 128, 1)],
+    deconv3d=[("deconv3D_1", 128, 64, "conv3D_4b"), ("deconv3D_2", 64, 64, "conv3D_3b"),
+              ("deconv3D_3", 64, 64, "conv3D_2b"), ("deconv3D_4", 64, 32, "conv3D_1b"),
+              ("deconv3D_5", 32, 1, None)])
+
+
+def synth_weights_3d(cfg, seed=7):
+    """Seeded weights with the names/shapes of sample_app/{nvsmall,nvtiny,resnet18}_*_net.cpp."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for s in ("left", "right"):
+        w[s + "_scale_shift"] = np.zeros(1, np.float32)
+        w[s + "_scale_scale"] = np.ones(1, np.float32)
+        w[s + "_scale_power"] = np.ones(1, np.float32)
+    enc = {}
+    if cfg["enc2d"] == "resnet":
+        _add_conv(enc, rng, "conv1", 32, 3, (5, 5))
+        for i in range(1, 9):
+            _add_conv(enc, rng, "resblock%d_conv1" % i, 32, 32, (3, 3))
+            _add_conv(enc, rng, "resblock%d_conv2" % i, 32, 32, (3, 3), gain=0.5)
+        _add_conv(enc, rng, "encoder2D_out", 32, 32, (3, 3), gain=0.7)
+    else:
+        _add_conv(enc, rng, "conv1", 32, 3, (5, 5))
+        for l in ("conv2", "conv3", "conv4"):
+            _add_conv(enc, rng, l, 32, 32, (3, 3))
+        _add_conv(enc, rng, "conv5", cfg["feat"], 32, (3, 3), gain=0.7)
+    for s in ("left", "right"):
+        for k, v in enc.items():
+            w[s + "_" + k] = v.copy()
+    for name, k, c, _s in cfg["conv3d"]:
+        w[name + "_k"] = _he(rng, (k, 3, c, 3, 3), 27 * c).reshape(-1)
+        w[name + "_b"] = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+    for name, k, c, _skip in cfg["deconv3d"]:
+        w[name + "_k"] = _he(rng, (k, 3, c, 3, 3), 27 * k / 8.0).reshape(-1)
+        w[name + "_b"] = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# Whole networks, op for op as the generated builders call them
+# --------------------------------------------------------------------------------------
+def _t(w, name, shape):
+    return torch.from_numpy(np.ascontiguousarray(w[name])).reshape(shape)
+
+
+def _conv2d_named(x, w, name, k, stride):
+    cin = x.shape[1]
+    b = _t(w, name + "_b", (-1,))
+    kk = _t(w, name + "_k", (b.numel(), cin, k, k)).to(x.dtype)
+    ph = tf_same_pad(x.shape[2], k, stride)
+    pw = tf_same_pad(x.shape[3], k, stride)
+    assert ph[0] == ph[1] and pw[0] == pw[1], "asymmetric 2-D pad (tensorrt_model_builder.py:203-207)"
+    return conv2d(x, kk, b.to(x.dtype), stride, (ph[0], pw[0]))
+
+
+def _resnet_encoder(x, w, side):
+    """sample_app/resnet18_2D_513x257_net.cpp:48-598 (scripts/model_resnet18.py:20-45)."""
+    cur = elu(_conv2d_named(x, w, side + "_conv1", 5, 2))
+    conv1_act = cur
+    for i in range(1, 9):
+        p = "%s_resblock%d" % (side, i)
+        t = elu(_conv2d_named(cur, w, p + "_conv1", 3, 1))
+        t = _conv2d_named(t, w, p + "_conv2", 3, 1)
+        cur = elu(t + cur)
+    return _conv2d_named(cur, w, side + "_encoder2D_out", 3, 1), conv1_act
+
+
+def resnet18_2d(left, right, w, max_disp=48, return_intermediates=False):
+    """ResNet-18 2D network, sample_app/resnet18_2D_513x257_net.cpp:21-777
+    (scripts/model_resnet18_2D.py:16-45).  left/right: (N,3,H,W) in [0,1], H,W = 1 (mod 8).
+    Returns (N,1,H,W) sigmoid output = disparity / width."""
+    lf, l1 = _resnet_encoder(left, w, "left")
+    rf, _ = _resnet_encoder(right, w, "right")
+    cv = corr_cost_volume(lf, rf, max_disp)
+    sa = softargmax(cv, is_min=False)
+    cur = torch.cat([l1, sa], 1)
+    acts = {}
+    for name, k, s in (("conv2D_1", 3, 1), ("conv2D_2", 3, 1), ("conv2D_3ds", 3, 2), ("conv2D_4", 3, 1),
+                       ("conv2D_5", 3, 1), ("conv2D_6ds", 3, 2), ("conv2D_7", 3, 1), ("conv2D_8", 3, 1)):
+        cur = elu(_conv2d_named(cur, w, name, k, s))
+        acts[name] = cur
+    for name, skip in (("deconv2D_1", "conv2D_5"), ("deconv2D_2", "conv2D_2"), ("deconv2D_3", None)):
+        b = _t(w, name + "_b", (-1,)).to(cur.dtype)
+        kk = _t(w, name + "_k", (cur.shape[1], b.numel(), 3, 3)).to(cur.dtype)
+        cur = deconv2d(cur, kk, b, 2, 1)
+        if skip is not None:
+            cur = elu(cur + acts[skip])
+    out = torch.sigmoid(cur)
+    if return_intermediates:
+        return out, dict(left_feat=lf, right_feat=rf, cost_vol=cv, softargmax=sa)
+    return out
+
+
+def stereo3d(left, right, w, cfg, max_disp):
+    """NVSmall / NVTiny / ResNet-18 (3-D) networks: sample_app/nvsmall_1025x321_net.cpp,
+    nvtiny_513x161_net.cpp, resnet18_1025x321_net.cpp (scripts/model_nvsmall.py:18-73,
+    scripts/model_resnet18.py:46-85).  max_disp is the half-resolution D of the cost volume.
+    Returns (N,1,H,W) disparity in pixels (softargmin)."""
+    def enc(x, side):
+        if cfg["enc2d"] == "resnet":
+            return _resnet_encoder(x, w, side)[0]
+        cur = elu(_conv2d_named(x, w, side + "_conv1", 5, 2))
+        for l in ("conv2", "conv3", "conv4"):
+            cur = elu(_conv2d_named(cur, w, "%s_%s" % (side, l), 3, 1))
+        return _conv2d_named(cur, w, side + "_conv5", 3, 1)
+
+    cur = cost_volume(enc(left, "left"), enc(right, "right"), max_disp)    # N D 2C H W
+    acts = {}
+    last = cfg["conv3d"][-1][0]
+    for name, k, c, s in cfg["conv3d"]:
+        kk = _t(w, name + "_k", (k, 3, c, 3, 3)).to(cur.dtype)
+        b = _t(w, name + "_b", (k,)).to(cur.dtype)
+        if s == 2:
+            cur = pad_d(cur, 1)                      # Pad plugin is emitted before every *ds conv
+            pd = tf_same_pad(cur.shape[1] - 1, 3, 2)
+            ph = tf_same_pad(cur.shape[3], 3, 2)
+            pw = tf_same_pad(cur.shape[4], 3, 2)
+            cur = conv3d_tf(cur, kk, b, (2, 2, 2), (pd[0], ph[0], pw[0]), (pd[1], ph[1], pw[1]))
+        else:
+            cur = conv3d_tf(cur, kk, b, (1, 1, 1), (1, 1, 1), (1, 1, 1))
+        if name != last:
+            cur = transform(cur)                     # KDHW -> DKHW
+        cur = elu(cur)
+        acts[name] = cur
+    for i, (name, k, c, skip) in enumerate(cfg["deconv3d"]):
+        kk = _t(w, name + "_k", (k, 3, c, 3, 3)).to(cur.dtype)
+        b = _t(w, name + "_b", (c,)).to(cur.dtype)
+        dy, hy, wy = cur.shape[2], cur.shape[3], cur.shape[4]
+        if skip is not None:
+            dx, hx, wx = acts[skip].shape[1], acts[skip].shape[3], acts[skip].shape[4]
+        else:
+            dx, hx, wx = 2 * dy, 2 * hy - 1, 2 * wy - 1
+        pd = tf_same_pad(dx, 3, 2)
+        if pd[0] != pd[1]:                           # tensorrt_model_builder.py:422-440
+            cur = conv3d_transpose_tf(cur, kk, b, (dx + 1, c, hx, wx), (2, 2, 2), (0, 1, 1), (0, 1, 1))
+            cur = slice_d(cur, 0, dx)
+        else:
+            cur = conv3d_transpose_tf(cur, kk, b, (dx, c, hx, wx), (2, 2, 2), (pd[0], 1, 1), (pd[1], 1, 1))
+        if skip is not None:
+            cur = elu(cur + acts[skip])
+            cur = transform(cur)                     # DKHW -> KDHW
+    return softargmax(cur, is_min=True)
+
+
+# --------------------------------------------------------------------------------------
+# KITTI-shaped synthetic stereo pairs
+# --------------------------------------------------------------------------------------
+def synth_pair(h, w, seed=1234):
+    """Textured left image + right image = left warped by a smooth disparity field
+    d(y,x) = 4 + 60*(y/H) + 8*sin(2*pi*x/W) px, scaled by w/1257.  Returns (3,H,W) x2 in [0,1]."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((3, h, w), np.float64)
+    for scale, amp in ((1, 0.25), (2, 0.25), (4, 0.2), (8, 0.15), (16, 0.15)):
+        hh, ww = -(-h // scale) + 1, -(-w // scale) + 1
+        n = rng.uniform(0, 1, (3, hh, ww))
+        up = np.kron(n, np.ones((1, scale, scale)))[:, :h, :w]
+        img += amp * up
+    img += 0.1 * np.linspace(0, 1, w)[None, None, :]
+    img = (img - img.min()) / (img.max() - img.min())
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    disp = (4 + 60 * (yy / h) + 8 * np.sin(2 * np.pi * xx / w)) * (w / 1257.0)
+    # right[y, x] = left[y, x + d]  (a point at x in the right view sits at x + d in the left)
+    src = xx + disp
+    x0 = np.floor(src).astype(int)
+    fr = src - x0
+    valid = (x0 >= 0) & (x0 + 1 < w)
+    x0c = np.clip(x0, 0, w - 2)
+    right = (1 - fr) * img[:, yy, x0c] + fr * img[:, yy, x0c + 1]
+    right = np.where(valid[None], right, 0.0)
+    return img.astype(np.float32), right.astype(np.float32)

@@ -1,0 +1,108 @@
+"""Build recipes for the native libraries (all in-tree, so the .so files travel with gpurun).
+
+  lib/librt_stereo_hip.so        HIP kernels + C ABI (include/rt_stereo.h), hipcc, gfx950 only
+  lib/libnvstereo_inference.so   host C++: NvInfer.h shim, plugins, executor, networks, net-level C ABI
+  tests/emu/build/*.so           the same sources compiled for x86 against the SIMT emulator
+                                 (tests only -- see tests/emu/hip/hip_runtime.h)
+
+    python -m redtail_amd.build [hip] [host] [emu] [apps]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "redtail_amd", "csrc")
+LIB = os.path.join(ROOT, "redtail_amd", "lib")
+EMU = os.path.join(ROOT, "tests", "emu")
+EMU_BUILD = os.path.join(EMU, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOSTCXX = os.environ.get("RT_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+GXX = os.environ.get("CXX", "g++")
+
+HOST_SOURCES = ["host/plugins.cpp", "host/engine.cpp", "host/networks.cpp", "host/net_capi.cpp"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for s in sources:
+        if os.path.isdir(s):
+            for d, _, fs in os.walk(s):
+                if any(os.path.getmtime(os.path.join(d, f)) > t for f in fs):
+                    return True
+        elif os.path.exists(s) and os.path.getmtime(s) > t:
+            return True
+    return False
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_hip(force=False):
+    """Cross-compiles the kernels for gfx950 (works without a GPU)."""
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "librt_stereo_hip.so")
+    deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
+    if force or _newer(out, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+              "-Wno-unused-function", os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+    return out
+
+
+def build_emu(force=False):
+    """Host build of the same kernel sources on top of tests/emu (test infrastructure)."""
+    os.makedirs(EMU_BUILD, exist_ok=True)
+    out = os.path.join(EMU_BUILD, "librt_stereo_emu.so")
+    deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include"),
+            os.path.join(EMU, "hip"), os.path.join(EMU, "hip_emu.cpp")]
+    if force or _newer(out, deps):
+        _run([HOSTCXX, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-I", EMU, "-Wall",
+              "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable",
+              os.path.join(CSRC, "rt_capi.hip"), os.path.join(EMU, "hip_emu.cpp"), "-o", out])
+    return out
+
+
+def _build_host_against(kernels_lib, out):
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    libdir, libname = os.path.split(kernels_lib)
+    _run([GXX, "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "redtail_amd", "include")] + srcs +
+         ["-L", libdir, "-l:" + libname, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + libdir, "-o", out])
+
+
+def build_host(force=False):
+    out = os.path.join(LIB, "libnvstereo_inference.so")
+    kern = build_hip()
+    deps = [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]
+    if force or _newer(out, deps):
+        _build_host_against(kern, out)
+    return out
+
+
+def build_host_emu(force=False):
+    out = os.path.join(EMU_BUILD, "libnvstereo_inference_emu.so")
+    kern = build_emu()
+    deps = [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]
+    if force or _newer(out, deps):
+        _build_host_against(kern, out)
+    return out
+
+
+def main(argv):
+    what = argv or ["hip", "host", "emu"]
+    if "hip" in what:
+        build_hip()
+    if "host" in what:
+        build_host()
+    if "emu" in what:
+        build_emu()
+        if os.path.exists(os.path.join(CSRC, "host", "engine.cpp")):
+            build_host_emu()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

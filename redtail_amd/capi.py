@@ -1,0 +1,199 @@
+"""ctypes binding of the C ABI in include/rt_stereo.h (+ the net-level ABI in include/rt_stereo_net.h).
+
+This is plumbing for tests and bench.py: PyTorch (or numpy under the test-only emulator) owns the
+buffers, the C ABI does the work.  There is no Python/torch compute fallback: if the HIP library is
+missing, or no GPU is visible, loading fails loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_LIB = os.path.join(ROOT, "redtail_amd", "lib", "librt_stereo_hip.so")
+HOST_LIB = os.path.join(ROOT, "redtail_amd", "lib", "libnvstereo_inference.so")
+
+RT_F32, RT_F16 = 0, 1
+RT_NCHW, RT_NC2HW2 = 0, 1
+RT_ACT_NONE, RT_ACT_ELU, RT_ACT_SIGMOID = 0, 1, 2
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Conv2dDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("Cin", "Cout", "Hin", "Win", "KH", "KW", "stride", "pad_h", "pad_w", "act",
+                                     "has_residual", "dtype")]
+
+
+class Conv3dDesc(ctypes.Structure):
+    _fields_ = [("C", c_int), ("K", c_int), ("D", c_int), ("H", c_int), ("W", c_int), ("kernel", c_int * 3),
+                ("stride", c_int * 3), ("pad_start", c_int * 3), ("pad_end", c_int * 3), ("act", c_int),
+                ("out_dchw", c_int), ("has_residual", c_int), ("dtype", c_int)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rt_stereo.h
+KERNEL_SYMBOLS = {
+    "rt_last_error_string": (c_char_p, []),
+    "rt_backend_name": (c_char_p, []),
+    "rt_device_count": (c_int, []),
+    "rt_set_device": (c_int, [c_int]),
+    "rt_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "rt_free": (c_int, [c_void_p]),
+    "rt_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rt_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rt_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rt_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "rt_stream_create": (c_int, [POINTER(c_void_p)]),
+    "rt_stream_destroy": (c_int, [c_void_p]),
+    "rt_stream_sync": (c_int, [c_void_p]),
+    "rt_event_create": (c_int, [POINTER(c_void_p)]),
+    "rt_event_destroy": (c_int, [c_void_p]),
+    "rt_event_record": (c_int, [c_void_p, c_void_p]),
+    "rt_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "rt_elu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rt_add_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rt_activation": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rt_corr_cost_volume": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rt_cost_volume": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "rt_softargmax": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "rt_corr_softargmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int64, c_int, c_void_p]),
+    "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
+    "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "rt_slice_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rt_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "rt_conv2d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv2dDesc), c_void_p, c_void_p]),
+    "rt_deconv2d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv2dDesc), c_void_p, c_void_p]),
+    "rt_conv3d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), c_void_p, c_void_p]),
+    "rt_conv3d_transpose_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), POINTER(c_int), c_void_p,
+                                                c_void_p]),
+    "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
+    "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_conv_plan_destroy": (c_int, [c_void_p]),
+}
+
+
+def _ptr(x):
+    """Raw device address of a torch tensor / numpy array (emulator) / int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+class KernelLib:
+    """The op-level C ABI.  `path=None` loads the gfx950 build and requires a visible GPU."""
+
+    def __init__(self, path=None):
+        emulated = path is not None
+        path = path or HIP_LIB
+        if not os.path.exists(path):
+            raise RtError("native library %s is missing -- run `python -m redtail_amd.build` "
+                          "(there is no Python fallback for the HIP path)" % path)
+        self.path = path
+        self.lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in KERNEL_SYMBOLS.items():
+            fn = getattr(self.lib, name)      # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if not emulated and self.lib.rt_device_count() < 1:
+            raise RtError("no HIP device visible: the Stereo DNN path runs on MI355X only")
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise RtError("%s failed (%d): %s" % (what, rc, self.lib.rt_last_error_string().decode()))
+
+    def backend(self):
+        return self.lib.rt_backend_name().decode()
+
+    # -- ops (x/y are torch CUDA tensors, or numpy arrays under the emulator) -----------------------
+    def elu(self, x, y, n, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_elu(_ptr(x), _ptr(y), n, dtype, stream), "rt_elu")
+
+    def add_act(self, a, b, y, n, act, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_add_act(_ptr(a), _ptr(b), _ptr(y), n, act, dtype, stream), "rt_add_act")
+
+    def activation(self, x, y, n, act, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_activation(_ptr(x), _ptr(y), n, act, dtype, stream), "rt_activation")
+
+    def corr_cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, fmt=RT_NCHW, stream=None):
+        self.check(self.lib.rt_corr_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, stream),
+                   "rt_corr_cost_volume")
+
+    def cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, stream),
+                   "rt_cost_volume")
+
+    def softargmax(self, vol, out, batch, D, H, W, is_min, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_softargmax(_ptr(vol), _ptr(out), batch, D, H, W, int(is_min), dtype, stream),
+                   "rt_softargmax")
+
+    def corr_softargmax(self, l, r, out, batch, C, H, W, D, is_min, out_bstride=0, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_corr_softargmax(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min),
+                                               out_bstride, dtype, stream), "rt_corr_softargmax")
+
+    def permute4d(self, x, y, batch, dims, order, dtype=RT_F32, stream=None):
+        o = (c_int * 4)(*order)
+        self.check(self.lib.rt_permute4d(_ptr(x), _ptr(y), batch, dims[0], dims[1], dims[2], dims[3], o, dtype,
+                                         stream), "rt_permute4d")
+
+    def pad_d(self, x, y, batch, D, inner, pad_end, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_pad_d(_ptr(x), _ptr(y), batch, D, inner, pad_end, dtype, stream), "rt_pad_d")
+
+    def slice_d(self, x, y, batch, D, inner, start, end, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_slice_d(_ptr(x), _ptr(y), batch, D, inner, start, end, dtype, stream), "rt_slice_d")
+
+    def concat_channels(self, x, y, batch, C, Ctot, c_off, inner, dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_concat_channels(_ptr(x), _ptr(y), batch, C, Ctot, c_off, inner, dtype, stream),
+                   "rt_concat_channels")
+
+    # -- convolution plans -------------------------------------------------------------------------
+    def conv2d_plan(self, w_host, b_host, Cin, Cout, Hin, Win, k, stride, pad, act=0, has_residual=False,
+                    dtype=RT_F32, transposed=False):
+        d = Conv2dDesc(Cin, Cout, Hin, Win, k, k, stride, pad, pad, act, int(has_residual), dtype)
+        plan = c_void_p()
+        fn = self.lib.rt_deconv2d_plan_create if transposed else self.lib.rt_conv2d_plan_create
+        self.check(fn(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host)), "conv2d plan")
+        return ConvPlan(self, plan)
+
+    def conv3d_plan(self, w_host, b_host, C, K, dims, kernel, stride, pad_start, pad_end, act=0, out_dchw=False,
+                    has_residual=False, dtype=RT_F32, transposed_in_dims=None):
+        d = Conv3dDesc(C, K, dims[0], dims[1], dims[2], (c_int * 3)(*kernel), (c_int * 3)(*stride),
+                       (c_int * 3)(*pad_start), (c_int * 3)(*pad_end), act, int(out_dchw), int(has_residual), dtype)
+        plan = c_void_p()
+        if transposed_in_dims is None:
+            rc = self.lib.rt_conv3d_plan_create(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host))
+        else:
+            ind = (c_int * 3)(*transposed_in_dims)
+            rc = self.lib.rt_conv3d_transpose_plan_create(ctypes.byref(plan), ctypes.byref(d), ind, _ptr(w_host),
+                                                          _ptr(b_host))
+        self.check(rc, "conv3d plan")
+        return ConvPlan(self, plan)
+
+
+class ConvPlan:
+    def __init__(self, klib, handle):
+        self.klib, self.handle = klib, handle
+        dims = (c_int * 4)()
+        klib.check(klib.lib.rt_conv_plan_out_dims(handle, dims), "rt_conv_plan_out_dims")
+        self.out_dims = tuple(dims)
+
+    def enqueue(self, x, y, residual=None, batch=1, stream=None):
+        self.klib.check(self.klib.lib.rt_conv_enqueue(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream),
+                        "rt_conv_enqueue")
+
+    def destroy(self):
+        if self.handle:
+            self.klib.lib.rt_conv_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

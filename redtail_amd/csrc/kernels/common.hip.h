@@ -1,0 +1,34 @@
+// Shared helpers for the gfx950 kernels of the Stereo DNN hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+__host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ELU(alpha = 1), NaN-propagating like cudnnActivationForward(CUDNN_ACTIVATION_ELU, PROPAGATE_NAN)
+// (reference lib/elu_plugin.cpp:93): x > 0 ? x : exp(x) - 1  (TF computes exp(x) - 1, not expm1).
+__device__ static __forceinline__ float elu1(float x) { return x > 0.f ? x : expf(x) - 1.f; }
+__device__ static __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int ACT>
+__device__ static __forceinline__ float apply_act(float v) {
+    if (ACT == 1) return elu1(v);
+    if (ACT == 2) return sigmoid1(v);
+    return v;
+}
+__device__ static __forceinline__ float apply_act_rt(float v, int act) {
+    return act == 1 ? elu1(v) : (act == 2 ? sigmoid1(v) : v);
+}
+
+}  // namespace rt

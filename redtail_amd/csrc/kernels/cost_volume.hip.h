@@ -1,0 +1,232 @@
+// Cost-volume and soft-argmax kernels (HBM-bound part of the hot path).
+//   corr_f32_kernel        replaces corrCostVolumeKernel            (reference lib/kernels.cu:168-200)
+//   corr_f32_kernel<FUSED> = correlation + soft-argmax in one pass  (volume never written to HBM)
+//   cost_volume_f32_kernel replaces costVolumeCopy{,Pad}Kernel      (reference lib/kernels.cu:50-97)
+//   softargmax_f32_kernel  replaces SoftargmaxPlugin::enqueue's 5 passes (lib/softargmax_plugin.cpp:167-205)
+#pragma once
+#include "common.hip.h"
+
+namespace rt {
+
+// ------------------------------------------------------------------------------------------------
+// Correlation cost volume, fp32 NCHW.
+//
+// Workgroup = 4 waves = one 4-row x 128-pixel tile of one sample, all disparities of one 4*DT block.
+// Wave w owns the disparity group d in [d_base + w*DT, d_base + (w+1)*DT); lane = (row r = lane>>4,
+// pixel group xg = lane&15) owns 8 consecutive pixels -> an 8 x DT register tile of accumulators.
+// Per channel a lane needs L[8] and the sliding window R[8 + DT - 1]: both come from LDS as
+// ds_read_b128.  The tiles are stored de-interleaved by 16-byte chunk parity (E = even chunks,
+// O = odd chunks): a lane's window starts at chunk 2*xg + const, so within one instruction all
+// lanes of a row read consecutive 16-byte slots of ONE parity array, and row regions are 512 B
+// apart, i.e. every ds_read_b128 lane group is bank-conflict free (MI355X_MICROARCH.md, LDS table).
+// Each L / R element is fetched from HBM once per tile (R has a D-wide halo), instead of D times
+// as in the reference kernel ("not optimized", kernels.cu:45).
+// ------------------------------------------------------------------------------------------------
+constexpr int kCorrRY = 4;      // rows per tile
+constexpr int kCorrTX = 128;    // pixels per tile row
+constexpr int kCorrCC = 8;      // channels per LDS stage
+constexpr int kCorrRS = 32;     // 16-byte slots per (channel, parity, row) region of the R tile
+
+template <int DT, bool FUSED, bool ISMIN>
+__global__ void __launch_bounds__(256)
+corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out, int C,
+                int H, int W, int D, int d_base, int64_t out_bstride) {
+    constexpr int RY = kCorrRY, TX = kCorrTX, CC = kCorrCC, RS = kCorrRS;
+    constexpr int DPAD = 4 * DT;          // disparities covered by the 4 waves of this workgroup
+    constexpr int RW = DPAD + TX;         // R tile row width (floats), starts at x0 - d_base - DPAD + 1 - 1
+    constexpr int NW = DT / 4 + 2;        // 16-byte chunks in a lane's R window (DT + 8 floats)
+    static_assert(DT % 4 == 0 && DT >= 4 && DT <= 16, "DT must be 4, 8, 12 or 16");
+    static_assert(RW / 8 <= RS, "R region too small");
+
+    __shared__ __attribute__((aligned(16))) float sR[CC * 2 * RY * RS * 4];   // [c][parity][row][slot][4]
+    __shared__ __attribute__((aligned(16))) float sL[CC * 2 * RY * 16 * 4];   // [c][parity][row][slot][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, dg = tid >> 6;
+    const int r = lane >> 4, xg = lane & 15;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z;
+    const int64_t plane = (int64_t)H * W;
+    const float* __restrict__ lb = left + (int64_t)n * C * plane;
+    const float* __restrict__ rb = right + (int64_t)n * C * plane;
+
+    float acc[8][DT];
+#pragma unroll
+    for (int pq = 0; pq < 8; pq++)
+#pragma unroll
+        for (int q = 0; q < DT; q++) acc[pq][q] = 0.f;
+
+    // R tile float index i in [0, RW) <-> right-image column x0 - d_base - DPAD + i.
+    // Lane window = floats [8*xg + DT*(3-dg), +DT+8)  ->  first chunk g0 = 2*xg + q0.
+    const int q0 = (DT / 4) * (3 - dg);
+
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        __syncthreads();
+        for (int idx = tid; idx < CC * RY * RW; idx += 256) {
+            const int c = idx / (RY * RW);
+            const int rem = idx - c * (RY * RW);
+            const int rr = rem / RW, i = rem - rr * RW;
+            const int gx = x0 - d_base - DPAD + i, gy = y0 + rr;
+            float v = 0.f;
+            if (c0 + c < C && gy < H && gx >= 0 && gx < W) v = rb[(int64_t)(c0 + c) * plane + (int64_t)gy * W + gx];
+            sR[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * RS + (i >> 3)) * 4 + (i & 3)] = v;
+        }
+        for (int idx = tid; idx < CC * RY * TX; idx += 256) {
+            const int c = idx / (RY * TX);
+            const int rem = idx - c * (RY * TX);
+            const int rr = rem / TX, i = rem - rr * TX;
+            const int gx = x0 + i, gy = y0 + rr;
+            float v = 0.f;
+            if (c0 + c < C && gy < H && gx < W) v = lb[(int64_t)(c0 + c) * plane + (int64_t)gy * W + gx];
+            sL[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * 16 + (i >> 3)) * 4 + (i & 3)] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int c = 0; c < CC; c++) {
+            float lv[8], rw[DT + 8];
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(&sL[(((c * 2 + 0) * RY + r) * 16 + xg) * 4]);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(&sL[(((c * 2 + 1) * RY + r) * 16 + xg) * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { lv[e] = l0[e]; lv[4 + e] = l1[e]; }
+#pragma unroll
+            for (int t = 0; t < NW; t++) {
+                const int g = q0 + t;   // wave-uniform
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&sR[(((c * 2 + (g & 1)) * RY + r) * RS + xg + (g >> 1)) * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) rw[4 * t + e] = v[e];
+            }
+            // pixel pq, disparity q (d = d_base + DT*dg + q): R column = window float pq - q + DT
+#pragma unroll
+            for (int pq = 0; pq < 8; pq++)
+#pragma unroll
+                for (int q = 0; q < DT; q++) acc[pq][q] = fmaf(lv[pq], rw[pq - q + DT], acc[pq][q]);
+        }
+    }
+
+    const int gy = y0 + r;
+    const int gx0 = x0 + 8 * xg;
+    if (!FUSED) {
+        // cv[n][d][y][x]; x < d comes out as 0 because the R tile is zero-filled left of column 0.
+        if (gy < H) {
+#pragma unroll
+            for (int q = 0; q < DT; q++) {
+                const int d = d_base + DT * dg + q;
+                if (d < D) {
+                    float* o = out + (int64_t)n * out_bstride + (int64_t)d * plane + (int64_t)gy * W + gx0;
+#pragma unroll
+                    for (int pq = 0; pq < 8; pq++)
+                        if (gx0 + pq < W) o[pq] = acc[pq][q];
+                }
+            }
+        }
+    } else {
+        // per-lane soft-argmax partials over this wave's DT disparities, then combine the 4 waves via LDS
+        __syncthreads();                       // all waves are done with sR
+        float* red = sR;                       // [3][4 waves][RY*TX]
+        constexpr int NPX = RY * TX;
+#pragma unroll
+        for (int pq = 0; pq < 8; pq++) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < DT; q++) {
+                const int d = d_base + DT * dg + q;
+                const float v = ISMIN ? -acc[pq][q] : acc[pq][q];
+                if (d < D) m = fmaxf(m, v);
+            }
+            float s = 0.f, ws = 0.f;
+#pragma unroll
+            for (int q = 0; q < DT; q++) {
+                const int d = d_base + DT * dg + q;
+                const float v = ISMIN ? -acc[pq][q] : acc[pq][q];
+                if (d < D) {
+                    const float e = expf(v - m);
+                    s += e;
+                    ws += e * (float)d;
+                }
+            }
+            const int px = r * TX + 8 * xg + pq;
+            red[(0 * 4 + dg) * NPX + px] = m;
+            red[(1 * 4 + dg) * NPX + px] = s;
+            red[(2 * 4 + dg) * NPX + px] = ws;
+        }
+        __syncthreads();
+        for (int px = tid; px < NPX; px += 256) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) m = fmaxf(m, red[(0 * 4 + w4) * NPX + px]);
+            float s = 0.f, ws = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) {
+                const float mw = red[(0 * 4 + w4) * NPX + px];
+                const float sc = mw == -INFINITY ? 0.f : expf(mw - m);
+                s += red[(1 * 4 + w4) * NPX + px] * sc;
+                ws += red[(2 * 4 + w4) * NPX + px] * sc;
+            }
+            const int yy = y0 + px / TX, xx = x0 + px % TX;
+            if (yy < H && xx < W) out[(int64_t)n * out_bstride + (int64_t)yy * W + xx] = ws / s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Default (concatenation) cost volume: (N,C,H,W) x2 -> (N,D,2C,H,W).  Pure store bandwidth:
+// every lane reads its L value once and streams D + D coalesced stores.
+// grid = (ceil(W/256), H, N*C)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cost_volume_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out,
+                       int C, int H, int W, int D) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int c = blockIdx.z % C, n = blockIdx.z / C;
+    if (x >= W) return;
+    const int64_t plane = (int64_t)H * W;
+    const int64_t src = ((int64_t)n * C + c) * plane + (int64_t)y * W + x;
+    const float lv = left[src];
+    const float* rrow = right + src;
+    float* ol = out + (((int64_t)n * D) * 2 * C + c) * plane + (int64_t)y * W + x;
+    float* orr = ol + (int64_t)C * plane;
+    const int64_t dstride = 2 * (int64_t)C * plane;
+    for (int d = 0; d < D; d++) {
+        ol[d * dstride] = lv;
+        orr[d * dstride] = x >= d ? rrow[-d] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Soft-argmax / soft-argmin over D: one pass, online softmax in registers, coalesced along W.
+// grid = (ceil(H*W/256), N)
+// ------------------------------------------------------------------------------------------------
+template <bool ISMIN>
+__global__ void __launch_bounds__(256)
+softargmax_f32_kernel(const float* __restrict__ vol, float* __restrict__ out, int D, int64_t HW) {
+    const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (px >= HW) return;
+    const float* v = vol + (int64_t)n * D * HW + px;
+    float m = -INFINITY, s = 0.f, ws = 0.f;
+    for (int d0 = 0; d0 < D; d0 += 8) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float t = d0 + j < D ? v[(int64_t)(d0 + j) * HW] : 0.f;
+            xv[j] = d0 + j < D ? (ISMIN ? -t : t) : -INFINITY;
+        }
+        float cm = xv[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) cm = fmaxf(cm, xv[j]);
+        const float mn = fmaxf(m, cm);
+        const float sc = m == -INFINITY ? 0.f : expf(m - mn);
+        s *= sc;
+        ws *= sc;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float e = expf(xv[j] - mn);      // exp(-inf) = 0 for the masked tail
+            s += e;
+            ws += e * (float)(d0 + j);
+        }
+        m = mn;
+    }
+    out[(int64_t)n * HW + px] = ws / s;
+}
+
+}  // namespace rt

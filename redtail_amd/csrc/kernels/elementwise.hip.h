@@ -1,0 +1,58 @@
+// Element-wise kernels: ELU, add(+activation), sigmoid.  HBM-bound: 16-byte accesses per lane,
+// grid-stride, 2 loads + 1 store in flight per iteration.
+#pragma once
+#include "common.hip.h"
+
+namespace rt {
+
+// y = act(a [+ b]);  VEC floats per lane per iteration (4 => dwordx4).  Requires 16-B aligned
+// pointers when VEC == 4; the launcher falls back to VEC == 1 otherwise.
+template <int VEC, bool ADD>
+__global__ void __launch_bounds__(256) ew_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ y, int64_t n, int act) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+    if (VEC == 4) {
+        for (; i + 3 < n; i += stride) {
+            f32x4 va = *reinterpret_cast<const f32x4*>(a + i);
+            if (ADD) va += *reinterpret_cast<const f32x4*>(b + i);
+            f32x4 r;
+            for (int j = 0; j < 4; j++) r[j] = apply_act_rt(va[j], act);
+            *reinterpret_cast<f32x4*>(y + i) = r;
+        }
+        if (i < n)   // the single lane that owns the ragged tail (n % 4 elements)
+            for (int64_t j = i; j < n; j++) y[j] = apply_act_rt(ADD ? a[j] + b[j] : a[j], act);
+    } else {
+        for (; i < n; i += stride) y[i] = apply_act_rt(ADD ? a[i] + b[i] : a[i], act);
+    }
+}
+
+// fp16 storage, fp32 math; 8 halfs (16 B) per lane.
+template <int VEC, bool ADD>
+__global__ void __launch_bounds__(256) ew_f16_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                                     _Float16* __restrict__ y, int64_t n, int act) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+    if (VEC == 8) {
+        for (; i + 7 < n; i += stride) {
+            f16x8 va = *reinterpret_cast<const f16x8*>(a + i);
+            f16x8 vb = va;
+            if (ADD) vb = *reinterpret_cast<const f16x8*>(b + i);
+            f16x8 r;
+            for (int j = 0; j < 8; j++) {
+                float v = (float)va[j];
+                if (ADD) v += (float)vb[j];
+                r[j] = (_Float16)apply_act_rt(v, act);
+            }
+            *reinterpret_cast<f16x8*>(y + i) = r;
+        }
+        if (i < n)
+            for (int64_t j = i; j < n; j++)
+                y[j] = (_Float16)apply_act_rt(ADD ? (float)a[j] + (float)b[j] : (float)a[j], act);
+    } else {
+        for (; i < n; i += stride)
+            y[i] = (_Float16)apply_act_rt(ADD ? (float)a[i] + (float)b[i] : (float)a[i], act);
+    }
+}
+
+}  // namespace rt

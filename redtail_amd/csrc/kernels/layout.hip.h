@@ -1,0 +1,41 @@
+// Layout glue kernels of the 3-D models (Transform / Padding / Slice plugins, channel concat).
+// The fusing executor elides most of these; they exist so that the plugin API keeps its meaning.
+#pragma once
+#include "common.hip.h"
+
+namespace rt {
+
+// Copy `rows` segments of `len` elements: dst[r*dstride + i] = src[r*sstride + i]; optional zero tail
+// of `ztail` elements after each segment (PaddingPlugin).  16-byte path when everything is aligned.
+template <typename T>
+__global__ void __launch_bounds__(256)
+copy_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t len, int64_t sstride, int64_t dstride,
+                 int64_t ztail) {
+    const int64_t row = blockIdx.y;
+    const T* s = src + row * sstride;
+    T* d = dst + row * dstride;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len + ztail; i += stride)
+        d[i] = i < len ? s[i] : (T)0;
+}
+
+// Generic 4-D permute (plus batch): y dims = x dims permuted by `order`; thread per output element,
+// coalesced on the output side.
+template <typename T>
+__global__ void __launch_bounds__(256)
+permute4d_kernel(const T* __restrict__ x, T* __restrict__ y, int o0, int o1, int o2, int o3, int64_t s0, int64_t s1,
+                 int64_t s2, int64_t s3, int64_t total) {
+    // o* = output dims, s* = input stride (elements) of the input dim that feeds output dim *
+    const int64_t n = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        int64_t t = i;
+        const int i3 = (int)(t % o3); t /= o3;
+        const int i2 = (int)(t % o2); t /= o2;
+        const int i1 = (int)(t % o1); t /= o1;
+        const int i0 = (int)t;
+        y[n * total + i] = x[n * total + i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+    }
+}
+
+}  // namespace rt

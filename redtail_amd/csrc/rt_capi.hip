@@ -1,0 +1,757 @@
+// C-ABI of the MI355X kernels (include/rt_stereo.h): argument checking, launch geometry, weight
+// re-packing and gather-table construction.  No CPU compute path exists here on purpose: if there is
+// no HIP device every entry point fails with a non-zero status.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_stereo.h"
+#include "kernels/common.hip.h"
+#include "kernels/conv_mfma.hip.h"
+#include "kernels/cost_volume.hip.h"
+#include "kernels/elementwise.hip.h"
+#include "kernels/layout.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail((int)e, "%s: HIP error %d (%s: %s)", what, (int)e, hipGetErrorName(e), hipGetErrorString(e));
+}
+
+#define RT_HIP(call)                                        \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+    } while (0)
+
+#define RT_LAUNCH_CHECK(what)                               \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) return hip_fail(e_, what);    \
+    } while (0)
+
+#define RT_REQUIRE(cond, ...)                               \
+    do {                                                    \
+        if (!(cond)) return fail(RT_E_BADARG, __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t S(rtStream s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline unsigned ew_blocks(int64_t n, int vec) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(rt::cdiv(n, 256 * (int64_t)vec), 256 * 16));
+}
+
+int launch_ew(const void* a, const void* b, void* y, int64_t n, int act, int dtype, bool add, hipStream_t st) {
+    if (n == 0) return 0;
+    RT_REQUIRE(a && y && (!add || b) && n > 0, "elementwise: null pointer or negative size");
+    const bool al = aligned16(a) && aligned16(y) && (!add || aligned16(b));
+    if (dtype == RT_F32) {
+        auto pa = static_cast<const float*>(a);
+        auto pb = static_cast<const float*>(b);
+        auto py = static_cast<float*>(y);
+        if (al) {
+            if (add) hipLaunchKernelGGL((rt::ew_f32_kernel<4, true>), dim3(ew_blocks(n, 4)), dim3(256), 0, st, pa, pb, py, n, act);
+            else hipLaunchKernelGGL((rt::ew_f32_kernel<4, false>), dim3(ew_blocks(n, 4)), dim3(256), 0, st, pa, pb, py, n, act);
+        } else {
+            if (add) hipLaunchKernelGGL((rt::ew_f32_kernel<1, true>), dim3(ew_blocks(n, 1)), dim3(256), 0, st, pa, pb, py, n, act);
+            else hipLaunchKernelGGL((rt::ew_f32_kernel<1, false>), dim3(ew_blocks(n, 1)), dim3(256), 0, st, pa, pb, py, n, act);
+        }
+    } else if (dtype == RT_F16) {
+        auto pa = static_cast<const _Float16*>(a);
+        auto pb = static_cast<const _Float16*>(b);
+        auto py = static_cast<_Float16*>(y);
+        if (al) {
+            if (add) hipLaunchKernelGGL((rt::ew_f16_kernel<8, true>), dim3(ew_blocks(n, 8)), dim3(256), 0, st, pa, pb, py, n, act);
+            else hipLaunchKernelGGL((rt::ew_f16_kernel<8, false>), dim3(ew_blocks(n, 8)), dim3(256), 0, st, pa, pb, py, n, act);
+        } else {
+            if (add) hipLaunchKernelGGL((rt::ew_f16_kernel<1, true>), dim3(ew_blocks(n, 1)), dim3(256), 0, st, pa, pb, py, n, act);
+            else hipLaunchKernelGGL((rt::ew_f16_kernel<1, false>), dim3(ew_blocks(n, 1)), dim3(256), 0, st, pa, pb, py, n, act);
+        }
+    } else {
+        return fail(RT_E_UNSUPPORTED, "elementwise: dtype %d not supported", dtype);
+    }
+    RT_LAUNCH_CHECK("elementwise kernel");
+    return 0;
+}
+
+size_t dsize(int dtype) { return dtype == RT_F16 ? 2 : 4; }
+
+template <typename T>
+int launch_copy_rows(const void* src, void* dst, int64_t rows, int64_t len, int64_t sstride, int64_t dstride,
+                     int64_t ztail, hipStream_t st) {
+    if (rows == 0 || len + ztail == 0) return 0;
+    RT_REQUIRE(rows <= 65535, "copy: more than 65535 rows");
+    const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(rt::cdiv(len + ztail, 256), 2048));
+    hipLaunchKernelGGL((rt::copy_rows_kernel<T>), dim3(bx, (unsigned)rows), dim3(256), 0, st, static_cast<const T*>(src),
+                       static_cast<T*>(dst), len, sstride, dstride, ztail);
+    RT_LAUNCH_CHECK("copy_rows kernel");
+    return 0;
+}
+
+int copy_rows(const void* src, void* dst, int64_t rows, int64_t len, int64_t sstride, int64_t dstride, int64_t ztail,
+              int dtype, hipStream_t st) {
+    if (dtype == RT_F32) return launch_copy_rows<float>(src, dst, rows, len, sstride, dstride, ztail, st);
+    if (dtype == RT_F16) return launch_copy_rows<_Float16>(src, dst, rows, len, sstride, dstride, ztail, st);
+    return fail(RT_E_UNSUPPORTED, "copy: dtype %d not supported", dtype);
+}
+
+}  // namespace
+
+// =================================================================================================
+// library / device
+// =================================================================================================
+extern "C" const char* rt_last_error_string(void) { return g_err.c_str(); }
+
+extern "C" const char* rt_backend_name(void) {
+    static thread_local char name[320];
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        snprintf(name, sizeof(name), "hip:none");
+        return name;
+    }
+    snprintf(name, sizeof(name), "hip:%s (%s)", prop.gcnArchName, prop.name);
+    return name;
+}
+
+extern "C" int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int rt_set_device(int ordinal) { RT_HIP(hipSetDevice(ordinal)); return 0; }
+extern "C" int rt_malloc(void** dptr, size_t bytes) {
+    RT_REQUIRE(dptr, "rt_malloc: null out pointer");
+    RT_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+extern "C" int rt_free(void* dptr) { if (dptr) RT_HIP(hipFree(dptr)); return 0; }
+extern "C" int rt_memcpy_h2d(void* dst, const void* src, size_t bytes, rtStream s) {
+    if (bytes) RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(s)));
+    return 0;
+}
+extern "C" int rt_memcpy_d2h(void* dst, const void* src, size_t bytes, rtStream s) {
+    if (bytes) RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(s)));
+    return 0;
+}
+extern "C" int rt_memcpy_d2d(void* dst, const void* src, size_t bytes, rtStream s) {
+    if (bytes) RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
+    return 0;
+}
+extern "C" int rt_memset(void* dst, int value, size_t bytes, rtStream s) {
+    if (bytes) RT_HIP(hipMemsetAsync(dst, value, bytes, S(s)));
+    return 0;
+}
+extern "C" int rt_stream_create(rtStream* s) {
+    RT_REQUIRE(s, "rt_stream_create: null");
+    hipStream_t st;
+    RT_HIP(hipStreamCreate(&st));
+    *s = st;
+    return 0;
+}
+extern "C" int rt_stream_destroy(rtStream s) { RT_HIP(hipStreamDestroy(S(s))); return 0; }
+extern "C" int rt_stream_sync(rtStream s) { RT_HIP(hipStreamSynchronize(S(s))); return 0; }
+extern "C" int rt_event_create(void** ev) {
+    RT_REQUIRE(ev, "rt_event_create: null");
+    hipEvent_t e;
+    RT_HIP(hipEventCreate(&e));
+    *ev = e;
+    return 0;
+}
+extern "C" int rt_event_destroy(void* ev) { RT_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+extern "C" int rt_event_record(void* ev, rtStream s) { RT_HIP(hipEventRecord((hipEvent_t)ev, S(s))); return 0; }
+extern "C" int rt_event_elapsed_ms(void* a, void* b, float* ms) {
+    RT_REQUIRE(ms, "rt_event_elapsed_ms: null");
+    RT_HIP(hipEventSynchronize((hipEvent_t)b));
+    RT_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return 0;
+}
+
+// =================================================================================================
+// element-wise
+// =================================================================================================
+extern "C" int rt_elu(const void* x, void* y, int64_t n, int dtype, rtStream s) {
+    return launch_ew(x, nullptr, y, n, RT_ACT_ELU, dtype, false, S(s));
+}
+extern "C" int rt_add_act(const void* a, const void* b, void* y, int64_t n, int act, int dtype, rtStream s) {
+    RT_REQUIRE(act >= 0 && act <= 2, "rt_add_act: bad activation %d", act);
+    return launch_ew(a, b, y, n, act, dtype, true, S(s));
+}
+extern "C" int rt_activation(const void* x, void* y, int64_t n, int act, int dtype, rtStream s) {
+    RT_REQUIRE(act >= 0 && act <= 2, "rt_activation: bad activation %d", act);
+    return launch_ew(x, nullptr, y, n, act, dtype, false, S(s));
+}
+
+// =================================================================================================
+// cost volumes / soft-argmax
+// =================================================================================================
+namespace {
+template <bool FUSED, bool ISMIN>
+int launch_corr(const float* l, const float* r, float* out, int batch, int C, int H, int W, int D, int64_t obs,
+                hipStream_t st) {
+    const int dt = std::min(16, rt::round_up((int)rt::cdiv(D, 4), 4));
+    if (FUSED && D > 4 * dt) return fail(RT_E_UNSUPPORTED, "fused corr+softargmax supports max_disp <= 64 (got %d)", D);
+    dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)batch);
+    for (int d_base = 0; d_base < D; d_base += 4 * dt) {
+        switch (dt) {
+            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs); break;
+            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs); break;
+            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs); break;
+            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs); break;
+        }
+        RT_LAUNCH_CHECK("corr cost volume kernel");
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int rt_corr_cost_volume(const void* left, const void* right, void* cv, int batch, int C, int H, int W,
+                                   int D, int dtype, int format, rtStream s) {
+    RT_REQUIRE(left && right && cv, "rt_corr_cost_volume: null pointer");
+    RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_cost_volume: bad dims");
+    if (dtype != RT_F32 || format != RT_NCHW)
+        return fail(RT_E_UNSUPPORTED, "rt_corr_cost_volume: only fp32 NCHW in this build (dtype %d format %d)", dtype, format);
+    return launch_corr<false, false>(static_cast<const float*>(left), static_cast<const float*>(right),
+                                     static_cast<float*>(cv), batch, C, H, W, D, (int64_t)D * H * W, S(s));
+}
+
+extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,
+                                  int D, int is_min, int64_t out_bstride, int dtype, rtStream s) {
+    RT_REQUIRE(left && right && out, "rt_corr_softargmax: null pointer");
+    RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax: bad dims");
+    if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax: only fp32 in this build");
+    if (out_bstride == 0) out_bstride = (int64_t)H * W;
+    auto l = static_cast<const float*>(left);
+    auto r = static_cast<const float*>(right);
+    auto o = static_cast<float*>(out);
+    return is_min ? launch_corr<true, true>(l, r, o, batch, C, H, W, D, out_bstride, S(s))
+                  : launch_corr<true, false>(l, r, o, batch, C, H, W, D, out_bstride, S(s));
+}
+
+extern "C" int rt_cost_volume(const void* left, const void* right, void* cv, int batch, int C, int H, int W, int D,
+                              int dtype, rtStream s) {
+    RT_REQUIRE(left && right && cv, "rt_cost_volume: null pointer");
+    RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_cost_volume: bad dims");
+    RT_REQUIRE(H <= 65535 && (int64_t)batch * C <= 65535, "rt_cost_volume: grid too large");
+    if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_cost_volume: only fp32 (as the reference, kernels.cu:140)");
+    dim3 grid((unsigned)rt::cdiv(W, 256), (unsigned)H, (unsigned)(batch * C));
+    hipLaunchKernelGGL(rt::cost_volume_f32_kernel, grid, dim3(256), 0, S(s), static_cast<const float*>(left),
+                       static_cast<const float*>(right), static_cast<float*>(cv), C, H, W, D);
+    RT_LAUNCH_CHECK("cost volume kernel");
+    return 0;
+}
+
+extern "C" int rt_softargmax(const void* vol, void* out, int batch, int D, int H, int W, int is_min, int dtype,
+                             rtStream s) {
+    RT_REQUIRE(vol && out, "rt_softargmax: null pointer");
+    RT_REQUIRE(batch > 0 && D > 0 && H > 0 && W > 0 && batch <= 65535, "rt_softargmax: bad dims");
+    if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_softargmax: only fp32 in this build");
+    const int64_t hw = (int64_t)H * W;
+    dim3 grid((unsigned)rt::cdiv(hw, 256), (unsigned)batch);
+    if (is_min)
+        hipLaunchKernelGGL((rt::softargmax_f32_kernel<true>), grid, dim3(256), 0, S(s), static_cast<const float*>(vol),
+                           static_cast<float*>(out), D, hw);
+    else
+        hipLaunchKernelGGL((rt::softargmax_f32_kernel<false>), grid, dim3(256), 0, S(s), static_cast<const float*>(vol),
+                           static_cast<float*>(out), D, hw);
+    RT_LAUNCH_CHECK("softargmax kernel");
+    return 0;
+}
+
+// =================================================================================================
+// layout glue
+// =================================================================================================
+extern "C" int rt_permute4d(const void* x, void* y, int batch, int d0, int d1, int d2, int d3, const int order[4],
+                            int dtype, rtStream s) {
+    RT_REQUIRE(x && y && order, "rt_permute4d: null pointer");
+    RT_REQUIRE(batch > 0 && batch <= 65535 && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "rt_permute4d: bad dims");
+    int seen = 0;
+    for (int i = 0; i < 4; i++) {
+        RT_REQUIRE(order[i] >= 0 && order[i] < 4, "rt_permute4d: bad order");
+        seen |= 1 << order[i];
+    }
+    RT_REQUIRE(seen == 15, "rt_permute4d: order is not a permutation");
+    const int in_dims[4] = {d0, d1, d2, d3};
+    const int64_t in_str[4] = {(int64_t)d1 * d2 * d3, (int64_t)d2 * d3, (int64_t)d3, 1};
+    const int64_t total = in_str[0] * d0;
+    const int o[4] = {in_dims[order[0]], in_dims[order[1]], in_dims[order[2]], in_dims[order[3]]};
+    const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(rt::cdiv(total, 256), 4096));
+    dim3 grid(bx, (unsigned)batch);
+    if (dtype == RT_F32)
+        hipLaunchKernelGGL((rt::permute4d_kernel<float>), grid, dim3(256), 0, S(s), static_cast<const float*>(x),
+                           static_cast<float*>(y), o[0], o[1], o[2], o[3], in_str[order[0]], in_str[order[1]],
+                           in_str[order[2]], in_str[order[3]], total);
+    else if (dtype == RT_F16)
+        hipLaunchKernelGGL((rt::permute4d_kernel<_Float16>), grid, dim3(256), 0, S(s), static_cast<const _Float16*>(x),
+                           static_cast<_Float16*>(y), o[0], o[1], o[2], o[3], in_str[order[0]], in_str[order[1]],
+                           in_str[order[2]], in_str[order[3]], total);
+    else
+        return fail(RT_E_UNSUPPORTED, "rt_permute4d: dtype %d", dtype);
+    RT_LAUNCH_CHECK("permute kernel");
+    return 0;
+}
+
+extern "C" int rt_pad_d(const void* x, void* y, int batch, int D, int64_t inner, int pad_end, int dtype, rtStream s) {
+    RT_REQUIRE(x && y && batch > 0 && D > 0 && inner > 0 && pad_end >= 0, "rt_pad_d: bad arguments");
+    return copy_rows(x, y, batch, D * inner, D * inner, (D + pad_end) * inner, pad_end * inner, dtype, S(s));
+}
+
+extern "C" int rt_slice_d(const void* x, void* y, int batch, int D, int64_t inner, int start, int end, int dtype,
+                          rtStream s) {
+    RT_REQUIRE(x && y && batch > 0 && inner > 0, "rt_slice_d: bad arguments");
+    RT_REQUIRE(0 <= start && start < end && end <= D, "rt_slice_d: bad range [%d,%d) of %d", start, end, D);
+    const char* src = static_cast<const char*>(x) + (size_t)start * inner * dsize(dtype);
+    return copy_rows(src, y, batch, (end - start) * inner, D * inner, (end - start) * inner, 0, dtype, S(s));
+}
+
+extern "C" int rt_concat_channels(const void* x, void* y, int batch, int C, int Ctot, int c_off, int64_t inner,
+                                  int dtype, rtStream s) {
+    RT_REQUIRE(x && y && batch > 0 && C > 0 && inner > 0, "rt_concat_channels: bad arguments");
+    RT_REQUIRE(c_off >= 0 && c_off + C <= Ctot, "rt_concat_channels: channel range out of bounds");
+    char* dst = static_cast<char*>(y) + (size_t)c_off * inner * dsize(dtype);
+    return copy_rows(x, dst, batch, C * inner, C * inner, Ctot * inner, 0, dtype, S(s));
+}
+
+// =================================================================================================
+// convolutions
+// =================================================================================================
+namespace {
+
+constexpr int kTY = 4, kTXW = 2;   // 4 rows x 64 pixels per workgroup
+
+struct SubConv {                    // one launch of conv_mfma_f32_kernel
+    int KH = 1, KW = 1, S = 1, NBW = 1, CC = 8;
+    int CinPad = 0, Cout = 0;
+    int Hi = 0, Wi = 0, Ho = 0, Wo = 0, pad_y = 0, pad_x = 0, nz = 1;
+    int64_t y_cstride = 0, y_zstride = 0, y_off = 0;
+    int y_ystride = 0, y_xstride = 1;
+    float* w_dev = nullptr;
+    int* choff_dev = nullptr;
+};
+
+}  // namespace
+
+struct rtConvPlan {
+    std::vector<SubConv> subs;
+    float* bias_dev = nullptr;
+    int act = 0, has_resid = 0, dtype = RT_F32;
+    int out_dims[4] = {0, 0, 0, 1};
+    int64_t x_bstride = 0, y_bstride = 0;
+};
+
+namespace {
+
+// 1-D decomposition of a transposed convolution (scatter: o = i*s + r - p) into `s` dense
+// correlations, one per output phase phi = o mod s:  i = m + u - pad,  r = tap[u]  (o = m*s + phi).
+struct Phase1D {
+    int K = 0;          // taps in the window (0: this phase receives no contribution)
+    int pad = 0;
+    int tap[8] = {0};
+};
+Phase1D phase1d(int s, int p, int k, int phi) {
+    Phase1D ph;
+    int r0 = -1;
+    for (int r = k - 1; r >= 0; r--)
+        if (((r - (phi + p)) % s + s) % s == 0) { r0 = r; break; }
+    if (r0 < 0) return ph;
+    // base = (phi + p - r0) / s  (exact);  i = m + base + u
+    ph.pad = -((phi + p - r0) / s);
+    for (int r = r0; r >= 0; r -= s) ph.tap[ph.K++] = r;
+    return ph;
+}
+
+// Packs weights for one launch: [nblk][chunk][tap][CC][NB]; wfun(co, ci, u, v) returns the weight of
+// output channel co, gathered channel ci, window tap (u, v).
+template <typename F>
+int upload_packed(SubConv& sc, int cin_real, F wfun) {
+    const int NB = 32 * sc.NBW, taps = sc.KH * sc.KW;
+    const int nblk = (int)rt::cdiv(sc.Cout, NB), nch = sc.CinPad / sc.CC;
+    std::vector<float> packed((size_t)nblk * nch * taps * sc.CC * NB, 0.f);
+    for (int nb = 0; nb < nblk; nb++)
+        for (int ch = 0; ch < nch; ch++)
+            for (int u = 0; u < sc.KH; u++)
+                for (int v = 0; v < sc.KW; v++)
+                    for (int cc = 0; cc < sc.CC; cc++) {
+                        const int ci = ch * sc.CC + cc;
+                        if (ci >= cin_real) continue;
+                        float* dst = &packed[((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * sc.CC + cc) * NB];
+                        for (int nn = 0; nn < NB; nn++) {
+                            const int co = nb * NB + nn;
+                            if (co < sc.Cout) dst[nn] = wfun(co, ci, u, v);
+                        }
+                    }
+    RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * sizeof(float)));
+    RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_table(SubConv& sc, const std::vector<int>& table) {
+    RT_HIP(hipMalloc((void**)&sc.choff_dev, table.size() * sizeof(int)));
+    RT_HIP(hipMemcpy(sc.choff_dev, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_bias(rtConvPlan* plan, const float* bias, int n) {
+    if (!bias) return 0;
+    RT_HIP(hipMalloc((void**)&plan->bias_dev, n * sizeof(float)));
+    RT_HIP(hipMemcpy(plan->bias_dev, bias, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+bool window_supported(int KH, int KW, int S) {
+    if (S == 1) return (KH == 3 && KW == 3) || (KH <= 2 && KW <= 2 && KH >= 1 && KW >= 1);
+    if (S == 2) return (KH == 3 && KW == 3) || (KH == 5 && KW == 5);
+    return false;
+}
+
+void choose_tiling(SubConv& sc) {
+    sc.NBW = sc.Cout > 32 ? 2 : 1;
+    sc.CC = 8;
+    if (sc.KH == 5) { sc.NBW = 1; sc.CC = 4; }
+}
+
+// weights to host fp32 (fp16 weight files are widened once; activations stay fp32 in this build)
+std::vector<float> to_f32(const void* w, size_t n, int dtype) {
+    std::vector<float> out(n);
+    if (dtype == RT_F16) {
+        const _Float16* h = static_cast<const _Float16*>(w);
+        for (size_t i = 0; i < n; i++) out[i] = (float)h[i];
+    } else {
+        std::memcpy(out.data(), w, n * sizeof(float));
+    }
+    return out;
+}
+
+template <int KH, int KW, int S, int NBW, int CC>
+void launch_cfg(const rt::ConvArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, kTY, kTXW, NBW, CC>), grid, dim3(256), 0, st, a);
+}
+
+int launch_sub(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream_t st) {
+#define RT_CASE(kh, kw, s, nbw, cc)                                                             \
+    if (sc.KH == kh && sc.KW == kw && sc.S == s && sc.NBW == nbw && sc.CC == cc) {              \
+        launch_cfg<kh, kw, s, nbw, cc>(a, grid, st);                                            \
+        RT_LAUNCH_CHECK("conv_mfma_f32_kernel<" #kh "," #kw "," #s "," #nbw "," #cc ">");       \
+        return 0;                                                                               \
+    }
+    RT_CASE(3, 3, 1, 1, 8) RT_CASE(3, 3, 1, 2, 8)
+    RT_CASE(3, 3, 2, 1, 8) RT_CASE(3, 3, 2, 2, 8)
+    RT_CASE(5, 5, 2, 1, 4)
+    RT_CASE(1, 1, 1, 1, 8) RT_CASE(1, 1, 1, 2, 8)
+    RT_CASE(1, 2, 1, 1, 8) RT_CASE(1, 2, 1, 2, 8)
+    RT_CASE(2, 1, 1, 1, 8) RT_CASE(2, 1, 1, 2, 8)
+    RT_CASE(2, 2, 1, 1, 8) RT_CASE(2, 2, 1, 2, 8)
+#undef RT_CASE
+    return fail(RT_E_UNSUPPORTED, "conv: no kernel for window %dx%d stride %d", sc.KH, sc.KW, sc.S);
+}
+
+void free_plan(rtConvPlan* p) {
+    if (!p) return;
+    for (auto& s : p->subs) {
+        if (s.w_dev) (void)hipFree(s.w_dev);
+        if (s.choff_dev) (void)hipFree(s.choff_dev);
+    }
+    if (p->bias_dev) (void)hipFree(p->bias_dev);
+    delete p;
+}
+
+}  // namespace
+
+extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, const void* weights, const void* bias) {
+    RT_REQUIRE(out && d && weights, "rt_conv2d_plan_create: null pointer");
+    RT_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "rt_conv2d_plan_create: bad dims");
+    RT_REQUIRE(d->dtype == RT_F32 || d->dtype == RT_F16, "rt_conv2d_plan_create: bad dtype");
+    if (!window_supported(d->KH, d->KW, d->stride))
+        return fail(RT_E_UNSUPPORTED, "conv2d: window %dx%d stride %d not supported", d->KH, d->KW, d->stride);
+    const int Ho = (d->Hin + 2 * d->pad_h - d->KH) / d->stride + 1;
+    const int Wo = (d->Win + 2 * d->pad_w - d->KW) / d->stride + 1;
+    RT_REQUIRE(Ho > 0 && Wo > 0, "conv2d: empty output");
+    RT_REQUIRE((int64_t)d->Cin * d->Hin * d->Win < (1ll << 31), "conv2d: input sample exceeds 2^31 elements");
+
+    auto plan = new rtConvPlan();
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->out_dims[0] = d->Cout; plan->out_dims[1] = Ho; plan->out_dims[2] = Wo; plan->out_dims[3] = 1;
+    plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
+    plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
+
+    SubConv sc;
+    sc.KH = d->KH; sc.KW = d->KW; sc.S = d->stride;
+    sc.Cout = d->Cout; sc.Hi = d->Hin; sc.Wi = d->Win; sc.Ho = Ho; sc.Wo = Wo;
+    sc.pad_y = d->pad_h; sc.pad_x = d->pad_w; sc.nz = 1;
+    sc.y_cstride = (int64_t)Ho * Wo; sc.y_ystride = Wo; sc.y_xstride = 1;
+    choose_tiling(sc);
+    sc.CinPad = rt::round_up(d->Cin, sc.CC);
+    if (sc.CinPad > 512) { free_plan(plan); return fail(RT_E_UNSUPPORTED, "conv2d: Cin > 512"); }
+    const std::vector<float> w = to_f32(weights, (size_t)d->Cout * d->Cin * d->KH * d->KW, d->dtype);
+    const int Cin = d->Cin, KH = d->KH, KW = d->KW;
+    int rc = upload_packed(sc, Cin, [&](int co, int ci, int u, int v) {
+        return w[(((size_t)co * Cin + ci) * KH + u) * KW + v];          // KCRS
+    });
+    std::vector<int> table(sc.CinPad, -1);
+    for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
+    if (!rc) rc = upload_table(sc, table);
+    plan->subs.push_back(sc);
+    if (!rc && bias) {
+        const std::vector<float> b = to_f32(bias, d->Cout, d->dtype);
+        rc = upload_bias(plan, b.data(), d->Cout);
+    }
+    if (rc) { free_plan(plan); return rc; }
+    *out = plan;
+    return 0;
+}
+
+extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, const void* weights, const void* bias) {
+    RT_REQUIRE(out && d && weights, "rt_deconv2d_plan_create: null pointer");
+    RT_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "rt_deconv2d_plan_create: bad dims");
+    RT_REQUIRE(d->dtype == RT_F32 || d->dtype == RT_F16, "rt_deconv2d_plan_create: bad dtype");
+    if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1)) || d->stride < 1 || d->stride > 2)
+        return fail(RT_E_UNSUPPORTED, "deconv2d: only 3x3 / 1x1 kernels with stride 1 or 2");
+    const int s = d->stride;
+    const int Ho = (d->Hin - 1) * s - 2 * d->pad_h + d->KH;
+    const int Wo = (d->Win - 1) * s - 2 * d->pad_w + d->KW;
+    RT_REQUIRE(Ho > 0 && Wo > 0, "deconv2d: empty output");
+    RT_REQUIRE((int64_t)d->Cin * d->Hin * d->Win < (1ll << 31), "deconv2d: input sample exceeds 2^31 elements");
+
+    auto plan = new rtConvPlan();
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->out_dims[0] = d->Cout; plan->out_dims[1] = Ho; plan->out_dims[2] = Wo; plan->out_dims[3] = 1;
+    plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
+    plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
+    const std::vector<float> w = to_f32(weights, (size_t)d->Cin * d->Cout * d->KH * d->KW, d->dtype);
+    const int Cin = d->Cin, Cout = d->Cout, KH = d->KH, KW = d->KW;
+    int rc = 0;
+    for (int py = 0; py < s && !rc; py++)
+        for (int px = 0; px < s && !rc; px++) {
+            if (py >= Ho || px >= Wo) continue;
+            const Phase1D ay = phase1d(s, d->pad_h, KH, py), ax = phase1d(s, d->pad_w, KW, px);
+            SubConv sc;
+            const bool empty = ay.K == 0 || ax.K == 0;          // bias-only phase: 1x1 window, zero weights
+            sc.KH = empty ? 1 : ay.K; sc.KW = empty ? 1 : ax.K; sc.S = 1;
+            sc.Cout = Cout; sc.Hi = d->Hin; sc.Wi = d->Win;
+            sc.Ho = (Ho - py + s - 1) / s; sc.Wo = (Wo - px + s - 1) / s;
+            sc.pad_y = empty ? 0 : ay.pad; sc.pad_x = empty ? 0 : ax.pad; sc.nz = 1;
+            sc.y_cstride = (int64_t)Ho * Wo; sc.y_ystride = s * Wo; sc.y_xstride = s;
+            sc.y_off = (int64_t)py * Wo + px;
+            choose_tiling(sc);
+            sc.CinPad = rt::round_up(Cin, sc.CC);
+            if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "deconv2d: unsupported shape"); break; }
+            rc = upload_packed(sc, Cin, [&](int co, int ci, int u, int v) {
+                if (empty) return 0.f;
+                return w[(((size_t)ci * Cout + co) * KH + ay.tap[u]) * KW + ax.tap[v]];   // (Cin,Cout,R,S)
+            });
+            std::vector<int> table(sc.CinPad, -1);
+            for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
+            if (!rc) rc = upload_table(sc, table);
+            plan->subs.push_back(sc);
+        }
+    if (!rc && bias) {
+        const std::vector<float> b = to_f32(bias, Cout, d->dtype);
+        rc = upload_bias(plan, b.data(), Cout);
+    }
+    if (rc) { free_plan(plan); return rc; }
+    *out = plan;
+    return 0;
+}
+
+namespace {
+int check_conv3d_desc(const rtConv3dDesc* d, const char* who) {
+    RT_REQUIRE(d->C > 0 && d->K > 0 && d->D > 0 && d->H > 0 && d->W > 0, "%s: bad dims", who);
+    RT_REQUIRE(d->dtype == RT_F32 || d->dtype == RT_F16, "%s: bad dtype", who);
+    RT_REQUIRE(d->kernel[0] >= 1 && d->kernel[0] <= 8, "%s: bad kernel depth", who);
+    RT_REQUIRE(d->kernel[1] == d->kernel[2] && (d->kernel[1] == 1 || d->kernel[1] == 3), "%s: R,S must be 1x1 or 3x3", who);
+    RT_REQUIRE(d->stride[1] == d->stride[2] && d->stride[1] >= 1 && d->stride[1] <= 2, "%s: H/W stride must be equal, 1 or 2", who);
+    RT_REQUIRE(d->stride[0] >= 1 && d->stride[0] <= 2, "%s: D stride must be 1 or 2", who);
+    // same validation as the reference plugins (lib/conv3d_plugin.cpp:43-49)
+    RT_REQUIRE(d->pad_start[1] == d->pad_end[1] && d->pad_start[2] == d->pad_end[2], "%s: H/W padding must be symmetric", who);
+    RT_REQUIRE(d->pad_start[0] == d->pad_end[0] || d->pad_start[0] == d->pad_end[0] - 1, "%s: unsupported D padding", who);
+    return 0;
+}
+}  // namespace
+
+extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, const void* weights, const void* bias) {
+    RT_REQUIRE(out && d && weights, "rt_conv3d_plan_create: null pointer");
+    if (int rc = check_conv3d_desc(d, "rt_conv3d_plan_create")) return rc;
+    const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
+    const int sd = d->stride[0], sh = d->stride[1];
+    const int pd = d->pad_start[0], ph = d->pad_start[1], pw = d->pad_start[2];
+    // output dims exactly as cuDNN derives them from pad_start (lib/conv3d_plugin.cpp:74-100)
+    const int Do = (d->D + 2 * pd - V) / sd + 1, Ho = (d->H + 2 * ph - R) / sh + 1, Wo = (d->W + 2 * pw - Sk) / sh + 1;
+    RT_REQUIRE(Do > 0 && Ho > 0 && Wo > 0, "conv3d: empty output");
+    RT_REQUIRE((int64_t)d->D * d->C * d->H * d->W < (1ll << 31), "conv3d: input sample exceeds 2^31 elements");
+    if (!window_supported(R, Sk, sh)) return fail(RT_E_UNSUPPORTED, "conv3d: window %dx%d stride %d", R, Sk, sh);
+
+    auto plan = new rtConvPlan();
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    const int K = d->K, C = d->C;
+    if (d->out_dchw) { plan->out_dims[0] = Do; plan->out_dims[1] = K; }
+    else { plan->out_dims[0] = K; plan->out_dims[1] = Do; }
+    plan->out_dims[2] = Ho; plan->out_dims[3] = Wo;
+    plan->x_bstride = (int64_t)d->D * C * d->H * d->W;
+    plan->y_bstride = (int64_t)K * Do * Ho * Wo;
+
+    SubConv sc;
+    sc.KH = R; sc.KW = Sk; sc.S = sh; sc.Cout = K;
+    sc.Hi = d->H; sc.Wi = d->W; sc.Ho = Ho; sc.Wo = Wo; sc.pad_y = ph; sc.pad_x = pw; sc.nz = Do;
+    sc.y_ystride = Wo; sc.y_xstride = 1;
+    if (d->out_dchw) { sc.y_cstride = (int64_t)Ho * Wo; sc.y_zstride = (int64_t)K * Ho * Wo; }
+    else { sc.y_cstride = (int64_t)Do * Ho * Wo; sc.y_zstride = (int64_t)Ho * Wo; }
+    choose_tiling(sc);
+    const int cin_real = V * C;
+    sc.CinPad = rt::round_up(cin_real, sc.CC);
+    if (sc.CinPad > 512) { free_plan(plan); return fail(RT_E_UNSUPPORTED, "conv3d: V*C = %d > 512", cin_real); }
+    const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
+    int rc = upload_packed(sc, cin_real, [&](int co, int ci, int u, int v) {
+        return w[((size_t)co * cin_real + ci) * R * Sk + u * Sk + v];      // (K, V*C, R, S): ci = v*C + c
+    });
+    // gather table: z-slice `dz` reads input depth dz*sd + v - pd for tap v (the (D*C)-merged axis of
+    // lib/conv_utils.cpp:27-32 with its D stride/pad multiplied by C, :58-72); out-of-range depth = zeros.
+    std::vector<int> table((size_t)Do * sc.CinPad, -1);
+    const int64_t plane = (int64_t)d->H * d->W;
+    for (int dz = 0; dz < Do; dz++)
+        for (int v = 0; v < V; v++) {
+            const int din = dz * sd + v - pd;
+            if (din < 0 || din >= d->D) continue;
+            for (int c = 0; c < C; c++) table[(size_t)dz * sc.CinPad + v * C + c] = (int)(((int64_t)din * C + c) * plane);
+        }
+    if (!rc) rc = upload_table(sc, table);
+    plan->subs.push_back(sc);
+    if (!rc && bias) {
+        const std::vector<float> b = to_f32(bias, K, d->dtype);
+        rc = upload_bias(plan, b.data(), K);
+    }
+    if (rc) { free_plan(plan); return rc; }
+    *out = plan;
+    return 0;
+}
+
+extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dDesc* d, const int in_dims[3],
+                                               const void* weights, const void* bias) {
+    RT_REQUIRE(out && d && in_dims && weights, "rt_conv3d_transpose_plan_create: null pointer");
+    if (int rc = check_conv3d_desc(d, "rt_conv3d_transpose_plan_create")) return rc;
+    RT_REQUIRE(!d->out_dchw, "conv3d_transpose: output is always (D,C,H,W)");
+    const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
+    const int sd = d->stride[0], sh = d->stride[1];
+    const int pd = d->pad_start[0], ph = d->pad_start[1], pw = d->pad_start[2];
+    const int Dy = in_dims[0], Hy = in_dims[1], Wy = in_dims[2];
+    const int Dx = d->D, Hx = d->H, Wx = d->W, K = d->K, C = d->C;
+    // the reference verifies that the forward conv of the output gives the input dims
+    // (lib/conv3d_transpose_plugin.cpp:108-111)
+    RT_REQUIRE((Dx + 2 * pd - V) / sd + 1 == Dy && (Hx + 2 * ph - R) / sh + 1 == Hy && (Wx + 2 * pw - Sk) / sh + 1 == Wy,
+               "conv3d_transpose: out dims (%d,%d,%d) inconsistent with in dims (%d,%d,%d)", Dx, Hx, Wx, Dy, Hy, Wy);
+    RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 31), "conv3d_transpose: input sample exceeds 2^31 elements");
+
+    auto plan = new rtConvPlan();
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->out_dims[0] = Dx; plan->out_dims[1] = C; plan->out_dims[2] = Hx; plan->out_dims[3] = Wx;
+    plan->x_bstride = (int64_t)K * Dy * Hy * Wy;
+    plan->y_bstride = (int64_t)Dx * C * Hx * Wx;
+    const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
+    const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
+    int rc = 0;
+    for (int cls = 0; cls < sd && !rc; cls++) {          // output depths dx = cls, cls + sd, ...
+        if (cls >= Dx) continue;
+        const Phase1D az = phase1d(sd, pd, V, cls);
+        const int nz = (Dx - cls + sd - 1) / sd;
+        const int nv = std::max(az.K, 1);
+        for (int py = 0; py < sh && !rc; py++)
+            for (int px = 0; px < sh && !rc; px++) {
+                if (py >= Hx || px >= Wx) continue;
+                const Phase1D ay = phase1d(sh, ph, R, py), ax = phase1d(sh, pw, Sk, px);
+                const bool empty = az.K == 0 || ay.K == 0 || ax.K == 0;
+                SubConv sc;
+                sc.KH = empty ? 1 : ay.K; sc.KW = empty ? 1 : ax.K; sc.S = 1; sc.Cout = C;
+                sc.Hi = Hy; sc.Wi = Wy;
+                sc.Ho = (Hx - py + sh - 1) / sh; sc.Wo = (Wx - px + sh - 1) / sh;
+                sc.pad_y = empty ? 0 : ay.pad; sc.pad_x = empty ? 0 : ax.pad; sc.nz = nz;
+                sc.y_cstride = out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
+                sc.y_zstride = (int64_t)sd * C * out_plane;
+                sc.y_off = (int64_t)cls * C * out_plane + (int64_t)py * Wx + px;
+                choose_tiling(sc);
+                const int cin_real = nv * K;
+                sc.CinPad = rt::round_up(cin_real, sc.CC);
+                if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
+                rc = upload_packed(sc, cin_real, [&](int co, int ci, int u, int v) {
+                    if (empty) return 0.f;
+                    const int j = ci / K, k = ci % K;                        // gathered channel = (depth tap j, input channel k)
+                    return w[((((size_t)k * V + az.tap[j]) * C + co) * R + ay.tap[u]) * Sk + ax.tap[v]];   // KVCRS
+                });
+                // z-slice m <-> output depth dx = cls + m*sd, which reads input depth m + j - az.pad for tap j
+                std::vector<int> table((size_t)nz * sc.CinPad, -1);
+                if (!empty)
+                    for (int m = 0; m < nz; m++)
+                        for (int j = 0; j < az.K; j++) {
+                            const int dy = m + j - az.pad;
+                            if (dy < 0 || dy >= Dy) continue;
+                            for (int k = 0; k < K; k++)
+                                table[(size_t)m * sc.CinPad + j * K + k] = (int)(((int64_t)k * Dy + dy) * in_plane);
+                        }
+                if (!rc) rc = upload_table(sc, table);
+                plan->subs.push_back(sc);
+            }
+    }
+    if (!rc && bias) {
+        const std::vector<float> b = to_f32(bias, C, d->dtype);
+        rc = upload_bias(plan, b.data(), C);
+    }
+    if (rc) { free_plan(plan); return rc; }
+    *out = plan;
+    return 0;
+}
+
+extern "C" int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]) {
+    RT_REQUIRE(plan && dims, "rt_conv_plan_out_dims: null pointer");
+    for (int i = 0; i < 4; i++) dims[i] = plan->out_dims[i];
+    return 0;
+}
+
+extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
+                               rtStream s) {
+    RT_REQUIRE(plan && x && y, "rt_conv_enqueue: null pointer");
+    RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
+    RT_REQUIRE(!plan->has_resid || residual, "rt_conv_enqueue: plan expects a residual tensor");
+    for (const SubConv& sc : plan->subs) {
+        rt::ConvArgs a;
+        a.x = static_cast<const float*>(x);
+        a.y = static_cast<float*>(y);
+        a.w = sc.w_dev;
+        a.bias = plan->bias_dev;
+        a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
+        a.ch_off = sc.choff_dev;
+        a.CinPad = sc.CinPad; a.Cout = sc.Cout;
+        a.Hi = sc.Hi; a.Wi = sc.Wi; a.Ho = sc.Ho; a.Wo = sc.Wo;
+        a.pad_y = sc.pad_y; a.pad_x = sc.pad_x; a.nz = sc.nz;
+        a.tiles_x = (int)rt::cdiv(sc.Wo, 32 * kTXW);
+        a.act = plan->act;
+        a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
+        a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
+        a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
+        const int tiles_y = (int)rt::cdiv(sc.Ho, kTY);
+        const int64_t gz = (int64_t)batch * sc.nz;
+        RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
+        dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (int rc = launch_sub(sc, a, grid, S(s))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int rt_conv_plan_destroy(rtConvPlan* plan) {
+    free_plan(plan);
+    return 0;
+}

@@ -1,0 +1,177 @@
+"""C-ABI parity tests: every op of include/rt_stereo.h against the reference's golden tensors and the
+oracle.  Each test runs twice: on the SIMT emulator (CPU tier, same kernel sources) and, with -m gpu,
+on the MI355X through librt_stereo_hip.so.  Tolerances are the reference's own
+(/root/reference/stereoDNN/tests/tests_main.cpp, lines cited per test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import capi
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def near(actual, expected, tol):
+    a, e = np.asarray(actual, np.float32), np.asarray(expected, np.float32)
+    assert a.shape == e.shape, (a.shape, e.shape)
+    assert not np.isnan(a).any(), "output has unwritten / NaN elements"
+    err = np.abs(a - e).max() if a.size else 0.0
+    assert err <= tol, "max |diff| = %g > %g" % (err, tol)
+
+
+def float_eq(actual, expected, ulps=4):
+    a, e = np.asarray(actual, np.float32).ravel(), np.asarray(expected, np.float32).ravel()
+    assert a.shape == e.shape
+    assert not np.isnan(a).any()
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(e)).astype(np.float32))
+    assert (np.abs(a - e) <= tol).all(), "max |diff| %g" % np.abs(a - e).max()
+
+
+RNG = np.random.default_rng(1)
+
+
+def rnd(*shape):
+    return RNG.standard_normal(shape).astype(np.float32)
+
+
+# ---- ELU / element-wise (tests_main.cpp:280-342) --------------------------------------------------
+@pytest.mark.parametrize("idx", ["01", "02"])
+def test_elu_golden(backend, golden, idx):
+    x = backend.dev(golden["elu_i_" + idx])
+    y = backend.empty(x.shape)
+    backend.klib.elu(x, y, int(np.prod(x.shape)))
+    float_eq(backend.host(y), golden["elu_o_" + idx])
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (1027, 0), (4096, 1), (70001, 3)])
+def test_elementwise_sizes(backend, n, off):
+    """ragged tails and 4-byte (not 16-byte) aligned pointers"""
+    a, b = 3 * rnd(n + off), 3 * rnd(n + off)
+    da, db, dy = backend.dev(a), backend.dev(b), backend.empty((n + off,))
+    backend.klib.elu(da[off:], dy[off:], n)
+    near(backend.host(dy)[off:], O.elu(T(a[off:])).numpy(), 1e-6)
+    backend.klib.add_act(da[off:], db[off:], dy[off:], n, capi.RT_ACT_ELU)
+    near(backend.host(dy)[off:], O.elu(T(a[off:] + b[off:])).numpy(), 1e-6)
+    backend.klib.add_act(da[off:], db[off:], dy[off:], n, capi.RT_ACT_NONE)
+    near(backend.host(dy)[off:], a[off:] + b[off:], 0)
+    backend.klib.activation(da[off:], dy[off:], n, capi.RT_ACT_SIGMOID)
+    near(backend.host(dy)[off:], torch.sigmoid(T(a[off:])).numpy(), 1e-6)
+
+
+def test_elementwise_empty(backend):
+    backend.klib.elu(None, None, 0)            # n == 0 is a no-op, like an empty TRT tensor
+
+
+# ---- correlation cost volume (tests_main.cpp:961-986) --------------------------------------------
+def run_corr(backend, l, r, D):
+    n, c, h, w = l.shape
+    cv = backend.empty((n, D, h, w))
+    backend.klib.corr_cost_volume(backend.dev(l), backend.dev(r), cv, n, c, h, w, D)
+    return backend.host(cv)
+
+
+def test_corr_golden(backend, golden):
+    cv = golden["corr_cost_vol_01_cv"]
+    out = run_corr(backend, golden["corr_cost_vol_01_l"], golden["corr_cost_vol_01_r"], cv.shape[1])
+    near(out[:, :, None], cv, 1e-6)
+
+
+@pytest.mark.parametrize("shape,D", [((1, 5, 7, 37), 6), ((2, 32, 9, 140), 48), ((1, 3, 5, 130), 70),
+                                     ((1, 8, 4, 129), 16)])
+def test_corr_random(backend, shape, D):
+    l, r = rnd(*shape), rnd(*shape)
+    near(run_corr(backend, l, r, D), O.corr_cost_volume(T(l), T(r), D).numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("shape,D,is_min", [((1, 5, 7, 37), 6, False), ((2, 32, 9, 140), 48, False),
+                                            ((1, 8, 5, 129), 13, True), ((1, 4, 6, 6), 2, False)])
+def test_corr_softargmax_fused(backend, shape, D, is_min):
+    l, r = rnd(*shape), rnd(*shape)
+    n, c, h, w = shape
+    out = backend.empty((n, 1, h, w))
+    backend.klib.corr_softargmax(backend.dev(l), backend.dev(r), out, n, c, h, w, D, is_min)
+    ref = O.softargmax(O.corr_cost_volume(T(l), T(r), D), is_min).numpy()
+    near(backend.host(out), ref, 2e-4)
+
+
+def test_corr_softargmax_into_concat_buffer(backend):
+    """out_batch_stride places the result in channel 32 of a 33-channel buffer (resnet18_2D net :601-615)"""
+    n, c, h, w, D = 2, 8, 6, 40, 12
+    l, r = rnd(n, c, h, w), rnd(n, c, h, w)
+    buf = backend.dev(np.zeros((n, 5, h, w), np.float32))
+    backend.klib.corr_softargmax(backend.dev(l), backend.dev(r), buf[:, 4], n, c, h, w, D, False, out_bstride=5 * h * w)
+    got = backend.host(buf)
+    near(got[:, 4:5], O.softargmax(O.corr_cost_volume(T(l), T(r), D), False).numpy(), 2e-4)
+    assert (got[:, :4] == 0).all()
+
+
+# ---- default cost volume (tests_main.cpp:884-934) ------------------------------------------------
+@pytest.mark.parametrize("idx", ["01", "02"])
+def test_cost_volume_golden(backend, golden, idx):
+    l, r, cv = (golden["cost_vol_%s_%s" % (idx, k)] for k in ("l", "r", "cv"))
+    n, c, h, w = l.shape
+    out = backend.empty(cv.shape)
+    backend.klib.cost_volume(backend.dev(l), backend.dev(r), out, n, c, h, w, cv.shape[1])
+    float_eq(backend.host(out), cv)
+
+
+def test_cost_volume_random(backend):
+    l, r = rnd(2, 3, 5, 300), rnd(2, 3, 5, 300)
+    out = backend.empty((2, 7, 6, 5, 300))
+    backend.klib.cost_volume(backend.dev(l), backend.dev(r), out, 2, 3, 5, 300, 7)
+    near(backend.host(out), O.cost_volume(T(l), T(r), 7).numpy(), 0)
+
+
+# ---- soft-argmax (tests_main.cpp:1032-1099) ---------------------------------------------------------
+@pytest.mark.parametrize("idx,is_min,tol", [("01", True, 2e-6), ("02", True, 1e-5), ("03", False, 2e-6)])
+def test_softargmax_golden(backend, golden, idx, is_min, tol):
+    x, y = golden["softargmax_%s_x" % idx], golden["softargmax_%s_y" % idx]
+    n, d, _, h, w = x.shape
+    out = backend.empty(y.shape)
+    backend.klib.softargmax(backend.dev(x), out, n, d, h, w, is_min)
+    near(backend.host(out), y, tol)
+
+
+@pytest.mark.parametrize("D", [1, 7, 8, 9, 48, 136])
+def test_softargmax_random(backend, D):
+    x = 4 * rnd(2, D, 5, 67)
+    out = backend.empty((2, 1, 5, 67))
+    backend.klib.softargmax(backend.dev(x), out, 2, D, 5, 67, False)
+    near(backend.host(out), O.softargmax(T(x), False).numpy(), 1e-5 * max(D, 8))
+
+
+# ---- Transform / Padding / Slice / concat -------------------------------------------------------------
+def test_permute_pad_slice_concat(backend):
+    x = rnd(2, 3, 4, 5, 6)
+    y = backend.empty((2, 4, 3, 5, 6))
+    backend.klib.permute4d(backend.dev(x), y, 2, (3, 4, 5, 6), (1, 0, 2, 3))
+    near(backend.host(y), O.transform(T(x)).numpy(), 0)
+    y = backend.empty((2, 6, 3, 5, 4))
+    backend.klib.permute4d(backend.dev(x), y, 2, (3, 4, 5, 6), (3, 0, 2, 1))
+    near(backend.host(y), np.transpose(x, (0, 4, 1, 3, 2)), 0)
+    y = backend.empty((2, 4, 4, 5, 6))
+    backend.klib.pad_d(backend.dev(x), y, 2, 3, 4 * 5 * 6, 1)
+    near(backend.host(y), O.pad_d(T(x), 1).numpy(), 0)
+    y = backend.empty((2, 2, 4, 5, 6))
+    backend.klib.slice_d(backend.dev(x), y, 2, 3, 4 * 5 * 6, 0, 2)
+    near(backend.host(y), x[:, 0:2], 0)
+    backend.klib.slice_d(backend.dev(x), y, 2, 3, 4 * 5 * 6, 1, 3)
+    near(backend.host(y), x[:, 1:3], 0)
+    buf = backend.dev(np.zeros((2, 5, 4, 5, 6), np.float32))
+    backend.klib.concat_channels(backend.dev(x), buf, 2, 3, 5, 1, 4 * 5 * 6)
+    got = backend.host(buf)
+    near(got[:, 1:4], x, 0)
+    assert (got[:, 0] == 0).all() and (got[:, 4] == 0).all()
+
+
+def test_bad_arguments_fail_loudly(backend):
+    x = backend.dev(rnd(8))
+    with pytest.raises(capi.RtError):
+        backend.klib.slice_d(x, x, 1, 3, 1, 2, 1)            # empty slice, slice_plugin.cpp:28-29 asserts
+    with pytest.raises(capi.RtError):
+        backend.klib.permute4d(x, x, 1, (1, 2, 2, 2), (0, 0, 1, 2))
+    with pytest.raises(capi.RtError):
+        backend.klib.corr_cost_volume(x, x, x, 1, 0, 1, 1, 1)

@@ -1,0 +1,144 @@
+"""Pins oracle/stereo_oracle.py to the reference's own golden tensors.
+
+One test per TEST() in /root/reference/stereoDNN/tests/tests_main.cpp (line numbers cited),
+with the reference's own tolerance: EXPECT_FLOAT_EQ == 4 ULP, EXPECT_NEAR otherwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def assert_float_eq(actual, expected, ulps=4):
+    a = np.asarray(actual, np.float32).ravel()
+    e = np.asarray(expected, np.float32).ravel()
+    assert a.shape == e.shape
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(e)).astype(np.float32))
+    bad = np.abs(a - e) > tol
+    assert not bad.any(), "max |diff| %g at %d" % (np.abs(a - e).max(), int(np.argmax(np.abs(a - e))))
+
+
+def assert_near(actual, expected, tol):
+    a = np.asarray(actual, np.float32)
+    e = np.asarray(expected, np.float32)
+    assert a.shape == e.shape, (a.shape, e.shape)
+    assert np.abs(a - e).max() <= tol, np.abs(a - e).max()
+
+
+# ---- ELU (tests_main.cpp:280-342) -------------------------------------------------------
+@pytest.mark.parametrize("idx", ["01", "02"])
+def test_elu(golden, idx):
+    assert_float_eq(O.elu(T(golden["elu_i_" + idx])), golden["elu_o_" + idx])
+
+
+# ---- Conv3D (tests_main.cpp:345-623); fixtures: x NDCHW, w KVCRS, y NDKHW ------------------
+def run_conv3d(g, idx, stride, pad_start, pad_end, pad_input_d=False, bias=None):
+    x, w = T(g["conv3d_%s_x" % idx]), T(g["conv3d_%s_w" % idx])
+    if pad_input_d:                      # "manually pad input in D dimension" (tests_main.cpp:435-438)
+        x = O.pad_d(x, 1)
+    y = O.conv3d_tf(x, w, bias, stride, pad_start, pad_end)       # N K D H W
+    return O.transform(y)                                            # Transform {1,0,2,3}: KDHW -> DKHW
+
+
+def test_conv3d_01_basic(golden):                       # :362-389
+    assert_float_eq(run_conv3d(golden, "01", (1, 1, 1), (0, 0, 0), (0, 0, 0)), golden["conv3d_01_y"], ulps=16)
+
+
+def test_conv3d_02_hw_strides(golden):                  # :391-420
+    assert_near(run_conv3d(golden, "02", (1, 2, 2), (0, 1, 1), (0, 1, 1)), golden["conv3d_02_y"], 1e-5)
+
+
+def test_conv3d_03_dhw_strides(golden):                 # :422-455
+    assert_near(run_conv3d(golden, "03", (1, 2, 2), (0, 1, 1), (0, 1, 1), pad_input_d=True),
+                golden["conv3d_03_y"], 1e-5)
+
+
+def test_conv3d_04_unit_sym(golden):                    # :457-486
+    assert_near(run_conv3d(golden, "04", (1, 1, 1), (1, 1, 1), (1, 1, 1)), golden["conv3d_04_y"], 1e-4)
+
+
+def test_conv3d_05_asym(golden):                        # :488-521
+    assert_near(run_conv3d(golden, "05", (2, 2, 2), (0, 1, 1), (1, 1, 1), pad_input_d=True),
+                golden["conv3d_05_y"], 1e-4)
+
+
+def test_conv3d_06_bias_elu(golden):                    # :523-570
+    y = run_conv3d(golden, "06", (2, 2, 2), (0, 1, 1), (1, 1, 1), pad_input_d=True,
+                   bias=T(golden["conv3d_06_b"]))
+    assert_near(O.elu(y), golden["conv3d_06_y"], 1e-4)
+
+
+def test_conv3d_07_multiple(golden):                    # :572-623
+    x, w = T(golden["conv3d_07_x"]), T(golden["conv3d_07_w"])
+    y1 = O.transform(O.conv3d_tf(x, w, None, (1, 1, 1), (1, 1, 1), (1, 1, 1)))
+    y2 = O.conv3d_tf(O.pad_d(y1, 1), w, None, (2, 2, 2), (0, 1, 1), (0, 1, 1))
+    assert_near(O.transform(y2), golden["conv3d_07_y"], 1e-4)
+
+
+# ---- Conv3DTranspose (tests_main.cpp:629-878); y NDKHW (01,02) / NKDHW (03+), x NDCHW ------
+def test_conv3d_tran_01_basic(golden):                  # :653-683
+    y, w, x = (golden["conv3d_tran_01_" + k] for k in "ywx")
+    out = O.conv3d_transpose_tf(T(y), T(w), None, x.shape[1:], (1, 1, 1), (0, 0, 0), (0, 0, 0))
+    assert_float_eq(O.transform(out), x)                # D == C == ... transform is a no-op shape-wise
+
+
+def test_conv3d_tran_02_hw(golden):                     # :685-715
+    y, w, x = (golden["conv3d_tran_02_" + k] for k in "ywx")
+    out = O.conv3d_transpose_tf(T(y), T(w), None, x.shape[1:], (1, 2, 2), (0, 1, 1), (0, 1, 1))
+    assert_near(O.transform(out).reshape(x.shape), x, 1e-4)
+
+
+def tran_sliced(y, w, b, x_shape):
+    od = (x_shape[1] + 1,) + tuple(x_shape[2:])         # "manually pad output by 1 in D" (:730-732)
+    out = O.conv3d_transpose_tf(T(y), T(w), b, od, (2, 2, 2), (0, 1, 1), (0, 1, 1))
+    return O.slice_d(out, 0, x_shape[1])
+
+
+def test_conv3d_tran_03_asym(golden):                   # :717-761
+    y, w, x = (golden["conv3d_tran_03_" + k] for k in "ywx")
+    assert_near(tran_sliced(y, w, None, x.shape), x, 1e-4)
+
+
+def test_conv3d_tran_04_bias_elu(golden):               # :763-817
+    y, w, x = (golden["conv3d_tran_04_" + k] for k in "ywx")
+    assert_near(O.elu(tran_sliced(y, w, T(golden["conv3d_tran_04_b"]), x.shape)), x, 1e-4)
+
+
+def test_conv3d_tran_05_multiple(golden):               # :819-878
+    g = golden
+    x1 = tran_sliced(g["conv3d_tran_05_y"], g["conv3d_tran_05_w1"], None, (1, 8, 8, 9, 9))
+    x1 = O.transform(x1)                                # DCHW -> KDHW for the second deconv
+    x2 = tran_sliced(x1.numpy(), g["conv3d_tran_05_w2"], None, g["conv3d_tran_05_x"].shape)
+    assert_near(x2, g["conv3d_tran_05_x"], 1e-4)
+
+
+# ---- Cost volumes (tests_main.cpp:884-1026) ----------------------------------------------
+@pytest.mark.parametrize("idx", ["01", "02"])
+def test_cost_volume(golden, idx):                      # :884-934
+    cv = golden["cost_vol_%s_cv" % idx]
+    out = O.cost_volume(T(golden["cost_vol_%s_l" % idx]), T(golden["cost_vol_%s_r" % idx]), cv.shape[1])
+    assert_float_eq(out, cv)
+
+
+def test_corr_cost_volume(golden):                      # :961-986
+    cv = golden["corr_cost_vol_01_cv"]                   # (1, D, 1, H, W)
+    out = O.corr_cost_volume(T(golden["corr_cost_vol_01_l"]), T(golden["corr_cost_vol_01_r"]), cv.shape[1])
+    assert_near(out[:, :, None], cv, 1e-6)
+
+
+# ---- Softargmax (tests_main.cpp:1032-1099) -----------------------------------------------
+def test_softargmin_basic(golden):                      # :1032-1054
+    assert_near(O.softargmax(T(golden["softargmax_01_x"]), True), golden["softargmax_01_y"], 2e-6)
+
+
+def test_softargmin_batch2(golden):                     # :1056-1077
+    assert_near(O.softargmax(T(golden["softargmax_02_x"]), True), golden["softargmax_02_y"], 1e-5)
+
+
+def test_softargmax_basic(golden):                      # :1079-1099
+    assert_near(O.softargmax(T(golden["softargmax_03_x"]), False), golden["softargmax_03_y"], 2e-6)
