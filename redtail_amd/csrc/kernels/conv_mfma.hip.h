@@ -17,10 +17,15 @@
 // of a half-wave: global stores are 128-byte coalesced with no alignment requirement (W is odd in
 // every network of the reference).
 //
-// Data flow: global -> registers (prefetch of chunk i+1 is in flight while chunk i is multiplied)
-// -> LDS (input patch [CC][PR][PC] + weight slab [taps][CC][NB]) -> one ds_read_b32 per MFMA operand.
-// v_mfma_f32_32x32x2_f32 issues every 64 cycles per SIMD, so two LDS reads per MFMA keep the matrix
-// pipe fed (MI355X_MICROARCH.md, LDS table); the kernel is MFMA-bound, roofline = 157.3 TFLOP/s.
+// Data flow per chunk of CC input channels:
+//   global --(register prefetch: loads of chunk i+1 fly under the MFMAs of chunk i)--> LDS
+//   LDS image of the patch: [row][h][col][CC/2]  with channel = 2*j + h, so ONE ds_read_b128 hands a
+//   lane its B operands for the CC/2 consecutive MFMA k-steps of a tap; the weight slab is
+//   [tap][h][co][CC/2], so ONE ds_read_b128 hands it the matching A operands.  Both images make
+//   every ds_read_b128 lane group hit 16 distinct 16-byte slots (bank-conflict free, stride 1).
+//   Per tap a wave issues (NBW + WT) wide LDS reads for 4*NBW*WT MFMAs of 64 cycles each, and the
+//   reads of tap t+1 are issued before the MFMAs of tap t: the kernel is MFMA-bound,
+//   roofline = 157.3 TFLOP/s (MI355X_MICROARCH.md).
 #pragma once
 #include "common.hip.h"
 
@@ -29,9 +34,10 @@ namespace rt {
 struct ConvArgs {
     const float* x;
     float* y;
-    const float* w;        // packed [nblk][chunk][tap][CC][NB]
-    const float* bias;     // [Cout] or nullptr
+    const float* w;        // packed [nblk][chunk][tap][h][NB][CC/2]
+    const float* bias;     // [round_up(Cout, NB)], zero padded, never null
     const float* resid;    // same addressing as y, or nullptr
+    const float* zeros;    // >= 16 bytes of zeros: target of every out-of-image / padded-channel gather
     const int* ch_off;     // [nz][CinPad] plane offsets (elements) relative to the sample base, -1 = zeros
     int CinPad;            // multiple of CC
     int Cout;
@@ -49,36 +55,50 @@ struct ConvArgs {
     int y_ystride, y_xstride;
 };
 
-template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC>
+template <int N> struct VecOf;
+template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW = 4, bool WLDS = true>
 struct ConvCfg {
     static constexpr int TX = 32 * TXW;
     static constexpr int NB = 32 * NBW;
     static constexpr int TAPS = KH * KW;
+    static constexpr int CPG = CC / 2;                    // MFMA k-steps (channel pairs) per tap per chunk
     static constexpr int PR = (TY - 1) * S + KH;
     static constexpr int PC = (TX - 1) * S + KW;
-    static constexpr int IN_ELEMS = CC * PR * PC;
+    static constexpr int NPIX = PR * PC;                  // patch pixels
+    static constexpr int IN_ELEMS = CC * NPIX;
     static constexpr int W_ELEMS = TAPS * CC * NB;
-    static constexpr int NK_IN = (IN_ELEMS + 255) / 256;
-    static constexpr int NK_W = (W_ELEMS / 4 + 255) / 256;
-    static constexpr int WT = TY * TXW / 4;              // wave-tiles (32 px) per wave
-    static_assert((TY * TXW) % 4 == 0, "tile must split evenly over 4 waves");
-    static_assert(CC % 2 == 0, "MFMA 32x32x2 consumes channel pairs");
+    // staging roles: with 4 waves, wave w gathers channel parity w&1 for pixel half w>>1; a
+    // single-wave workgroup gathers both parities of all pixels itself
+    static constexpr int NPAR = NW == 1 ? 2 : 1;          // parities gathered per wave
+    static constexpr int NPART = NW == 1 ? 1 : NW / 2;    // pixel partitions
+    static constexpr int NKP = ((NPIX + NPART - 1) / NPART + 63) / 64;   // patch pixels per lane
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int NK_W = (W_ELEMS / 4 + NTHR - 1) / NTHR;
+    static constexpr int WT = TY * TXW / NW;              // wave-tiles (32 px) per wave
+    static_assert(NW == 1 || NW == 4, "1 or 4 waves per workgroup");
+    static_assert((TY * TXW) % NW == 0, "tile must split evenly over the waves");
+    static_assert(WLDS || true, "");
+    static_assert(CC == 4 || CC == 8, "CC/2 k-steps are fetched by one ds_read_b64 / ds_read_b128");
     static_assert(W_ELEMS % 4 == 0, "weight slab is copied as float4");
-    static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * 4 + 4 * 512;
 };
 
-template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC>
-__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs p) {
-    using Cfg = ConvCfg<KH, KW, S, TY, TXW, NBW, CC>;
-    constexpr int TX = Cfg::TX, NB = Cfg::NB, PR = Cfg::PR, PC = Cfg::PC, WT = Cfg::WT;
+template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS>
+__global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
+    using Cfg = ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>;
+    constexpr int TX = Cfg::TX, NB = Cfg::NB, PR = Cfg::PR, PC = Cfg::PC, WT = Cfg::WT, CPG = Cfg::CPG;
+    constexpr int NPIX = Cfg::NPIX, NKP = Cfg::NKP, TAPS = Cfg::TAPS, NPAR = Cfg::NPAR, NTHR = Cfg::NTHR;
+    typedef typename VecOf<CPG>::type vec_t;
 
-    __shared__ float sIn[CC * PR * PC];
-    __shared__ __attribute__((aligned(16))) float sW[Cfg::W_ELEMS];
-    __shared__ int sOff[512];
+    __shared__ __attribute__((aligned(16))) float sIn[Cfg::IN_ELEMS];   // [row][h][col][CPG]
+    __shared__ __attribute__((aligned(16))) float sW[WLDS ? Cfg::W_ELEMS : 4];   // [tap][h][co][CPG]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const int half = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int tile = blockIdx.x;
     const int tx0 = (tile % p.tiles_x) * TX;
@@ -90,30 +110,29 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs p) {
     const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
     const int nchunks = p.CinPad / CC;
 
-    // plane-offset table of this z-slice -> LDS (CinPad <= 512 is checked by the launcher)
-    for (int i = tid; i < p.CinPad; i += 256) sOff[i] = p.ch_off[(int64_t)zi * p.CinPad + i];
+    const int act = p.act;
 
-    // per-thread, chunk-invariant part of the input gather: in-plane offset or -1
-    int poff[Cfg::NK_IN];
-    int pch[Cfg::NK_IN];
+    // ---- staging roles (see ConvCfg) ------------------------------------------------------------------
+    const int sh = NW == 1 ? 0 : (wv & 1), spart = NW == 1 ? 0 : (wv >> 1);
+    const int* __restrict__ tab = p.ch_off + (int64_t)zi * p.CinPad + sh;
+    int poff[NKP];      // in-plane element offset of the patch pixel, or -1 outside the image
+    int lidx[NKP];      // LDS vec_t index of the patch pixel (parity 0 of this wave), or -1 if not owned
 #pragma unroll
-    for (int k = 0; k < Cfg::NK_IN; k++) {
-        const int idx = tid + 256 * k;
-        const int c = idx / (PR * PC);
-        const int rem = idx - c * (PR * PC);
-        const int pr = rem / PC, pc = rem - pr * PC;
+    for (int k = 0; k < NKP; k++) {
+        const int pidx = spart * (NKP * 64) + lane + 64 * k;
+        const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 * S - p.pad_y + pr;
         const int ix = tx0 * S - p.pad_x + pc;
-        const bool ok = idx < Cfg::IN_ELEMS && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        poff[k] = ok ? iy * p.Wi + ix : -1;
-        pch[k] = c;
+        const bool own = pidx < NPIX;
+        poff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
+        lidx[k] = own ? (pr * 2 + sh) * PC + pc : -1;
     }
 
     const f32x4* __restrict__ wsrc =
         reinterpret_cast<const f32x4*>(p.w + ((int64_t)nblk * nchunks) * Cfg::W_ELEMS);
 
-    float rin[Cfg::NK_IN];
-    f32x4 rw[Cfg::NK_W];
+    vec_t rin[NPAR][NKP];
+    f32x4 rw[WLDS ? Cfg::NK_W : 1];
 
     f32x16 acc[WT][NBW];
 #pragma unroll
@@ -123,86 +142,118 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][b][r] = 0.f;
 
-    __syncthreads();   // sOff visible
-
+    // Loads only: invalid gathers are redirected to a zero word, so nothing has to be selected
+    // afterwards and the results are not touched until they are written to LDS one iteration later.
     auto prefetch = [&](int ch) {
 #pragma unroll
-        for (int k = 0; k < Cfg::NK_IN; k++) {
-            float v = 0.f;
-            if (poff[k] >= 0) {
-                const int off = sOff[ch * CC + pch[k]];
-                if (off >= 0) v = xb[(int64_t)off + poff[k]];
-            }
-            rin[k] = v;
-        }
-        const f32x4* ws = wsrc + (int64_t)ch * (Cfg::W_ELEMS / 4);
+        for (int h = 0; h < NPAR; h++)
 #pragma unroll
-        for (int k = 0; k < Cfg::NK_W; k++) {
-            const int idx = tid + 256 * k;
-            rw[k] = idx < Cfg::W_ELEMS / 4 ? ws[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < CPG; j++) {
+                const int off = tab[ch * CC + 2 * j + h];          // wave-uniform scalar load
+#pragma unroll
+                for (int k = 0; k < NKP; k++) {
+                    const bool ok = (poff[k] >= 0) & (off >= 0);
+                    const float* src = ok ? xb + ((int64_t)off + poff[k]) : p.zeros;
+                    rin[h][k][j] = *src;
+                }
+            }
+        if (WLDS) {
+            const f32x4* ws = wsrc + (int64_t)ch * (Cfg::W_ELEMS / 4);
+#pragma unroll
+            for (int k = 0; k < Cfg::NK_W; k++) {
+                const int idx = tid + NTHR * k;
+                rw[k] = ws[idx < Cfg::W_ELEMS / 4 ? idx : 0];
+            }
         }
     };
+
+    // per-lane LDS read bases (vec_t units)
+    int a_base[NBW], b_base[WT];
+#pragma unroll
+    for (int b = 0; b < NBW; b++) a_base[b] = half * NB + b * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < WT; i++) {
+        const int t = wv + NW * i;
+        b_base[i] = ((t / TXW) * S * 2 + half) * PC + ((t % TXW) * 32 + l31) * S;
+    }
+    const vec_t* sIn4 = reinterpret_cast<const vec_t*>(sIn);
+    const vec_t* sW4 = reinterpret_cast<const vec_t*>(sW);
+    const vec_t* __restrict__ gW4 = reinterpret_cast<const vec_t*>(wsrc);   // weights straight from L1/L2 (WLDS == false)
 
     prefetch(0);
     for (int ch = 0; ch < nchunks; ch++) {
         __syncthreads();   // everyone finished reading the previous chunk from LDS
 #pragma unroll
-        for (int k = 0; k < Cfg::NK_IN; k++) {
-            const int idx = tid + 256 * k;
-            if (idx < Cfg::IN_ELEMS) sIn[idx] = rin[k];
-        }
+        for (int h = 0; h < NPAR; h++)
 #pragma unroll
-        for (int k = 0; k < Cfg::NK_W; k++) {
-            const int idx = tid + 256 * k;
-            if (idx < Cfg::W_ELEMS / 4) reinterpret_cast<f32x4*>(sW)[idx] = rw[k];
+            for (int k = 0; k < NKP; k++)
+                if (lidx[k] >= 0) reinterpret_cast<vec_t*>(sIn)[lidx[k] + h * PC] = rin[h][k];
+        if (WLDS) {
+#pragma unroll
+            for (int k = 0; k < Cfg::NK_W; k++) {
+                const int idx = tid + NTHR * k;
+                if (idx < Cfg::W_ELEMS / 4) reinterpret_cast<f32x4*>(sW)[idx] = rw[k];
+            }
         }
         __syncthreads();
         if (ch + 1 < nchunks) prefetch(ch + 1);   // global loads fly while the MFMAs below run
 
+        const vec_t* wq = WLDS ? sW4 : gW4 + (int64_t)ch * (TAPS * 2 * NB);
+        // operands of tap t+1 are fetched before the MFMAs of tap t
+        vec_t a_cur[NBW], b_cur[WT], a_nxt[NBW], b_nxt[WT];
 #pragma unroll
-        for (int r = 0; r < KH; r++) {
+        for (int b = 0; b < NBW; b++) a_cur[b] = wq[a_base[b]];
 #pragma unroll
-            for (int s = 0; s < KW; s++) {
+        for (int i = 0; i < WT; i++) b_cur[i] = sIn4[b_base[i]];
 #pragma unroll
-                for (int cp = 0; cp < CC / 2; cp++) {
-                    const int c = 2 * cp + half;
-                    float a[NBW];
+        for (int t = 0; t < TAPS; t++) {
+            if (t + 1 < TAPS) {
+                const int r = (t + 1) / KW, s = (t + 1) % KW;
 #pragma unroll
-                    for (int b = 0; b < NBW; b++) a[b] = sW[((r * KW + s) * CC + c) * NB + b * 32 + l31];
+                for (int b = 0; b < NBW; b++) a_nxt[b] = wq[a_base[b] + (t + 1) * 2 * NB];
 #pragma unroll
-                    for (int i = 0; i < WT; i++) {
-                        const int t = wave + 4 * i;
-                        const int ty = t / TXW, txw = t % TXW;
-                        const float bv = sIn[(c * PR + ty * S + r) * PC + (txw * 32 + l31) * S + s];
+                for (int i = 0; i < WT; i++) b_nxt[i] = sIn4[b_base[i] + r * 2 * PC + s];
+            }
 #pragma unroll
-                        for (int b = 0; b < NBW; b++)
-                            acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b], bv, acc[i][b], 0, 0, 0);
-                    }
-                }
+            for (int j = 0; j < CPG; j++)
+#pragma unroll
+                for (int i = 0; i < WT; i++)
+#pragma unroll
+                    for (int b = 0; b < NBW; b++)
+                        acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[b][j], b_cur[i][j], acc[i][b], 0, 0, 0);
+            if (t + 1 < TAPS) {
+#pragma unroll
+                for (int b = 0; b < NBW; b++) a_cur[b] = a_nxt[b];
+#pragma unroll
+                for (int i = 0; i < WT; i++) b_cur[i] = b_nxt[i];
             }
         }
     }
 
-    // epilogue: bias (+ residual) + activation, 128-byte coalesced stores per half-wave
+    // ---- epilogue: bias (+ residual) + activation, 128-byte coalesced stores per half-wave ----------
     const int64_t ybase = (int64_t)n * p.y_bstride + (int64_t)zi * p.y_zstride + p.y_off;
 #pragma unroll
-    for (int i = 0; i < WT; i++) {
-        const int t = wave + 4 * i;
-        const int oy = ty0 + t / TXW;
-        const int ox = tx0 + (t % TXW) * 32 + l31;
-        const bool pix_ok = oy < p.Ho && ox < p.Wo;
-        const int64_t pbase = ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride;
+    for (int b = 0; b < NBW; b++) {
+        // accumulator register r holds channel (r&3) + 8*(r>>2) + 4*half of this 32-block
+        const int cbase = nblk * NB + b * 32 + 4 * half;
+        f32x4 bv[4];
 #pragma unroll
-        for (int b = 0; b < NBW; b++) {
+        for (int q = 0; q < 4; q++) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 8 * q);
+#pragma unroll
+        for (int i = 0; i < WT; i++) {
+            const int t = wv + NW * i;
+            const int oy = ty0 + t / TXW;
+            const int ox = tx0 + (t % TXW) * 32 + l31;
+            const bool pix_ok = oy < p.Ho && ox < p.Wo;
+            const int64_t pbase = ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int co = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = cbase + (r & 3) + 8 * (r >> 2);
                 if (pix_ok && co < p.Cout) {
                     const int64_t addr = pbase + (int64_t)co * p.y_cstride;
-                    float v = acc[i][b][r];
-                    if (p.bias) v += p.bias[co];
+                    float v = acc[i][b][r] + bv[r >> 2][r & 3];
                     if (p.resid) v += p.resid[addr];
-                    p.y[addr] = apply_act_rt(v, p.act);
+                    p.y[addr] = apply_act_rt(v, act);
                 }
             }
         }

@@ -59,27 +59,71 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
     // Lane window = floats [8*xg + DT*(3-dg), +DT+8)  ->  first chunk g0 = 2*xg + q0.
     const int q0 = (DT / 4) * (3 - dg);
 
+    // Staging: wave dg stages channels {2*dg, 2*dg+1} of each chunk (channel = wave-uniform), so the
+    // in-plane gather offsets depend on the lane only and are computed once; the loads of chunk i+1
+    // are issued before the FMAs of chunk i and land in LDS after them (register prefetch).
+    constexpr int CPW = CC / 4;
+    constexpr int NKR = (RY * RW + 63) / 64, NKL = (RY * TX) / 64;
+    const int wv = __builtin_amdgcn_readfirstlane(dg);
+    int roff[NKR], loff[NKL];
+#pragma unroll
+    for (int k = 0; k < NKR; k++) {
+        const int idx = lane + 64 * k;
+        const int rr = idx / RW, i = idx - rr * RW;
+        const int gx = x0 - d_base - DPAD + i, gyy = y0 + rr;
+        roff[k] = (idx < RY * RW && gyy < H && gx >= 0 && gx < W) ? gyy * W + gx : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NKL; k++) {
+        const int idx = lane + 64 * k;
+        const int rr = idx / TX, i = idx - rr * TX;
+        const int gx = x0 + i, gyy = y0 + rr;
+        loff[k] = (gyy < H && gx < W) ? gyy * W + gx : -1;
+    }
+    float pr_[CPW][NKR], pl_[CPW][NKL];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < CPW; j++) {
+            const int c = c0 + wv * CPW + j;
+            const bool cok = c < C;
+            const float* rp = rb + (int64_t)(cok ? c : 0) * plane;
+            const float* lp = lb + (int64_t)(cok ? c : 0) * plane;
+#pragma unroll
+            for (int k = 0; k < NKR; k++) {
+                const bool ok = cok & (roff[k] >= 0);
+                const float v = rp[ok ? roff[k] : 0];
+                pr_[j][k] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NKL; k++) {
+                const bool ok = cok & (loff[k] >= 0);
+                const float v = lp[ok ? loff[k] : 0];
+                pl_[j][k] = ok ? v : 0.f;
+            }
+        }
+    };
+
+    prefetch(0);
     for (int c0 = 0; c0 < C; c0 += CC) {
         __syncthreads();
-        for (int idx = tid; idx < CC * RY * RW; idx += 256) {
-            const int c = idx / (RY * RW);
-            const int rem = idx - c * (RY * RW);
-            const int rr = rem / RW, i = rem - rr * RW;
-            const int gx = x0 - d_base - DPAD + i, gy = y0 + rr;
-            float v = 0.f;
-            if (c0 + c < C && gy < H && gx >= 0 && gx < W) v = rb[(int64_t)(c0 + c) * plane + (int64_t)gy * W + gx];
-            sR[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * RS + (i >> 3)) * 4 + (i & 3)] = v;
-        }
-        for (int idx = tid; idx < CC * RY * TX; idx += 256) {
-            const int c = idx / (RY * TX);
-            const int rem = idx - c * (RY * TX);
-            const int rr = rem / TX, i = rem - rr * TX;
-            const int gx = x0 + i, gy = y0 + rr;
-            float v = 0.f;
-            if (c0 + c < C && gy < H && gx < W) v = lb[(int64_t)(c0 + c) * plane + (int64_t)gy * W + gx];
-            sL[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * 16 + (i >> 3)) * 4 + (i & 3)] = v;
+#pragma unroll
+        for (int j = 0; j < CPW; j++) {
+            const int c = wv * CPW + j;
+#pragma unroll
+            for (int k = 0; k < NKR; k++) {
+                const int idx = lane + 64 * k;
+                const int rr = idx / RW, i = idx - rr * RW;
+                if (idx < RY * RW) sR[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * RS + (i >> 3)) * 4 + (i & 3)] = pr_[j][k];
+            }
+#pragma unroll
+            for (int k = 0; k < NKL; k++) {
+                const int idx = lane + 64 * k;
+                const int rr = idx / TX, i = idx - rr * TX;
+                sL[(((c * 2 + ((i >> 2) & 1)) * RY + rr) * 16 + (i >> 3)) * 4 + (i & 3)] = pl_[j][k];
+            }
         }
         __syncthreads();
+        if (c0 + CC < C) prefetch(c0 + CC);
 #pragma unroll 2
         for (int c = 0; c < CC; c++) {
             float lv[8], rw[DT + 8];

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -334,10 +335,10 @@ extern "C" int rt_concat_channels(const void* x, void* y, int batch, int C, int 
 // =================================================================================================
 namespace {
 
-constexpr int kTY = 4, kTXW = 2;   // 4 rows x 64 pixels per workgroup
 
 struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int KH = 1, KW = 1, S = 1, NBW = 1, CC = 8;
+    int TY = 4, TXW = 2, NW = 4, WLDS = 1;      // workgroup tile: TY rows x 32*TXW pixels, NW waves
     int CinPad = 0, Cout = 0;
     int Hi = 0, Wi = 0, Ho = 0, Wo = 0, pad_y = 0, pad_x = 0, nz = 1;
     int64_t y_cstride = 0, y_zstride = 0, y_off = 0;
@@ -351,6 +352,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
 struct rtConvPlan {
     std::vector<SubConv> subs;
     float* bias_dev = nullptr;
+    float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
     int out_dims[4] = {0, 0, 0, 1};
     int64_t x_bstride = 0, y_bstride = 0;
@@ -377,26 +379,28 @@ Phase1D phase1d(int s, int p, int k, int phi) {
     return ph;
 }
 
-// Packs weights for one launch: [nblk][chunk][tap][CC][NB]; wfun(co, ci, u, v) returns the weight of
-// output channel co, gathered channel ci, window tap (u, v).
+// Packs weights for one launch in the exact order of the kernel's LDS slab:
+// [nblk][chunk][tap][h][NB][CC/2] with gathered channel ci = chunk*CC + 2*j + h;
+// wfun(co, ci, u, v) returns the weight of output channel co, gathered channel ci, window tap (u, v).
 template <typename F>
 int upload_packed(SubConv& sc, int cin_real, F wfun) {
-    const int NB = 32 * sc.NBW, taps = sc.KH * sc.KW;
+    const int NB = 32 * sc.NBW, taps = sc.KH * sc.KW, cpg = sc.CC / 2;
     const int nblk = (int)rt::cdiv(sc.Cout, NB), nch = sc.CinPad / sc.CC;
     std::vector<float> packed((size_t)nblk * nch * taps * sc.CC * NB, 0.f);
     for (int nb = 0; nb < nblk; nb++)
         for (int ch = 0; ch < nch; ch++)
             for (int u = 0; u < sc.KH; u++)
                 for (int v = 0; v < sc.KW; v++)
-                    for (int cc = 0; cc < sc.CC; cc++) {
-                        const int ci = ch * sc.CC + cc;
-                        if (ci >= cin_real) continue;
-                        float* dst = &packed[((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * sc.CC + cc) * NB];
+                    for (int h = 0; h < 2; h++)
                         for (int nn = 0; nn < NB; nn++) {
                             const int co = nb * NB + nn;
-                            if (co < sc.Cout) dst[nn] = wfun(co, ci, u, v);
+                            if (co >= sc.Cout) continue;
+                            float* dst = &packed[(((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * NB + nn) * cpg];
+                            for (int j = 0; j < cpg; j++) {
+                                const int ci = ch * sc.CC + 2 * j + h;
+                                if (ci < cin_real) dst[j] = wfun(co, ci, u, v);
+                            }
                         }
-                    }
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * sizeof(float)));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
@@ -408,10 +412,15 @@ int upload_table(SubConv& sc, const std::vector<int>& table) {
     return 0;
 }
 
+// bias is always materialised, zero padded to a multiple of 64 channels (the epilogue reads float4s);
+// the same allocation carries 64 trailing zeros that out-of-image gathers are redirected to.
 int upload_bias(rtConvPlan* plan, const float* bias, int n) {
-    if (!bias) return 0;
-    RT_HIP(hipMalloc((void**)&plan->bias_dev, n * sizeof(float)));
-    RT_HIP(hipMemcpy(plan->bias_dev, bias, n * sizeof(float), hipMemcpyHostToDevice));
+    const int padded = rt::round_up(n, 64);
+    std::vector<float> b(padded + 64, 0.f);
+    if (bias) std::memcpy(b.data(), bias, n * sizeof(float));
+    RT_HIP(hipMalloc((void**)&plan->bias_dev, b.size() * sizeof(float)));
+    RT_HIP(hipMemcpy(plan->bias_dev, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    plan->zeros_dev = plan->bias_dev + padded;
     return 0;
 }
 
@@ -421,10 +430,27 @@ bool window_supported(int KH, int KW, int S) {
     return false;
 }
 
+// Tile variant: 0 = 4 waves, 4x64 px tile, weights via LDS;  1 = one wave per workgroup, 2x64 px,
+// weights straight from L1/L2;  2 = one wave, 4x32 px;  3 = 4 waves, 4x64 px, weights from L1/L2.
+// RT_CONV_VARIANT overrides the default for A/B measurements.
+int conv_variant() {
+    static int v = [] {
+        const char* e = getenv("RT_CONV_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 void choose_tiling(SubConv& sc) {
     sc.NBW = sc.Cout > 32 ? 2 : 1;
     sc.CC = 8;
     if (sc.KH == 5) { sc.NBW = 1; sc.CC = 4; }
+    switch (conv_variant()) {
+        case 1: sc.TY = 2; sc.TXW = 2; sc.NW = 1; sc.WLDS = 0; break;
+        case 2: sc.TY = 4; sc.TXW = 1; sc.NW = 1; sc.WLDS = 0; break;
+        case 3: sc.TY = 4; sc.TXW = 2; sc.NW = 4; sc.WLDS = 0; break;
+        default: sc.TY = 4; sc.TXW = 2; sc.NW = 4; sc.WLDS = 1; break;
+    }
 }
 
 // weights to host fp32 (fp16 weight files are widened once; activations stay fp32 in this build)
@@ -440,14 +466,23 @@ std::vector<float> to_f32(const void* w, size_t n, int dtype) {
 }
 
 template <int KH, int KW, int S, int NBW, int CC>
-void launch_cfg(const rt::ConvArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, kTY, kTXW, NBW, CC>), grid, dim3(256), 0, st, a);
+int launch_window(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream_t st) {
+#define RT_TILE(ty, txw, nw, wlds)                                                                        \
+    if (sc.TY == ty && sc.TXW == txw && sc.NW == nw && sc.WLDS == (wlds ? 1 : 0)) {                       \
+        hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, ty, txw, NBW, CC, nw, wlds>), grid,       \
+                           dim3(64 * nw), 0, st, a);                                                      \
+        return 0;                                                                                         \
+    }
+    RT_TILE(4, 2, 4, true) RT_TILE(2, 2, 1, false) RT_TILE(4, 1, 1, false) RT_TILE(4, 2, 4, false)
+#undef RT_TILE
+    return 1;
 }
 
 int launch_sub(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream_t st) {
 #define RT_CASE(kh, kw, s, nbw, cc)                                                             \
     if (sc.KH == kh && sc.KW == kw && sc.S == s && sc.NBW == nbw && sc.CC == cc) {              \
-        launch_cfg<kh, kw, s, nbw, cc>(a, grid, st);                                            \
+        if (launch_window<kh, kw, s, nbw, cc>(sc, a, grid, st))                                 \
+            return fail(RT_E_UNSUPPORTED, "conv: tile %dx%d/%d waves not instantiated", sc.TY, 32 * sc.TXW, sc.NW); \
         RT_LAUNCH_CHECK("conv_mfma_f32_kernel<" #kh "," #kw "," #s "," #nbw "," #cc ">");       \
         return 0;                                                                               \
     }
@@ -508,9 +543,9 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
     if (!rc) rc = upload_table(sc, table);
     plan->subs.push_back(sc);
-    if (!rc && bias) {
-        const std::vector<float> b = to_f32(bias, d->Cout, d->dtype);
-        rc = upload_bias(plan, b.data(), d->Cout);
+    if (!rc) {
+        const std::vector<float> b = bias ? to_f32(bias, d->Cout, d->dtype) : std::vector<float>();
+        rc = upload_bias(plan, bias ? b.data() : nullptr, d->Cout);
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -561,9 +596,9 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             if (!rc) rc = upload_table(sc, table);
             plan->subs.push_back(sc);
         }
-    if (!rc && bias) {
-        const std::vector<float> b = to_f32(bias, Cout, d->dtype);
-        rc = upload_bias(plan, b.data(), Cout);
+    if (!rc) {
+        const std::vector<float> b = bias ? to_f32(bias, Cout, d->dtype) : std::vector<float>();
+        rc = upload_bias(plan, bias ? b.data() : nullptr, Cout);
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -632,9 +667,9 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
         }
     if (!rc) rc = upload_table(sc, table);
     plan->subs.push_back(sc);
-    if (!rc && bias) {
-        const std::vector<float> b = to_f32(bias, K, d->dtype);
-        rc = upload_bias(plan, b.data(), K);
+    if (!rc) {
+        const std::vector<float> b = bias ? to_f32(bias, K, d->dtype) : std::vector<float>();
+        rc = upload_bias(plan, bias ? b.data() : nullptr, K);
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -706,9 +741,9 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
                 plan->subs.push_back(sc);
             }
     }
-    if (!rc && bias) {
-        const std::vector<float> b = to_f32(bias, C, d->dtype);
-        rc = upload_bias(plan, b.data(), C);
+    if (!rc) {
+        const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
+        rc = upload_bias(plan, bias ? b.data() : nullptr, C);
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -732,17 +767,18 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.y = static_cast<float*>(y);
         a.w = sc.w_dev;
         a.bias = plan->bias_dev;
+        a.zeros = plan->zeros_dev;
         a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
         a.ch_off = sc.choff_dev;
         a.CinPad = sc.CinPad; a.Cout = sc.Cout;
         a.Hi = sc.Hi; a.Wi = sc.Wi; a.Ho = sc.Ho; a.Wo = sc.Wo;
         a.pad_y = sc.pad_y; a.pad_x = sc.pad_x; a.nz = sc.nz;
-        a.tiles_x = (int)rt::cdiv(sc.Wo, 32 * kTXW);
+        a.tiles_x = (int)rt::cdiv(sc.Wo, 32 * sc.TXW);
         a.act = plan->act;
         a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
         a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
-        const int tiles_y = (int)rt::cdiv(sc.Ho, kTY);
+        const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
