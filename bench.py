@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stereo pairs/sec of ResNet-18 2D Stereo DNN, fp32, 1257x369, batch 1 per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
+network (61 fused launches) with the inputs already resident in HBM (the reference times
+context->execute the same way, sample_app/main.cpp:303-309).  Stereo pairs are independent, so ranks
+share nothing but the weights: rank 0 builds the weight-file image and broadcasts it over RCCL
+(torch.distributed backend "nccl"); there is no data-path collective and scaling is weak (each rank
+processes its own K pairs).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = conv_mfma_f32_kernel<3,3,1,...> (the 34 residual-block 3x3 32->32
+                convolutions at 629x185 = 79 % of the network's FLOPs): algorithmic FLOPs per launch /
+                average launch duration measured with HIP events on the launch stream
+                (IProfiler path of the executor) right after the timed region.
+  cpu_baseline  the oracle (torch CPU restatement of the reference graph, oracle/stereo_oracle.py) timed
+                on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from redtail_amd import capi, synth  # noqa: E402
+
+W, H = 1257, 369
+MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HALF_W, HALF_H = 629, 185
+DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
+
+
+def dominant(name):
+    return "resblock" in name or name.endswith("encoder2D_out")
+
+
+def cpu_baseline(weights, budget_s=12.0):
+    """Bounded CPU sample of the same workload through the oracle (kind = "port")."""
+    from oracle import stereo_oracle as O
+    l, r = synth.synth_pair(H, W, 1234)
+    L, R = torch.from_numpy(l)[None], torch.from_numpy(r)[None]
+    with torch.no_grad():
+        O.resnet18_2d(L, R, weights)                        # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.resnet18_2d(L, R, weights)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or n >= 64:
+                break
+    return dict(value=n / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)       # the reference averages over 200 images
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- weights: rank 0 owns the file image, everyone else receives it over RCCL/xGMI ------------------
+    if rank == 0:
+        weights = synth.synth_weights_resnet18_2d(seed=7)
+        blob = capi.pack_weights(weights)
+    if distributed:
+        import torch.distributed as dist
+        size = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(size, 0)
+        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        blob = bytes(buf.cpu().numpy())
+
+    lib = capi.NetLib()
+    lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
+    net = lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob)
+
+    b = args.batch
+    ls, rs = zip(*(synth.synth_pair(H, W, 1234 + rank * 64 + i) for i in range(b)))
+    left = torch.from_numpy(np.stack(ls)).to(dev)
+    right = torch.from_numpy(np.stack(rs)).to(dev)
+    disp = torch.empty(b, 1, H, W, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        net.execute(left, right, disp, b, stream=sh)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.execute(left, right, disp, b, stream=sh)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+    assert torch.isfinite(disp).all(), "non-finite disparity"
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream ------
+        prof_runs, tot, cnt = 5, 0.0, 0
+        for _ in range(prof_runs):
+            for name, ms in net.profile(left, right, disp, b):
+                if dominant(name):
+                    tot += ms
+                    cnt += 1
+        avg_s = tot / cnt * 1e-3
+        achieved = DOMINANT_FLOPS * b / avg_s / 1e12
+        out = {
+            "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ResNet-18 2D Stereo DNN fp32, 1257x369, batch=%d per step, one MI355X per rank" % b,
+                       "pairs_per_step": b, "launches_per_step": net.num_launches, "layers": net.num_layers,
+                       "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<3,3,1> 32->32 @629x185 (+bias,+residual,+ELU)",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
+                         "flops_per_launch": DOMINANT_FLOPS * b},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth.synth_weights_resnet18_2d(seed=7))
+        print(json.dumps(out), flush=True)
+    net.destroy()
+    if distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,9 +49,10 @@ int rt_memcpy_h2d(void* dst, const void* src, size_t bytes, rtStream stream);
 int rt_memcpy_d2h(void* dst, const void* src, size_t bytes, rtStream stream);
 int rt_memcpy_d2d(void* dst, const void* src, size_t bytes, rtStream stream);
 int rt_memset(void* dst, int value, size_t bytes, rtStream stream);
-int rt_stream_create(rtStream* stream);
+int rt_stream_create(rtStream* stream);             /* non-blocking w.r.t. the NULL stream */
 int rt_stream_destroy(rtStream stream);
 int rt_stream_sync(rtStream stream);
+int rt_stream_wait_event(rtStream stream, void* ev);   /* later work on `stream` waits for `ev` */
 int rt_event_create(void** ev);
 int rt_event_destroy(void* ev);
 int rt_event_record(void* ev, rtStream stream);

@@ -1,0 +1,55 @@
+/*
+ * rt_stereo_net.h -- whole-network C ABI of the Stereo DNN inference path on MI355X.
+ *
+ * What sample_app/main.cpp:136-340 and ros/packages/stereo_dnn_ros/src/stereo_dnn_ros_node.cpp:224-377 of
+ * the reference do with TensorRT objects (read trt_weights.bin, build the network through the
+ * IPluginContainer API, build an engine, create a context, execute on device buffers) behind five
+ * plain-C calls, so that non-C++ hosts (ctypes in bench.py / tests, cgo, JNI ...) can drive the same
+ * code path.  Implemented by redtail_amd/csrc/host/net_capi.cpp on top of the NvInfer.h shim.
+ */
+#ifndef RT_STEREO_NET_H
+#define RT_STEREO_NET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt_stereo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtStereoNet rtStereoNet;
+
+/* model_type strings of sample_app/main.cpp:155-161 */
+enum { RT_MODEL_RESNET18_2D = 0, RT_MODEL_NVSMALL = 1, RT_MODEL_NVTINY = 2, RT_MODEL_RESNET18 = 3 };
+
+/* Build an engine for `width` x `height` images (any size = 1 mod 8 for ResNet-18 2D).
+ * weights_dtype: RT_F32 / RT_F16 = element type of the weight blob (trt_weights.bin / trt_weights_fp16.bin,
+ * layout of scripts/tensorrt_model_builder.py:52-60).  Activations are fp32.  max_disp <= 0 selects the
+ * model's default half-resolution disparity range (48 / 48 / 24 / 68). */
+int rt_net_create(rtStereoNet** net, int model, int width, int height, int max_batch, int weights_dtype,
+                  int max_disp, const char* weights_path);
+/* Same, from an in-memory image of the weight file (what rank 0 broadcasts over RCCL). */
+int rt_net_create_from_memory(rtStereoNet** net, int model, int width, int height, int max_batch, int weights_dtype,
+                              int max_disp, const void* blob, size_t bytes);
+
+/* left/right: device (N,3,H,W) fp32 in [0,1]; disp: device (N,1,H,W) fp32 (ResNet-18 2D: disparity / width;
+ * 3-D models: pixels).  stream == NULL: synchronous (IExecutionContext::execute); otherwise asynchronous on
+ * that HIP stream (IExecutionContext::enqueue). */
+int rt_net_execute(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, rtStream stream);
+
+/* Per-launch timing through nvinfer1::IProfiler (single stream, one event pair per launch):
+ * writes "name<TAB>milliseconds\n" lines into buf.  Returns 0 or an error. */
+int rt_net_profile(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, char* buf,
+                   size_t buf_bytes);
+
+int rt_net_num_layers(const rtStereoNet* net);     /* layers of the network definition  */
+int rt_net_num_launches(const rtStereoNet* net);   /* kernel launches after fusion       */
+int rt_net_destroy(rtStereoNet* net);
+const char* rt_net_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

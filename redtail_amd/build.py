@@ -61,7 +61,7 @@ def build_emu(force=False):
             os.path.join(EMU, "hip"), os.path.join(EMU, "hip_emu.cpp")]
     if force or _newer(out, deps):
         _run([HOSTCXX, "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-I", EMU, "-Wall",
-              "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable",
+              "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable", "-Wno-psabi",
               os.path.join(CSRC, "rt_capi.hip"), os.path.join(EMU, "hip_emu.cpp"), "-o", out])
     return out
 
@@ -89,6 +89,31 @@ def build_host_emu(force=False):
     deps = [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]
     if force or _newer(out, deps):
         _build_host_against(kern, out)
+    return out
+
+
+def build_ref_link_check(force=False):
+    """Compiles the REFERENCE's generated network builders, untouched and where they lie, against our
+    NvInfer.h / redtail_tensorrt_plugins.h and links them to libnvstereo_inference.so: the drop-in
+    check of the API surface.  Output goes to oracle/_ref/ (git-ignored; travels to the GPU box so the
+    GPU tests can run the reference-defined graphs).  Skipped when /root/reference is absent."""
+    ref = os.environ.get("RT_REFERENCE", "/root/reference")
+    app = os.path.join(ref, "stereoDNN", "sample_app")
+    if not os.path.isdir(app):
+        return None
+    outdir = os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "libref_nets.so")
+    nets = [os.path.join(app, f) for f in ("resnet18_2D_513x257_net.cpp", "nvtiny_513x161_net.cpp",
+                                           "nvsmall_1025x321_net.cpp", "resnet18_1025x321_net.cpp")]
+    glue = os.path.join(ROOT, "oracle", "ref_nets_glue.cpp")
+    host = build_host()
+    if force or _newer(out, nets + [glue, host]):
+        libdir, libname = os.path.split(host)
+        _run([GXX, "-std=c++17", "-O1", "-fPIC", "-shared", "-w", "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(ROOT, "redtail_amd", "include")] + nets + [glue] +
+             ["-L", libdir, "-l:" + libname, "-Wl,-Bsymbolic", "-Wl,-rpath,$ORIGIN/../../redtail_amd/lib",
+              "-Wl,-rpath," + libdir, "-o", out])
     return out
 
 

@@ -47,6 +47,7 @@ KERNEL_SYMBOLS = {
     "rt_stream_create": (c_int, [POINTER(c_void_p)]),
     "rt_stream_destroy": (c_int, [c_void_p]),
     "rt_stream_sync": (c_int, [c_void_p]),
+    "rt_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "rt_event_create": (c_int, [POINTER(c_void_p)]),
     "rt_event_destroy": (c_int, [c_void_p]),
     "rt_event_record": (c_int, [c_void_p, c_void_p]),
@@ -190,6 +191,110 @@ class ConvPlan:
     def destroy(self):
         if self.handle:
             self.klib.lib.rt_conv_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole-network ABI (include/rt_stereo_net.h, libnvstereo_inference.so)
+# ---------------------------------------------------------------------------------------------------
+RT_MODEL_RESNET18_2D, RT_MODEL_NVSMALL, RT_MODEL_NVTINY, RT_MODEL_RESNET18 = 0, 1, 2, 3
+MODEL_IDS = {"resnet18_2D": RT_MODEL_RESNET18_2D, "nvsmall": RT_MODEL_NVSMALL, "nvtiny": RT_MODEL_NVTINY,
+             "resnet18": RT_MODEL_RESNET18}
+
+NET_SYMBOLS = {
+    "rt_net_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_char_p]),
+    "rt_net_create_from_memory": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_size_t]),
+    "rt_net_execute": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_net_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_char_p, c_size_t]),
+    "rt_net_num_layers": (c_int, [c_void_p]),
+    "rt_net_num_launches": (c_int, [c_void_p]),
+    "rt_net_destroy": (c_int, [c_void_p]),
+    "rt_net_last_error": (c_char_p, []),
+}
+
+
+def pack_weights(weights, fp16=False):
+    """dict name -> array  ==>  bytes in trt_weights.bin layout (scripts/tensorrt_model_builder.py:52-60)."""
+    import struct
+
+    import numpy as np
+    out = bytearray()
+    for name, v in weights.items():
+        flat = np.asarray(v).reshape(-1)
+        out += name.encode() + b"\0" + struct.pack("<I", flat.size)
+        out += flat.astype("<f2" if fp16 else "<f4").tobytes()
+    return bytes(out)
+
+
+class NetLib:
+    """libnvstereo_inference.so: the NvInfer.h shim + plugins + executor, through the C ABI."""
+
+    def __init__(self, host_path=None, kernels_path=None):
+        self.kernels = KernelLib(kernels_path)          # loads (and checks) the kernel library first
+        path = host_path or HOST_LIB
+        if not os.path.exists(path):
+            raise RtError("native library %s is missing -- run `python -m redtail_amd.build`" % path)
+        self.lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in NET_SYMBOLS.items():
+            fn = getattr(self.lib, name)
+            fn.restype, fn.argtypes = res, args
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RtError("%s failed (%d): %s" % (what, rc, self.lib.rt_net_last_error().decode()))
+
+    def create(self, model, width, height, max_batch=1, weights=None, weights_path=None, fp16_weights=False,
+               max_disp=0):
+        h = c_void_p()
+        dt = RT_F16 if fp16_weights else RT_F32
+        mid = MODEL_IDS[model] if isinstance(model, str) else model
+        if weights_path is not None:
+            rc = self.lib.rt_net_create(ctypes.byref(h), mid, width, height, max_batch, dt, max_disp,
+                                        weights_path.encode())
+        else:
+            blob = weights if isinstance(weights, (bytes, bytearray)) else pack_weights(weights, fp16_weights)
+            rc = self.lib.rt_net_create_from_memory(ctypes.byref(h), mid, width, height, max_batch, dt, max_disp,
+                                                    blob, len(blob))
+        self.check(rc, "rt_net_create")
+        return StereoNet(self, h, width, height)
+
+
+class StereoNet:
+    def __init__(self, netlib, handle, width, height):
+        self.netlib, self.handle, self.width, self.height = netlib, handle, width, height
+
+    @property
+    def num_layers(self):
+        return self.netlib.lib.rt_net_num_layers(self.handle)
+
+    @property
+    def num_launches(self):
+        return self.netlib.lib.rt_net_num_launches(self.handle)
+
+    def execute(self, left, right, disp, batch=1, stream=None):
+        self.netlib.check(self.netlib.lib.rt_net_execute(self.handle, _ptr(left), _ptr(right), _ptr(disp), batch, stream),
+                          "rt_net_execute")
+
+    def profile(self, left, right, disp, batch=1):
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.netlib.check(self.netlib.lib.rt_net_profile(self.handle, _ptr(left), _ptr(right), _ptr(disp), batch, buf,
+                                                         len(buf)), "rt_net_profile")
+        rows = []
+        for line in buf.value.decode().splitlines():
+            name, ms = line.rsplit("\t", 1)
+            rows.append((name, float(ms)))
+        return rows
+
+    def destroy(self):
+        if self.handle:
+            self.netlib.lib.rt_net_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -1,0 +1,958 @@
+// Static-graph builder and fusing executor behind the NvInfer.h shim.
+//
+// TensorRT is the (closed-source) runtime the reference plugs into; on MI355X this file takes its
+// place for the Stereo DNN graphs: INetworkDefinition records layers, buildCudaEngine() runs shape
+// inference + the plugin life cycle (getOutputDimensions -> supportsFormat -> configure[WithFormat]
+// -> getWorkspaceSize, as listed in SURVEY.md 8b), lowers the graph to a short list of kernel
+// launches and fuses what TensorRT could not fuse across a plugin boundary:
+//     conv/deconv (+ residual add) (+ ELU plugin | sigmoid)  ->  one MFMA kernel with fused epilogue
+//     correlation cost volume + soft-argmax                    ->  one kernel, volume never in HBM
+//     identity scale / reshape                                 ->  aliases
+//     Conv3D + Transform(+ELU), Pad before Conv3D, Conv3DTranspose + Slice (+add +ELU) -> one kernel
+// Independent branches (the left and right encoders) are issued on two HIP streams.
+// Every launch goes through the C ABI of include/rt_stereo.h; there is no CPU compute path.
+#include <algorithm>
+#include <cassert>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "NvInfer.h"
+#include "plugin_internal.h"
+#include "rt_stereo.h"
+
+namespace nvinfer1 {
+namespace {
+
+using redtail::tensorrt::CostVolumeType;
+using redtail::tensorrt::SoftargmaxType;
+using redtail::tensorrt::internal::ConvFusion;
+using redtail::tensorrt::internal::IStereoPlugin;
+using redtail::tensorrt::internal::Kind;
+
+size_t volume(const Dims& d) {
+    size_t n = 1;
+    for (int i = 0; i < d.nbDims; i++) n *= (size_t)d.d[i];
+    return n;
+}
+
+struct LayerData;
+
+// ---- tensors -----------------------------------------------------------------------------------------
+struct TensorImpl : public ITensor {
+    std::string name;
+    Dims dims{};
+    int id = -1;
+    LayerData* producer = nullptr;
+    int producer_out = 0;
+    bool is_input = false, is_output = false;
+    // executor state
+    int alias_of = -1;          // shares the buffer of another tensor (identity scale, reshape)
+    int64_t alias_off = 0;      // element offset inside the aliased buffer (per sample)
+    int64_t bstride = 0;        // per-sample stride in elements (0 = dense volume)
+    void* dev = nullptr;
+    int stream = 0;             // which of the two execution streams produces it
+
+    void setName(const char* n) override { name = n ? n : ""; }
+    const char* getName() const override { return name.c_str(); }
+    void setDimensions(Dims d) override { dims = d; }
+    Dims getDimensions() const override { return dims; }
+    DataType getType() const override { return DataType::kFLOAT; }
+    bool isNetworkInput() const override { return is_input; }
+    bool isNetworkOutput() const override { return is_output; }
+};
+
+// ---- layers ------------------------------------------------------------------------------------------
+struct LayerData {
+    LayerType type;
+    std::string name;
+    std::vector<TensorImpl*> in, out;
+    // convolution / deconvolution
+    int nb_maps = 0;
+    DimsHW ksize{1, 1}, stride{1, 1}, padding{0, 0};
+    Weights kernel{DataType::kFLOAT, nullptr, 0}, bias{DataType::kFLOAT, nullptr, 0};
+    // others
+    ActivationType act = ActivationType::kRELU;
+    ScaleMode scale_mode = ScaleMode::kUNIFORM;
+    Weights shift{DataType::kFLOAT, nullptr, 0}, scale{DataType::kFLOAT, nullptr, 0}, power{DataType::kFLOAT, nullptr, 0};
+    ElementWiseOperation ew = ElementWiseOperation::kSUM;
+    Dims reshape{};
+    DimsHW pre_pad{0, 0}, post_pad{0, 0};
+    IPlugin* plugin = nullptr;
+    bool plugin_ext = false;
+    virtual void recomputeShapes() {}
+    virtual ~LayerData() {}
+};
+
+template <typename Iface>
+struct LayerImpl : public Iface, public LayerData {
+    LayerType getType() const override { return type; }
+    void setName(const char* n) override { name = n ? n : ""; }
+    const char* getName() const override { return name.c_str(); }
+    int getNbInputs() const override { return (int)in.size(); }
+    ITensor* getInput(int i) const override { return i >= 0 && i < (int)in.size() ? in[i] : nullptr; }
+    int getNbOutputs() const override { return (int)out.size(); }
+    ITensor* getOutput(int i) const override { return i >= 0 && i < (int)out.size() ? out[i] : nullptr; }
+};
+
+template <typename Iface, bool kDeconv>
+struct ConvLayerImpl : public LayerImpl<Iface> {
+    void setKernelSize(DimsHW k) override { this->ksize = k; recomputeShapes(); }
+    DimsHW getKernelSize() const override { return this->ksize; }
+    void setNbOutputMaps(int n) override { this->nb_maps = n; recomputeShapes(); }
+    int getNbOutputMaps() const override { return this->nb_maps; }
+    void setStride(DimsHW s) override { this->stride = s; recomputeShapes(); }
+    DimsHW getStride() const override { return this->stride; }
+    void setPadding(DimsHW p) override { this->padding = p; recomputeShapes(); }
+    DimsHW getPadding() const override { return this->padding; }
+    void setKernelWeights(Weights w) override { this->kernel = w; }
+    Weights getKernelWeights() const override { return this->kernel; }
+    void setBiasWeights(Weights w) override { this->bias = w; }
+    Weights getBiasWeights() const override { return this->bias; }
+    void recomputeShapes() override {
+        const Dims& x = this->in[0]->dims;
+        int ho, wo;
+        if (kDeconv) {
+            ho = (x.d[1] - 1) * this->stride.h() - 2 * this->padding.h() + this->ksize.h();
+            wo = (x.d[2] - 1) * this->stride.w() - 2 * this->padding.w() + this->ksize.w();
+        } else {
+            ho = (x.d[1] + 2 * this->padding.h() - this->ksize.h()) / this->stride.h() + 1;
+            wo = (x.d[2] + 2 * this->padding.w() - this->ksize.w()) / this->stride.w() + 1;
+        }
+        this->out[0]->dims = DimsCHW(this->nb_maps, ho, wo);
+    }
+};
+struct ActivationImpl : public LayerImpl<IActivationLayer> {
+    void setActivationType(ActivationType t) override { act = t; }
+    ActivationType getActivationType() const override { return act; }
+};
+struct ScaleImpl : public LayerImpl<IScaleLayer> {
+    ScaleMode getMode() const override { return scale_mode; }
+    Weights getShift() const override { return shift; }
+    Weights getScale() const override { return scale; }
+    Weights getPower() const override { return power; }
+};
+struct ElementWiseImpl : public LayerImpl<IElementWiseLayer> {
+    void setOperation(ElementWiseOperation o) override { ew = o; }
+    ElementWiseOperation getOperation() const override { return ew; }
+};
+struct ConcatImpl : public LayerImpl<IConcatenationLayer> {
+    void setAxis(int) override {}
+    int getAxis() const override { return 0; }
+};
+struct PaddingImpl : public LayerImpl<IPaddingLayer> {
+    DimsHW getPrePadding() const override { return pre_pad; }
+    DimsHW getPostPadding() const override { return post_pad; }
+};
+struct ShuffleImpl : public LayerImpl<IShuffleLayer> {
+    void setFirstTranspose(Permutation) override {}
+    void setSecondTranspose(Permutation) override {}
+    void setReshapeDimensions(Dims d) override {
+        assert(volume(d) == volume(in[0]->dims) && "reshape must preserve the volume");
+        reshape = d;
+        out[0]->dims = d;
+    }
+    Dims getReshapeDimensions() const override { return reshape; }
+};
+struct PluginLayerImpl : public LayerImpl<IPluginLayer> {
+    IPlugin& getPlugin() override { return *plugin; }
+};
+
+// ---- network -----------------------------------------------------------------------------------------
+class NetworkImpl : public INetworkDefinition {
+public:
+    explicit NetworkImpl(ILogger& log) : log_(log) {}
+    ~NetworkImpl() override {}
+
+    ITensor* addInput(const char* name, DataType, Dims dims) override {
+        TensorImpl* t = newTensor(name);
+        t->dims = dims;
+        t->is_input = true;
+        inputs_.push_back(t);
+        return t;
+    }
+    void markOutput(ITensor& t) override {
+        auto* ti = static_cast<TensorImpl*>(&t);
+        ti->is_output = true;
+        outputs_.push_back(ti);
+    }
+    IConvolutionLayer* addConvolution(ITensor& x, int maps, DimsHW k, Weights w, Weights b) override {
+        auto* l = add<ConvLayerImpl<IConvolutionLayer, false>>(LayerType::kCONVOLUTION, {&x}, 1);
+        l->nb_maps = maps; l->ksize = k; l->kernel = w; l->bias = b;
+        l->recomputeShapes();
+        return l;
+    }
+    IDeconvolutionLayer* addDeconvolution(ITensor& x, int maps, DimsHW k, Weights w, Weights b) override {
+        auto* l = add<ConvLayerImpl<IDeconvolutionLayer, true>>(LayerType::kDECONVOLUTION, {&x}, 1);
+        l->nb_maps = maps; l->ksize = k; l->kernel = w; l->bias = b;
+        l->recomputeShapes();
+        return l;
+    }
+    IActivationLayer* addActivation(ITensor& x, ActivationType t) override {
+        auto* l = add<ActivationImpl>(LayerType::kACTIVATION, {&x}, 1);
+        l->act = t;
+        l->out[0]->dims = l->in[0]->dims;
+        return l;
+    }
+    IScaleLayer* addScale(ITensor& x, ScaleMode mode, Weights shift, Weights scale, Weights power) override {
+        auto* l = add<ScaleImpl>(LayerType::kSCALE, {&x}, 1);
+        l->scale_mode = mode; l->shift = shift; l->scale = scale; l->power = power;
+        l->out[0]->dims = l->in[0]->dims;
+        return l;
+    }
+    IElementWiseLayer* addElementWise(ITensor& a, ITensor& b, ElementWiseOperation op) override {
+        auto* l = add<ElementWiseImpl>(LayerType::kELEMENTWISE, {&a, &b}, 1);
+        l->ew = op;
+        assert(volume(l->in[0]->dims) == volume(l->in[1]->dims));
+        l->out[0]->dims = l->in[0]->dims;
+        return l;
+    }
+    IConcatenationLayer* addConcatenation(ITensor* const* ins, int n) override {
+        std::vector<ITensor*> v(ins, ins + n);
+        auto* l = add<ConcatImpl>(LayerType::kCONCATENATION, v, 1);
+        Dims d = l->in[0]->dims;
+        for (int i = 1; i < n; i++) d.d[0] += l->in[i]->dims.d[0];
+        l->out[0]->dims = d;
+        return l;
+    }
+    IPaddingLayer* addPadding(ITensor& x, DimsHW pre, DimsHW post) override {
+        auto* l = add<PaddingImpl>(LayerType::kPADDING, {&x}, 1);
+        l->pre_pad = pre; l->post_pad = post;
+        Dims d = l->in[0]->dims;
+        d.d[1] += pre.h() + post.h();
+        d.d[2] += pre.w() + post.w();
+        l->out[0]->dims = d;
+        return l;
+    }
+    IShuffleLayer* addShuffle(ITensor& x) override {
+        auto* l = add<ShuffleImpl>(LayerType::kSHUFFLE, {&x}, 1);
+        l->out[0]->dims = l->in[0]->dims;
+        l->reshape = l->in[0]->dims;
+        return l;
+    }
+    IPluginLayer* addPlugin(ITensor* const* ins, int n, IPlugin& plugin) override { return addPluginImpl(ins, n, plugin, false); }
+    IPluginLayer* addPluginExt(ITensor* const* ins, int n, IPluginExt& plugin) override { return addPluginImpl(ins, n, plugin, true); }
+
+    int getNbLayers() const override { return (int)layers_.size(); }
+    ILayer* getLayer(int i) const override { return ilayers_[i]; }
+    int getNbInputs() const override { return (int)inputs_.size(); }
+    ITensor* getInput(int i) const override { return inputs_[i]; }
+    int getNbOutputs() const override { return (int)outputs_.size(); }
+    ITensor* getOutput(int i) const override { return outputs_[i]; }
+    void destroy() override { delete this; }
+
+    // the engine takes ownership of the graph
+    std::vector<std::unique_ptr<TensorImpl>> tensors_;
+    std::vector<std::unique_ptr<LayerData>> layers_;
+    std::vector<ILayer*> ilayers_;
+    std::vector<TensorImpl*> inputs_, outputs_;
+    ILogger& log_;
+
+private:
+    TensorImpl* newTensor(const char* name) {
+        tensors_.emplace_back(new TensorImpl());
+        TensorImpl* t = tensors_.back().get();
+        t->id = (int)tensors_.size() - 1;
+        t->name = name ? name : "";
+        return t;
+    }
+    template <typename L>
+    L* add(LayerType type, std::vector<ITensor*> ins, int nout) {
+        L* l = new L();
+        l->type = type;
+        l->name = "(Unnamed Layer* " + std::to_string(layers_.size()) + ")";
+        for (ITensor* t : ins) l->in.push_back(static_cast<TensorImpl*>(t));
+        for (int i = 0; i < nout; i++) {
+            TensorImpl* o = newTensor((l->name + "_output_" + std::to_string(i)).c_str());
+            o->producer = l;
+            o->producer_out = i;
+            l->out.push_back(o);
+        }
+        layers_.emplace_back(l);
+        ilayers_.push_back(l);
+        return l;
+    }
+    IPluginLayer* addPluginImpl(ITensor* const* ins, int n, IPlugin& plugin, bool ext) {
+        std::vector<ITensor*> v(ins, ins + n);
+        const int nout = plugin.getNbOutputs();
+        auto* l = add<PluginLayerImpl>(LayerType::kPLUGIN, v, nout);
+        l->plugin = &plugin;
+        l->plugin_ext = ext;
+        std::vector<Dims> in_dims;
+        for (auto* t : l->in) in_dims.push_back(t->dims);
+        for (int i = 0; i < nout; i++) l->out[i]->dims = plugin.getOutputDimensions(i, in_dims.data(), (int)in_dims.size());
+        return l;
+    }
+};
+
+// ---- lowered program -----------------------------------------------------------------------------------
+enum class OpKind { kConv, kPlugin, kConv3D, kAdd, kAct, kConcat, kCorrSoftargmax, kCopy };
+
+struct Op {
+    OpKind kind;
+    std::string name;                  // layer name reported to the profiler (first layer of a fused group)
+    std::vector<int> in;               // tensor ids
+    int out = -1;
+    int resid = -1;
+    int act = RT_ACT_NONE;
+    rtConvPlan* plan = nullptr;        // kConv
+    IPlugin* plugin = nullptr;         // kPlugin / kConv3D
+    IStereoPlugin* splugin = nullptr;  // kConv3D
+    int max_disp = 0, is_min = 0;      // kCorrSoftargmax
+    int stream = 0;
+    std::vector<int> wait_on;          // tensors produced on the other stream that this op consumes
+    bool publish = false;              // another stream consumes the result: record an event after the launch
+};
+
+class EngineImpl;
+
+class ContextImpl : public IExecutionContext {
+public:
+    explicit ContextImpl(EngineImpl& e);
+    ~ContextImpl() override;
+    bool execute(int batchSize, void** bindings) override;
+    bool enqueue(int batchSize, void** bindings, cudaStream_t stream, cudaEvent_t* inputConsumed) override;
+    void setDebugSync(bool s) override { debug_sync_ = s; }
+    bool getDebugSync() const override { return debug_sync_; }
+    void setProfiler(IProfiler* p) override { profiler_ = p; }
+    IProfiler* getProfiler() const override { return profiler_; }
+    const ICudaEngine& getEngine() const override;
+    void destroy() override { delete this; }
+
+private:
+    bool run(int batch, void** bindings, cudaStream_t stream, bool sync);
+    bool ensureBuffers(int batch);
+    void* addr(int tensor, int batch, void** bindings) const;
+
+    EngineImpl& eng_;
+    IProfiler* profiler_ = nullptr;
+    bool debug_sync_ = false;
+    int alloc_batch_ = 0;
+    std::vector<void*> buffers_;       // per tensor id (owned)
+    void* workspace_ = nullptr;
+    size_t workspace_bytes_ = 0;
+    rtStream side_stream_ = nullptr;
+    rtStream main_stream_ = nullptr;   // execute() runs on its own stream, never on the NULL stream
+    std::vector<void*> events_;        // per tensor id, lazily created
+    void* ev_fork_ = nullptr;
+    void* ev_join_ = nullptr;
+};
+
+class HostMemory : public IHostMemory {
+public:
+    std::string blob;
+    void* data() const override { return const_cast<char*>(blob.data()); }
+    std::size_t size() const override { return blob.size(); }
+    DataType type() const override { return DataType::kINT8; }
+    void destroy() override { delete this; }
+};
+
+class EngineImpl : public ICudaEngine {
+public:
+    EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log);
+    ~EngineImpl() override;
+    bool ok() const { return ok_; }
+
+    int getNbBindings() const override { return (int)bindings_.size(); }
+    int getBindingIndex(const char* name) const override {
+        for (size_t i = 0; i < bindings_.size(); i++)
+            if (tensors_[bindings_[i]]->name == name) return (int)i;
+        return -1;
+    }
+    const char* getBindingName(int i) const override { return tensors_[bindings_[i]]->name.c_str(); }
+    bool bindingIsInput(int i) const override { return tensors_[bindings_[i]]->is_input; }
+    Dims getBindingDimensions(int i) const override { return tensors_[bindings_[i]]->dims; }
+    DataType getBindingDataType(int) const override { return DataType::kFLOAT; }
+    int getMaxBatchSize() const override { return max_batch_; }
+    int getNbLayers() const override { return (int)ops_.size(); }
+    std::size_t getWorkspaceSize() const override { return workspace_bytes_; }
+    IHostMemory* serialize() const override;
+    IExecutionContext* createExecutionContext() override {
+        for (auto& l : layers_)
+            if (l->plugin && l->plugin->initialize() != 0)
+                log_.log(ILogger::Severity::kERROR, (l->name + ": plugin initialize() failed").c_str());
+        return new ContextImpl(*this);
+    }
+    void destroy() override { delete this; }
+
+    // graph (moved out of the network)
+    std::vector<std::unique_ptr<TensorImpl>> tensors_;
+    std::vector<std::unique_ptr<LayerData>> layers_;
+    std::vector<int> bindings_;        // tensor ids: inputs in declaration order, then outputs
+    std::vector<Op> ops_;
+    int max_batch_;
+    size_t workspace_bytes_ = 0;
+    bool two_streams_ = false;
+    ILogger& log_;
+
+private:
+    int root(int t) const {
+        while (tensors_[t]->alias_of >= 0) t = tensors_[t]->alias_of;
+        return t;
+    }
+    int consumers(int t) const {
+        int n = 0;
+        for (auto& l : layers_)
+            for (auto* i : l->in)
+                if (i->id == t) n++;
+        return n + (tensors_[t]->is_output ? 1 : 0);
+    }
+    LayerData* soleConsumer(int t) const {
+        if (consumers(t) != 1 || tensors_[t]->is_output) return nullptr;
+        for (auto& l : layers_)
+            for (auto* i : l->in)
+                if (i->id == t) return l.get();
+        return nullptr;
+    }
+    static IStereoPlugin* stereo(LayerData* l) { return l && l->plugin ? dynamic_cast<IStereoPlugin*>(l->plugin) : nullptr; }
+    static bool isKind(LayerData* l, Kind k) { auto* s = stereo(l); return s && s->kind() == k; }
+    bool lower();
+    void assignStreams();
+    bool ok_ = false;
+    bool half2_ = false;
+};
+
+// ---- building ------------------------------------------------------------------------------------------------
+EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log) : max_batch_(max_batch), log_(log), half2_(half2) {
+    tensors_ = std::move(net.tensors_);
+    layers_ = std::move(net.layers_);
+    for (auto* t : net.inputs_) bindings_.push_back(t->id);
+    for (auto* t : net.outputs_) bindings_.push_back(t->id);
+    net.inputs_.clear();
+    net.outputs_.clear();
+    net.ilayers_.clear();
+
+    // plugin life cycle (TensorRT build phase)
+    for (auto& l : layers_) {
+        if (!l->plugin) continue;
+        std::vector<Dims> in_dims, out_dims;
+        for (auto* t : l->in) in_dims.push_back(t->dims);
+        for (auto* t : l->out) out_dims.push_back(t->dims);
+        if (l->plugin_ext) {
+            auto* ext = static_cast<IPluginExt*>(l->plugin);
+            // activations are fp32 NCHW in this build; a plugin created for kHALF is asked for its own type
+            DataType type = ext->supportsFormat(DataType::kFLOAT, PluginFormat::kNCHW) ? DataType::kFLOAT : DataType::kHALF;
+            PluginFormat fmt = PluginFormat::kNCHW;
+            if (!ext->supportsFormat(type, fmt)) fmt = PluginFormat::kNC2HW2;
+            if (type != DataType::kFLOAT) {
+                log_.log(ILogger::Severity::kERROR, (l->name + ": fp16 activation tensors are not supported by this engine build").c_str());
+                return;
+            }
+            ext->configureWithFormat(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), type, fmt, max_batch_);
+        } else {
+            l->plugin->configure(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), max_batch_);
+        }
+        workspace_bytes_ = std::max(workspace_bytes_, l->plugin->getWorkspaceSize(max_batch_));
+    }
+    ok_ = lower();
+    if (ok_) assignStreams();
+}
+
+EngineImpl::~EngineImpl() {
+    for (auto& op : ops_)
+        if (op.plan) rt_conv_plan_destroy(op.plan);
+    for (auto& l : layers_)
+        if (l->plugin) l->plugin->terminate();
+}
+
+static bool isIdentityScale(const LayerData& l) {
+    auto val = [](const Weights& w, float dflt) {
+        if (w.count == 0 || !w.values) return dflt;
+        if (w.type == DataType::kHALF) {
+            uint16_t h;
+            std::memcpy(&h, w.values, 2);
+            // only exact 0 / 1 matter here
+            return h == 0 ? 0.f : (h == 0x3c00 ? 1.f : -1234.f);
+        }
+        float f;
+        std::memcpy(&f, w.values, 4);
+        return f;
+    };
+    return l.scale_mode == ScaleMode::kUNIFORM && val(l.shift, 0.f) == 0.f && val(l.scale, 1.f) == 1.f && val(l.power, 1.f) == 1.f;
+}
+
+bool EngineImpl::lower() {
+    std::vector<bool> done(layers_.size(), false);
+    auto index_of = [&](LayerData* l) {
+        for (size_t i = 0; i < layers_.size(); i++)
+            if (layers_[i].get() == l) return (int)i;
+        return -1;
+    };
+    auto fail = [&](const std::string& msg) {
+        log_.log(ILogger::Severity::kERROR, msg.c_str());
+        return false;
+    };
+    const bool fuse = getenv("RT_NO_FUSION") == nullptr;
+
+    for (size_t li = 0; li < layers_.size(); li++) {
+        if (done[li]) continue;
+        LayerData* l = layers_[li].get();
+        done[li] = true;
+        Op op;
+        op.name = l->name;
+        for (auto* t : l->in) op.in.push_back(t->id);
+        op.out = l->out[0]->id;
+
+        switch (l->type) {
+            case LayerType::kSCALE: {
+                if (!isIdentityScale(*l)) return fail(l->name + ": only identity scale layers occur in the Stereo DNN graphs");
+                l->out[0]->alias_of = l->in[0]->id;
+                continue;
+            }
+            case LayerType::kSHUFFLE: {
+                l->out[0]->alias_of = l->in[0]->id;
+                continue;
+            }
+            case LayerType::kCONVOLUTION:
+            case LayerType::kDECONVOLUTION: {
+                const bool deconv = l->type == LayerType::kDECONVOLUTION;
+                const Dims& x = l->in[0]->dims;
+                if (l->ksize.h() != l->ksize.w() || l->stride.h() != l->stride.w())
+                    return fail(l->name + ": non-square kernels / strides are not used by the Stereo DNN graphs");
+                // greedy epilogue fusion: [+ residual] [+ ELU plugin | sigmoid]
+                TensorImpl* cur = l->out[0];
+                int resid = -1, act = RT_ACT_NONE;
+                if (fuse) {
+                    LayerData* nx = soleConsumer(cur->id);
+                    if (nx && nx->type == LayerType::kELEMENTWISE && nx->ew == ElementWiseOperation::kSUM) {
+                        TensorImpl* other = nx->in[0] == cur ? nx->in[1] : nx->in[0];
+                        // the residual must already exist when the conv runs
+                        if (other != cur && (other->producer == nullptr || index_of(other->producer) < (int)li || done[index_of(other->producer)])) {
+                            resid = other->id;
+                            done[index_of(nx)] = true;
+                            cur = nx->out[0];
+                            nx = soleConsumer(cur->id);
+                        }
+                    }
+                    if (nx && isKind(nx, Kind::kElu)) {
+                        act = RT_ACT_ELU;
+                        done[index_of(nx)] = true;
+                        cur = nx->out[0];
+                    } else if (nx && nx->type == LayerType::kACTIVATION && nx->act == ActivationType::kSIGMOID) {
+                        act = RT_ACT_SIGMOID;
+                        done[index_of(nx)] = true;
+                        cur = nx->out[0];
+                    }
+                }
+                rtConv2dDesc d{};
+                d.Cin = x.d[0]; d.Cout = l->nb_maps; d.Hin = x.d[1]; d.Win = x.d[2];
+                d.KH = l->ksize.h(); d.KW = l->ksize.w(); d.stride = l->stride.h();
+                d.pad_h = l->padding.h(); d.pad_w = l->padding.w();
+                d.act = act; d.has_residual = resid >= 0;
+                d.dtype = l->kernel.type == DataType::kHALF ? RT_F16 : RT_F32;
+                const int64_t expect = (int64_t)d.Cin * d.Cout * d.KH * d.KW;
+                if (l->kernel.count != expect) return fail(l->name + ": kernel weight count does not match the layer shape");
+                if (l->bias.count != 0 && l->bias.count != d.Cout) return fail(l->name + ": bias count does not match");
+                int rc = deconv ? rt_deconv2d_plan_create(&op.plan, &d, l->kernel.values, l->bias.count ? l->bias.values : nullptr)
+                                : rt_conv2d_plan_create(&op.plan, &d, l->kernel.values, l->bias.count ? l->bias.values : nullptr);
+                if (rc) return fail(l->name + ": " + rt_last_error_string());
+                op.kind = OpKind::kConv;
+                op.resid = resid;
+                op.act = act;
+                op.out = cur->id;
+                ops_.push_back(op);
+                continue;
+            }
+            case LayerType::kELEMENTWISE: {
+                if (l->ew != ElementWiseOperation::kSUM) return fail(l->name + ": only kSUM is used by the Stereo DNN graphs");
+                op.kind = OpKind::kAdd;
+                TensorImpl* cur = l->out[0];
+                LayerData* nx = fuse ? soleConsumer(cur->id) : nullptr;
+                if (nx && isKind(nx, Kind::kElu)) {
+                    op.act = RT_ACT_ELU;
+                    done[index_of(nx)] = true;
+                    cur = nx->out[0];
+                }
+                op.out = cur->id;
+                ops_.push_back(op);
+                continue;
+            }
+            case LayerType::kACTIVATION: {
+                if (l->act != ActivationType::kSIGMOID) return fail(l->name + ": only sigmoid activations are used");
+                op.kind = OpKind::kAct;
+                op.act = RT_ACT_SIGMOID;
+                ops_.push_back(op);
+                continue;
+            }
+            case LayerType::kCONCATENATION: {
+                op.kind = OpKind::kConcat;
+                ops_.push_back(op);
+                continue;
+            }
+            case LayerType::kPLUGIN: {
+                IStereoPlugin* sp = stereo(l);
+                // correlation cost volume feeding only a soft-argmax: one fused kernel
+                if (fuse && sp && sp->kind() == Kind::kCostVolume && sp->costVolumeType() == CostVolumeType::kCorrelation &&
+                    sp->maxDisparity() <= 64) {
+                    LayerData* nx = soleConsumer(l->out[0]->id);
+                    if (nx && isKind(nx, Kind::kSoftargmax)) {
+                        op.kind = OpKind::kCorrSoftargmax;
+                        op.max_disp = sp->maxDisparity();
+                        op.is_min = stereo(nx)->softargmaxType() == SoftargmaxType::kMin;
+                        op.out = nx->out[0]->id;
+                        done[index_of(nx)] = true;
+                        ops_.push_back(op);
+                        continue;
+                    }
+                }
+                // Conv3D [+ Transform {1,0,2,3}] [+ ELU]   (Pad before a Conv3D is folded by the table)
+                if (fuse && sp && (sp->kind() == Kind::kConv3D || sp->kind() == Kind::kConv3DTranspose)) {
+                    ConvFusion f;
+                    TensorImpl* cur = l->out[0];
+                    std::vector<int> absorbed;
+                    LayerData* nx = soleConsumer(cur->id);
+                    if (sp->kind() == Kind::kConv3D && nx && isKind(nx, Kind::kTransform)) {
+                        Permutation p = stereo(nx)->permutation();
+                        if (p.order[0] == 1 && p.order[1] == 0 && p.order[2] == 2 && p.order[3] == 3) {
+                            f.out_dchw = true;
+                            absorbed.push_back(index_of(nx));
+                            cur = nx->out[0];
+                            nx = soleConsumer(cur->id);
+                        }
+                    }
+                    int resid = -1;
+                    if (nx && nx->type == LayerType::kELEMENTWISE && nx->ew == ElementWiseOperation::kSUM &&
+                        volume(nx->out[0]->dims) == volume(cur->dims)) {
+                        TensorImpl* other = nx->in[0] == cur ? nx->in[1] : nx->in[0];
+                        if (other != cur && (other->producer == nullptr || done[index_of(other->producer)])) {
+                            resid = other->id;
+                            f.residual = true;
+                            absorbed.push_back(index_of(nx));
+                            cur = nx->out[0];
+                            nx = soleConsumer(cur->id);
+                        }
+                    }
+                    if (nx && isKind(nx, Kind::kElu)) {
+                        f.act = RT_ACT_ELU;
+                        absorbed.push_back(index_of(nx));
+                        cur = nx->out[0];
+                    }
+                    if ((f.act || f.out_dchw || f.residual) && sp->setFusion(f)) {
+                        for (int a : absorbed) done[a] = true;
+                        op.kind = OpKind::kConv3D;
+                        op.plugin = l->plugin;
+                        op.splugin = sp;
+                        op.resid = resid;
+                        op.out = cur->id;
+                        ops_.push_back(op);
+                        continue;
+                    }
+                }
+                op.kind = OpKind::kPlugin;
+                op.plugin = l->plugin;
+                if (l->out.size() != 1) return fail(l->name + ": multi-output plugins are not supported");
+                ops_.push_back(op);
+                continue;
+            }
+            default:
+                return fail(l->name + ": layer type not supported by the Stereo DNN engine");
+        }
+    }
+    std::ostringstream s;
+    s << "engine: " << layers_.size() << " layers lowered to " << ops_.size() << " launches";
+    log_.log(ILogger::Severity::kINFO, s.str().c_str());
+    return true;
+}
+
+// Two-stream schedule: everything that depends only on the SECOND network input runs on the side
+// stream (the right-image encoder); ops that mix both wait on events.
+void EngineImpl::assignStreams() {
+    if (getenv("RT_SINGLE_STREAM")) return;
+    int n_inputs = 0;
+    for (int b : bindings_)
+        if (tensors_[b]->is_input) n_inputs++;
+    if (n_inputs != 2) return;
+    const int second = bindings_[1];
+    std::vector<int> dep(tensors_.size(), 0);      // bit0: depends on input 0 / others, bit1: depends on second input
+    for (auto& t : tensors_)
+        if (t->is_input) dep[t->id] = t->id == second ? 2 : 1;
+    auto dep_of = [&](int t) { return dep[root(t)]; };
+    int side_ops = 0;
+    for (auto& op : ops_) {
+        int d = 0;
+        for (int i : op.in) d |= dep_of(i);
+        if (op.resid >= 0) d |= dep_of(op.resid);
+        dep[root(op.out)] |= d;
+        dep[op.out] |= d;
+        op.stream = d == 2 ? 1 : 0;
+        tensors_[op.out]->stream = op.stream;
+        tensors_[root(op.out)]->stream = op.stream;
+        side_ops += op.stream;
+    }
+    if (side_ops < 4) {          // not worth a second stream
+        for (auto& op : ops_) op.stream = 0;
+        for (auto& t : tensors_) t->stream = 0;
+        return;
+    }
+    two_streams_ = true;
+    for (auto& op : ops_) {
+        auto consider = [&](int t) {
+            const int r = root(t);
+            if (!tensors_[r]->is_input && tensors_[r]->stream != op.stream) op.wait_on.push_back(r);
+        };
+        for (int i : op.in) consider(i);
+        if (op.resid >= 0) consider(op.resid);
+    }
+    for (auto& op : ops_)
+        for (auto& o2 : ops_)
+            for (int w : o2.wait_on) op.publish |= (w == root(op.out));
+}
+
+IHostMemory* EngineImpl::serialize() const {
+    // Plan = the serialisable plugins' blobs in layer order (same blobs StereoDnnPluginFactory reads);
+    // the graph itself is rebuilt from the network builder, so this is a plugin manifest rather than
+    // a TensorRT plan.  See INTEGRATION.md.
+    auto* m = new HostMemory();
+    for (auto& l : layers_) {
+        if (!l->plugin) continue;
+        const size_t n = l->plugin->getSerializationSize();
+        if (!n) continue;
+        std::string b(n, '\0');
+        l->plugin->serialize(&b[0]);
+        uint32_t len = (uint32_t)n;
+        m->blob.append(reinterpret_cast<const char*>(&len), 4);
+        m->blob.append(l->name);
+        m->blob.push_back('\0');
+        m->blob.append(b);
+    }
+    return m;
+}
+
+// ---- execution -----------------------------------------------------------------------------------------------
+ContextImpl::ContextImpl(EngineImpl& e) : eng_(e) {
+    buffers_.assign(e.tensors_.size(), nullptr);
+    events_.assign(e.tensors_.size(), nullptr);
+}
+
+ContextImpl::~ContextImpl() {
+    rt_stream_sync(nullptr);
+    for (void* b : buffers_)
+        if (b) rt_free(b);
+    if (workspace_) rt_free(workspace_);
+    for (void* ev : events_)
+        if (ev) rt_event_destroy(ev);
+    if (ev_fork_) rt_event_destroy(ev_fork_);
+    if (ev_join_) rt_event_destroy(ev_join_);
+    if (side_stream_) rt_stream_destroy(side_stream_);
+    if (main_stream_) rt_stream_destroy(main_stream_);
+}
+
+const ICudaEngine& ContextImpl::getEngine() const { return eng_; }
+
+bool ContextImpl::ensureBuffers(int batch) {
+    if (batch <= alloc_batch_) return true;
+    for (void*& b : buffers_) {
+        if (b) rt_free(b);
+        b = nullptr;
+    }
+    for (auto& t : eng_.tensors_) {
+        if (t->is_input || t->is_output || t->alias_of >= 0) continue;
+        bool used = false;
+        for (auto& op : eng_.ops_) {
+            used |= op.out == t->id || op.resid == t->id;
+            for (int i : op.in) used |= i == t->id;
+        }
+        if (!used) continue;
+        if (rt_malloc(&buffers_[t->id], volume(t->dims) * sizeof(float) * (size_t)batch) != 0) {
+            eng_.log_.log(ILogger::Severity::kERROR, (std::string("engine: device allocation failed: ") + rt_last_error_string()).c_str());
+            return false;
+        }
+    }
+    if (eng_.workspace_bytes_ && !workspace_) {
+        if (rt_malloc(&workspace_, eng_.workspace_bytes_) != 0) return false;
+        workspace_bytes_ = eng_.workspace_bytes_;
+    }
+    alloc_batch_ = batch;
+    return true;
+}
+
+void* ContextImpl::addr(int tensor, int, void** bindings) const {
+    int t = tensor;
+    while (eng_.tensors_[t]->alias_of >= 0) t = eng_.tensors_[t]->alias_of;
+    const TensorImpl& ti = *eng_.tensors_[t];
+    if (ti.is_input || ti.is_output) {
+        for (size_t b = 0; b < eng_.bindings_.size(); b++)
+            if (eng_.bindings_[b] == t) return bindings[b];
+    }
+    return buffers_[t];
+}
+
+bool ContextImpl::execute(int batchSize, void** bindings) {
+    if (!main_stream_ && rt_stream_create(&main_stream_) != 0) return false;
+    // execute() is the synchronous API: whatever the caller queued on the NULL stream (uploads, fills)
+    // must be complete before our own non-blocking streams touch the bindings
+    if (rt_stream_sync(nullptr) != 0) return false;
+    return run(batchSize, bindings, (cudaStream_t)main_stream_, true);
+}
+
+bool ContextImpl::enqueue(int batchSize, void** bindings, cudaStream_t stream, cudaEvent_t* inputConsumed) {
+    bool ok = run(batchSize, bindings, stream, false);
+    if (ok && inputConsumed && *inputConsumed) ok = rt_event_record(*inputConsumed, stream) == 0;
+    return ok;
+}
+
+bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync) {
+    ILogger& log = eng_.log_;
+    if (batch < 1 || batch > eng_.max_batch_) {
+        log.log(ILogger::Severity::kERROR, "execute: batch size exceeds the engine's max batch size");
+        return false;
+    }
+    if (!ensureBuffers(batch)) return false;
+    const bool profile = profiler_ != nullptr;
+    const bool two = eng_.two_streams_ && !profile;
+    rtStream main = stream;
+    if (two) {
+        if (!side_stream_ && rt_stream_create(&side_stream_) != 0) return false;
+        if (!ev_fork_) rt_event_create(&ev_fork_);
+        if (!ev_join_) rt_event_create(&ev_join_);
+        // the side stream must not start before work already queued on the caller's stream
+        // (e.g. the H2D copies of the inputs) is done
+        rt_event_record(ev_fork_, main);
+        rt_stream_wait_event(side_stream_, ev_fork_);
+    }
+    void *ev0 = nullptr, *ev1 = nullptr;
+    if (profile) { rt_event_create(&ev0); rt_event_create(&ev1); }
+
+    bool ok = true;
+    for (const Op& op : eng_.ops_) {
+        rtStream st = (two && op.stream == 1) ? side_stream_ : main;
+        if (two)
+            for (int w : op.wait_on)
+                if (events_[w]) rt_stream_wait_event(st, events_[w]);
+        if (profile) rt_event_record(ev0, st);
+        const TensorImpl& out = *eng_.tensors_[op.out];
+        void* y = addr(op.out, batch, bindings);
+        int rc = 0;
+        switch (op.kind) {
+            case OpKind::kConv:
+                rc = rt_conv_enqueue(op.plan, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr, batch, st);
+                break;
+            case OpKind::kConv3D:
+                rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y,
+                                              op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr, (cudaStream_t)st);
+                break;
+            case OpKind::kPlugin: {
+                const void* ins[8];
+                for (size_t i = 0; i < op.in.size() && i < 8; i++) ins[i] = addr(op.in[i], batch, bindings);
+                void* outs[1] = {y};
+                rc = op.plugin->enqueue(batch, ins, outs, workspace_, (cudaStream_t)st);
+                break;
+            }
+            case OpKind::kAdd:
+                rc = rt_add_act(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y,
+                                (int64_t)volume(out.dims) * batch, op.act, RT_F32, st);
+                break;
+            case OpKind::kAct:
+                rc = rt_activation(addr(op.in[0], batch, bindings), y, (int64_t)volume(out.dims) * batch, op.act, RT_F32, st);
+                break;
+            case OpKind::kConcat: {
+                const int ctot = out.dims.d[0];
+                const int64_t inner = (int64_t)volume(out.dims) / ctot;
+                int coff = 0;
+                for (int i : op.in) {
+                    const Dims& d = eng_.tensors_[i]->dims;
+                    if (rc == 0)
+                        rc = rt_concat_channels(addr(i, batch, bindings), y, batch, d.d[0], ctot, coff, inner, RT_F32, st);
+                    coff += d.d[0];
+                }
+                break;
+            }
+            case OpKind::kCorrSoftargmax: {
+                const Dims& f = eng_.tensors_[op.in[0]]->dims;
+                rc = rt_corr_softargmax(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
+                                        f.d[2], op.max_disp, op.is_min, 0, RT_F32, st);
+                break;
+            }
+            case OpKind::kCopy:
+                break;
+        }
+        if (rc != 0) {
+            log.log(ILogger::Severity::kERROR, (op.name + ": launch failed: " + rt_last_error_string()).c_str());
+            ok = false;
+            break;
+        }
+        if (profile) {
+            float ms = 0.f;
+            rt_event_record(ev1, st);
+            rt_event_elapsed_ms(ev0, ev1, &ms);
+            profiler_->reportLayerTime(op.name.c_str(), ms);
+        }
+        if (two && op.publish) {       // make the result visible to the consumer on the other stream
+            int r = op.out;
+            while (eng_.tensors_[r]->alias_of >= 0) r = eng_.tensors_[r]->alias_of;
+            if (!events_[r]) rt_event_create(&events_[r]);
+            rt_event_record(events_[r], st);
+        }
+        if (debug_sync_) rt_stream_sync(st);
+    }
+    if (two) {
+        rt_event_record(ev_join_, side_stream_);
+        rt_stream_wait_event(main, ev_join_);
+    }
+    if (ev0) rt_event_destroy(ev0);
+    if (ev1) rt_event_destroy(ev1);
+    if (sync) ok = (rt_stream_sync(main) == 0) && ok;
+    return ok;
+}
+
+// ---- builder / runtime ------------------------------------------------------------------------------------------
+class BuilderImpl : public IBuilder {
+public:
+    explicit BuilderImpl(ILogger& log) : log_(log) {}
+    INetworkDefinition* createNetwork() override { return new NetworkImpl(log_); }
+    void setMaxBatchSize(int b) override { max_batch_ = b; }
+    int getMaxBatchSize() const override { return max_batch_; }
+    void setMaxWorkspaceSize(std::size_t w) override { workspace_ = w; }
+    std::size_t getMaxWorkspaceSize() const override { return workspace_; }
+    void setHalf2Mode(bool m) override { half2_ = m; }
+    bool getHalf2Mode() const override { return half2_; }
+    void setDebugSync(bool s) override { debug_sync_ = s; }
+    bool getDebugSync() const override { return debug_sync_; }
+    void setMinFindIterations(int v) override { min_find_ = v; }
+    int getMinFindIterations() const override { return min_find_; }
+    void setAverageFindIterations(int v) override { avg_find_ = v; }
+    int getAverageFindIterations() const override { return avg_find_; }
+    bool platformHasFastFp16() const override { return true; }      // CDNA4: fp16 MFMA at 16x the fp32 rate
+    bool platformHasFastInt8() const override { return true; }
+    ICudaEngine* buildCudaEngine(INetworkDefinition& network) override {
+        auto* e = new EngineImpl(static_cast<NetworkImpl&>(network), max_batch_, half2_, log_);
+        if (!e->ok()) {
+            log_.log(ILogger::Severity::kERROR, "buildCudaEngine failed");
+            delete e;
+            return nullptr;
+        }
+        return e;
+    }
+    void destroy() override { delete this; }
+
+private:
+    ILogger& log_;
+    int max_batch_ = 1, min_find_ = 1, avg_find_ = 1;
+    std::size_t workspace_ = 0;
+    bool half2_ = false, debug_sync_ = false;
+};
+
+class RuntimeImpl : public IRuntime {
+public:
+    explicit RuntimeImpl(ILogger& log) : log_(log) {}
+    ICudaEngine* deserializeCudaEngine(const void*, std::size_t, IPluginFactory*) override {
+        log_.log(ILogger::Severity::kERROR,
+                 "deserializeCudaEngine: TensorRT plan files are not portable to this runtime; rebuild the engine from the "
+                 "network builder (takes milliseconds here, there is no kernel autotuning step)");
+        return nullptr;
+    }
+    void destroy() override { delete this; }
+private:
+    ILogger& log_;
+};
+
+}  // namespace
+
+IBuilder* createInferBuilder(ILogger& logger) { return new BuilderImpl(logger); }
+IRuntime* createInferRuntime(ILogger& logger) { return new RuntimeImpl(logger); }
+
+}  // namespace nvinfer1

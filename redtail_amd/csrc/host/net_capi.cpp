@@ -1,0 +1,194 @@
+// Whole-network C ABI (include/rt_stereo_net.h): weight-file parsing, network/engine/context life cycle.
+#include "rt_stereo_net.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "networks.h"
+#include "redtail_tensorrt_plugins.h"
+
+using namespace nvinfer1;
+using namespace redtail::tensorrt;
+
+namespace {
+
+thread_local std::string g_net_err;
+
+class NetLogger : public ILogger {
+public:
+    NetLogger() {
+        const char* e = getenv("RT_LOG_LEVEL");
+        level_ = e ? atoi(e) : 1;
+    }
+    void log(Severity severity, const char* msg) override {
+        if ((int)severity <= (int)Severity::kERROR) last_error = msg;
+        if ((int)severity > level_) return;
+        static const char* tag[] = {"INTERNAL_ERROR", "ERROR", "WARNING", "INFO"};
+        fprintf(stderr, "[redtail_amd %s] %s\n", tag[(int)severity & 3], msg);
+    }
+    std::string last_error;
+private:
+    int level_;
+};
+
+class TextProfiler : public IProfiler {
+public:
+    void reportLayerTime(const char* name, float ms) override { rows.emplace_back(name, ms); }
+    std::vector<std::pair<std::string, float>> rows;
+};
+
+int fail(const std::string& msg) {
+    g_net_err = msg;
+    return RT_E_BADARG;
+}
+
+}  // namespace
+
+struct rtStereoNet {
+    NetLogger log;
+    std::vector<char> blob;                       // weight file image; Weights::values point into it
+    weight_map weights;
+    std::unique_ptr<IPluginContainer> plugins;
+    ICudaEngine* engine = nullptr;
+    IExecutionContext* context = nullptr;
+    int layers = 0, width = 0, height = 0, max_batch = 1;
+    ~rtStereoNet() {
+        if (context) context->destroy();
+        if (engine) engine->destroy();
+    }
+};
+
+namespace {
+
+// name '\0' uint32 count, count elements (reference reader: sample_app/main.cpp:111-134)
+bool parseWeights(rtStereoNet& n, int dtype) {
+    const size_t el = dtype == RT_F16 ? 2 : 4;
+    size_t off = 0;
+    const std::vector<char>& b = n.blob;
+    while (off < b.size()) {
+        const void* z = memchr(b.data() + off, 0, b.size() - off);
+        if (!z) return false;
+        std::string name(b.data() + off);
+        off += name.size() + 1;
+        if (off + 4 > b.size()) return false;
+        uint32_t count;
+        memcpy(&count, b.data() + off, 4);
+        off += 4;
+        if (off + (size_t)count * el > b.size()) return false;
+        if (n.weights.count(name)) return false;
+        n.weights[name] = Weights{dtype == RT_F16 ? DataType::kHALF : DataType::kFLOAT, b.data() + off, (int64_t)count};
+        off += (size_t)count * el;
+    }
+    return !n.weights.empty();
+}
+
+int build(rtStereoNet** out, int model, int width, int height, int max_batch, int dtype, int max_disp,
+          std::vector<char>&& blob) {
+    if (!out) return fail("rt_net_create: null out pointer");
+    if (width < 17 || height < 17 || max_batch < 1) return fail("rt_net_create: bad dimensions");
+    if (dtype != RT_F32 && dtype != RT_F16) return fail("rt_net_create: weights_dtype must be RT_F32 or RT_F16");
+    std::unique_ptr<rtStereoNet> n(new rtStereoNet());
+    n->blob = std::move(blob);
+    n->width = width; n->height = height; n->max_batch = max_batch;
+    if (!parseWeights(*n, dtype)) return fail("rt_net_create: malformed weight file (expected name\\0, uint32 count, data ...)");
+    n->plugins = IPluginContainer::create(n->log);
+    IBuilder* builder = createInferBuilder(n->log);
+    const DimsCHW dims{3, height, width};
+    // like sample_app/main.cpp:228-256 the plugins' DataType stays kFLOAT: activations are fp32 tensors
+    const DataType act_type = DataType::kFLOAT;
+    INetworkDefinition* net = nullptr;
+    switch (model) {
+        case RT_MODEL_RESNET18_2D:
+            net = createResNet18_2DNetwork(*builder, *n->plugins, dims, n->weights, act_type, max_disp > 0 ? max_disp : 48, n->log);
+            break;
+        case RT_MODEL_NVSMALL:
+            net = createStereo3DNetwork(*builder, *n->plugins, Stereo3DModel::kNVSmall, dims, n->weights, act_type, max_disp > 0 ? max_disp : 48, n->log);
+            break;
+        case RT_MODEL_NVTINY:
+            net = createStereo3DNetwork(*builder, *n->plugins, Stereo3DModel::kNVTiny, dims, n->weights, act_type, max_disp > 0 ? max_disp : 24, n->log);
+            break;
+        case RT_MODEL_RESNET18:
+            net = createStereo3DNetwork(*builder, *n->plugins, Stereo3DModel::kResNet18, dims, n->weights, act_type, max_disp > 0 ? max_disp : 68, n->log);
+            break;
+        default:
+            builder->destroy();
+            return fail("rt_net_create: unknown model");
+    }
+    if (!net) {
+        builder->destroy();
+        return fail("rt_net_create: network construction failed: " + n->log.last_error);
+    }
+    n->layers = net->getNbLayers();
+    builder->setMaxBatchSize(max_batch);
+    builder->setMaxWorkspaceSize((size_t)1 << 30);
+    n->engine = builder->buildCudaEngine(*net);
+    net->destroy();
+    builder->destroy();
+    if (!n->engine) return fail("rt_net_create: engine build failed: " + n->log.last_error);
+    if (n->engine->getNbBindings() != 3 || n->engine->getBindingIndex("left") != 0 || n->engine->getBindingIndex("right") != 1 ||
+        n->engine->getBindingIndex("disp") != 2)
+        return fail("rt_net_create: unexpected bindings");
+    n->context = n->engine->createExecutionContext();
+    if (!n->context) return fail("rt_net_create: context creation failed");
+    *out = n.release();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" const char* rt_net_last_error(void) { return g_net_err.c_str(); }
+
+extern "C" int rt_net_create(rtStereoNet** net, int model, int width, int height, int max_batch, int dtype, int max_disp,
+                             const char* path) {
+    if (!path) return fail("rt_net_create: null weights path");
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f.is_open()) return fail(std::string("rt_net_create: cannot open ") + path);
+    std::vector<char> blob((size_t)f.tellg());
+    f.seekg(0);
+    f.read(blob.data(), (std::streamsize)blob.size());
+    return build(net, model, width, height, max_batch, dtype, max_disp, std::move(blob));
+}
+
+extern "C" int rt_net_create_from_memory(rtStereoNet** net, int model, int width, int height, int max_batch, int dtype,
+                                         int max_disp, const void* blob, size_t bytes) {
+    if (!blob || !bytes) return fail("rt_net_create_from_memory: empty blob");
+    std::vector<char> copy(static_cast<const char*>(blob), static_cast<const char*>(blob) + bytes);
+    return build(net, model, width, height, max_batch, dtype, max_disp, std::move(copy));
+}
+
+extern "C" int rt_net_execute(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, rtStream stream) {
+    if (!net || !left || !right || !disp) return fail("rt_net_execute: null pointer");
+    void* bindings[3] = {const_cast<void*>(left), const_cast<void*>(right), disp};
+    const bool ok = stream ? net->context->enqueue(batch, bindings, (cudaStream_t)stream, nullptr) : net->context->execute(batch, bindings);
+    if (!ok) return fail("rt_net_execute: " + net->log.last_error);
+    return 0;
+}
+
+extern "C" int rt_net_profile(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, char* buf,
+                              size_t buf_bytes) {
+    if (!net || !buf || !buf_bytes) return fail("rt_net_profile: null pointer");
+    TextProfiler prof;
+    net->context->setProfiler(&prof);
+    void* bindings[3] = {const_cast<void*>(left), const_cast<void*>(right), disp};
+    const bool ok = net->context->execute(batch, bindings);
+    net->context->setProfiler(nullptr);
+    if (!ok) return fail("rt_net_profile: " + net->log.last_error);
+    std::ostringstream s;
+    for (auto& r : prof.rows) s << r.first << "\t" << r.second << "\n";
+    const std::string t = s.str();
+    snprintf(buf, buf_bytes, "%s", t.c_str());
+    return 0;
+}
+
+extern "C" int rt_net_num_layers(const rtStereoNet* net) { return net ? net->layers : 0; }
+extern "C" int rt_net_num_launches(const rtStereoNet* net) { return net && net->engine ? net->engine->getNbLayers() : 0; }
+extern "C" int rt_net_destroy(rtStereoNet* net) {
+    delete net;
+    return 0;
+}

@@ -1,0 +1,51 @@
+// Internal view of the Stereo DNN plugins for the fusing executor (engine.cpp).  Not part of the
+// public API: TensorRT only ever saw IPlugin; our executor owns both sides and may look inside.
+#ifndef REDTAIL_AMD_PLUGIN_INTERNAL_H
+#define REDTAIL_AMD_PLUGIN_INTERNAL_H
+
+#include <string>
+
+#include "redtail_tensorrt_plugins.h"
+
+namespace redtail { namespace tensorrt { namespace internal {
+
+enum class Kind { kElu, kCostVolume, kSoftargmax, kConv3D, kConv3DTranspose, kTransform, kPadding, kSlice };
+
+struct ConvFusion {            // what the executor asks a Conv3D / Conv3DTranspose plugin to absorb
+    int act = 0;               // RT_ACT_*
+    bool out_dchw = false;     // Conv3D only: write (D,K,H,W) directly (elides the Transform plugin)
+    bool residual = false;     // add a residual tensor shaped like the output before the activation
+};
+
+class IStereoPlugin {
+public:
+    virtual Kind kind() const = 0;
+    virtual const std::string& pluginName() const = 0;
+    // cost volume / soft-argmax
+    virtual CostVolumeType costVolumeType() const { return CostVolumeType::kDefault; }
+    virtual int maxDisparity() const { return 0; }
+    virtual SoftargmaxType softargmaxType() const { return SoftargmaxType::kMax; }
+    // transform
+    virtual Permutation permutation() const { return Permutation{{0, 1, 2, 3}}; }
+    // padding / slice (outermost dim only)
+    virtual int padEnd() const { return 0; }
+    virtual int sliceStart() const { return 0; }
+    virtual int sliceEnd() const { return 0; }
+    // 3-D convolutions: re-plan with fused epilogue; enqueueFused takes the residual pointer
+    virtual bool setFusion(const ConvFusion&) { return false; }
+    virtual int enqueueFused(int, const void*, void*, const void*, cudaStream_t) { return -1; }
+    virtual ~IStereoPlugin() {}
+};
+
+void logError(ILogger& log, int status, const char* file, int line, const char* func);
+
+} } }  // namespace redtail::tensorrt::internal
+
+// Logs "<file>:<line>: <func>: ..." at kERROR when status != 0 (reference: lib/internal_macros.h:14-21).
+#define RT_CHECKL(status, log)                                                                        \
+    do {                                                                                              \
+        int res_ = (int)(status);                                                                     \
+        if (res_ != 0) ::redtail::tensorrt::internal::logError(log, res_, __FILE__, __LINE__, __func__); \
+    } while (false)
+
+#endif

@@ -163,12 +163,13 @@ extern "C" int rt_memset(void* dst, int value, size_t bytes, rtStream s) {
 extern "C" int rt_stream_create(rtStream* s) {
     RT_REQUIRE(s, "rt_stream_create: null");
     hipStream_t st;
-    RT_HIP(hipStreamCreate(&st));
+    RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     *s = st;
     return 0;
 }
 extern "C" int rt_stream_destroy(rtStream s) { RT_HIP(hipStreamDestroy(S(s))); return 0; }
 extern "C" int rt_stream_sync(rtStream s) { RT_HIP(hipStreamSynchronize(S(s))); return 0; }
+extern "C" int rt_stream_wait_event(rtStream s, void* ev) { RT_HIP(hipStreamWaitEvent(S(s), (hipEvent_t)ev, 0)); return 0; }
 extern "C" int rt_event_create(void** ev) {
     RT_REQUIRE(ev, "rt_event_create: null");
     hipEvent_t e;

@@ -117,6 +117,9 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hip
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamCreate(hipStream_t* s);
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();

@@ -322,6 +322,8 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }

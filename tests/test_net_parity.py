@@ -1,0 +1,144 @@
+"""End-to-end parity of the whole inference path (NvInfer.h shim -> plugins -> fused executor -> HIP
+kernels, driven through include/rt_stereo_net.h) against the oracle's op-for-op restatement of the
+reference's generated networks.  BASELINE tolerance: 1e-3 abs on the network's raw `disp` output.
+CPU tier: tiny images on the SIMT emulator; GPU tier (-m gpu): the real sizes incl. 1257x369."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import build, capi
+
+REF_W = "/root/reference/stereoDNN/models"
+_nets = {}
+
+
+def netlib(kind):
+    if kind not in _nets:
+        if kind == "emu":
+            _nets[kind] = capi.NetLib(build.build_host_emu(), build.build_emu())
+        else:
+            _nets[kind] = capi.NetLib()
+    return _nets[kind]
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def rt(request):
+    class R:
+        kind = request.param
+        lib = netlib(request.param)
+
+        def dev(self, a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            return a.copy() if self.kind == "emu" else torch.from_numpy(a).cuda()
+
+        def empty(self, *shape):
+            return np.full(shape, np.nan, np.float32) if self.kind == "emu" else torch.full(shape, float("nan"), device="cuda")
+
+        def host(self, t):
+            if self.kind == "emu":
+                return t
+            torch.cuda.synchronize()
+            return t.cpu().numpy()
+    return R()
+
+
+def pairs(n, h, w, seed=1234):
+    ls, rs = zip(*(O.synth_pair(h, w, seed + i) for i in range(n)))
+    return np.stack(ls), np.stack(rs)
+
+
+def run_net(rt, model, weights, l, r, **kw):
+    n, _, h, w = l.shape
+    net = rt.lib.create(model, w, h, max_batch=n, weights=weights, **kw)
+    out = rt.empty(n, 1, h, w)
+    net.execute(rt.dev(l), rt.dev(r), out, n)
+    res = np.array(rt.host(out))
+    info = (net.num_layers, net.num_launches)
+    net.destroy()
+    return res, info
+
+
+def test_resnet18_2d_tiny(rt):
+    """all fusions on; 41x25 image, batch 2, D = 8"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 25, 41)
+    out, (layers, launches) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w, max_disp=8).numpy()
+    assert not np.isnan(out).any()
+    assert np.abs(out - ref).max() <= 1e-3, np.abs(out - ref).max()
+    assert np.abs(out - ref).max() <= 2e-4            # fp32 path: far inside the budget
+    assert layers > 100 and launches < layers / 2     # conv+add+ELU, corr+softargmax fused
+
+
+def test_resnet18_2d_unfused_equals_fused(rt, monkeypatch):
+    """RT_NO_FUSION runs every plugin through its own enqueue(), i.e. the reference's layer-by-layer order"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 17, 33)
+    fused, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=6)
+    monkeypatch.setenv("RT_NO_FUSION", "1")
+    unfused, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=6)
+    assert n2 > n1
+    assert np.abs(fused - unfused).max() <= 1e-5
+
+
+def test_nvtiny_tiny(rt):
+    """3-D path: default cost volume, Conv3D/Transform/Pad/ELU, Conv3DTranspose/Slice/add, softargmin"""
+    w = O.synth_weights_3d(O.NVTINY_3D)
+    l, r = pairs(1, 25, 33)
+    out, (layers, launches) = run_net(rt, "nvtiny", w, l, r, max_disp=4)
+    with torch.no_grad():
+        ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), w, O.NVTINY_3D, 4).numpy()
+    assert not np.isnan(out).any()
+    assert np.abs(out - ref).max() <= 1e-3, np.abs(out - ref).max()
+
+
+def test_bad_inputs_fail_loudly(rt):
+    w = O.synth_weights_resnet18_2d()
+    with pytest.raises(capi.RtError):
+        rt.lib.create("resnet18_2D", 40, 25, weights=w)              # 40 is not 1 (mod 8): asymmetric pad
+    bad = dict(w)
+    del bad["conv2D_4_k"]
+    with pytest.raises(capi.RtError):
+        rt.lib.create("resnet18_2D", 41, 25, weights=bad)            # missing tensor
+    with pytest.raises(capi.RtError):
+        rt.lib.create("resnet18_2D", 41, 25, weights=b"garbage")
+
+
+# ---- GPU only: real sizes -----------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,batch", [(513, 257, 1), (1257, 369, 1), (1257, 369, 2)])
+def test_resnet18_2d_full_size(w, h, batch):
+    lib = netlib("gpu")
+    path = os.path.join(REF_W, "ResNet-18_2D/TensorRT/trt_weights.bin")
+    weights = O.read_weights(path) if os.path.exists(path) else O.synth_weights_resnet18_2d()
+    l, r = pairs(batch, h, w)
+    net = lib.create("resnet18_2D", w, h, max_batch=batch, weights=weights)
+    out = torch.full((batch, 1, h, w), float("nan"), device="cuda")
+    net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out, batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), weights)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-3, err
+    net.destroy()
+
+
+@pytest.mark.gpu
+def test_nvtiny_full_size():
+    lib = netlib("gpu")
+    path = os.path.join(REF_W, "NVTiny/TensorRT/trt_weights.bin")
+    weights = O.read_weights(path) if os.path.exists(path) else O.synth_weights_3d(O.NVTINY_3D)
+    l, r = pairs(1, 161, 513)
+    net = lib.create("nvtiny", 513, 161, weights=weights)
+    out = torch.full((1, 1, 161, 513), float("nan"), device="cuda")
+    net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out, 1)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), weights, O.NVTINY_3D, 24)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-3, err
+    net.destroy()
