@@ -53,6 +53,18 @@ def build_hip(force=False):
     return out
 
 
+def build_hip_timing(force=False):
+    """Instrumented build of the kernel library for tools/time_phases.py (never used by the product)."""
+    outdir = os.path.join(ROOT, "tools", "build")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "librt_stereo_hip_timing.so")
+    deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
+    if force or _newer(out, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRT_KERNEL_TIMING", "-w",
+              os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+    return out
+
+
 def build_emu(force=False):
     """Host build of the same kernel sources on top of tests/emu (test infrastructure)."""
     os.makedirs(EMU_BUILD, exist_ok=True)

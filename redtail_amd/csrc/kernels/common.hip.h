@@ -27,6 +27,15 @@ __device__ static __forceinline__ float apply_act(float v) {
     if (ACT == 2) return sigmoid1(v);
     return v;
 }
+// Fused-epilogue variants: exp through the hardware v_exp_f32 (2 instructions instead of ~25).  |error| of
+// exp(x) is <= ~1e-7 * max(1, |x|) for x <= 0, far inside the 1e-4 .. 1e-5 tolerances the reference applies
+// to convolution outputs (tests_main.cpp:419-877); the stand-alone ELU plugin keeps the accurate expf.
+__device__ static __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ static __forceinline__ float apply_act_fast(float v, int act) {
+    if (act == 1) return v > 0.f ? v : fast_exp(v) - 1.f;
+    if (act == 2) return 1.f / (1.f + fast_exp(-v));
+    return v;
+}
 __device__ static __forceinline__ float apply_act_rt(float v, int act) {
     return act == 1 ? elu1(v) : (act == 2 ? sigmoid1(v) : v);
 }

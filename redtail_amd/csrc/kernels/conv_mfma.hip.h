@@ -37,6 +37,7 @@ struct ConvArgs {
     const float* w;        // packed [nblk][chunk][tap][h][NB][CC/2]
     const float* bias;     // [round_up(Cout, NB)], zero padded, never null
     const float* resid;    // same addressing as y, or nullptr
+    unsigned long long* dbg;   // phase-timing buffer [workgroup][16]; only read when built with -DRT_KERNEL_TIMING
     const float* zeros;    // >= 16 bytes of zeros: target of every out-of-image / padded-channel gather
     const int* ch_off;     // [nz][CinPad] plane offsets (elements) relative to the sample base, -1 = zeros
     int CinPad;            // multiple of CC
@@ -54,6 +55,14 @@ struct ConvArgs {
     int64_t y_off;         // constant output offset (deconv phase origin)
     int y_ystride, y_xstride;
 };
+
+// Optional in-kernel phase timing (tools/time_phases.py builds a separate library with
+// -DRT_KERNEL_TIMING): thread 0 stamps s_memtime at phase boundaries.  Compiles to nothing otherwise.
+#ifdef RT_KERNEL_TIMING
+#define RT_TSTAMP() do { if (dbgp && tid == 0 && dbi < 16) dbgp[dbi++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RT_TSTAMP() do { } while (0)
+#endif
 
 template <int N> struct VecOf;
 template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -176,13 +185,40 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
         const int t = wv + NW * i;
         b_base[i] = ((t / TXW) * S * 2 + half) * PC + ((t % TXW) * 32 + l31) * S;
     }
+    // residual (skip connection) values of this lane's outputs, fetched under the last chunk's MFMAs
+    const int64_t ybase = (int64_t)n * p.y_bstride + (int64_t)zi * p.y_zstride + p.y_off;
+    const float* __restrict__ resid = p.resid;
+    float rv[WT][NBW][16];
+    // (one 64-bit base per wave-tile + 32-bit channel offsets keeps this at ~1 address register per load)
+    const int cs32 = (int)p.y_cstride;
+    auto prefetch_resid = [&]() {
+#pragma unroll
+        for (int i = 0; i < WT; i++) {
+            const int t = wv + NW * i;
+            const int oy = ty0 + t / TXW;
+            const int ox = tx0 + (t % TXW) * 32 + l31;
+            const bool pix_ok = (oy < p.Ho) & (ox < p.Wo) & (resid != nullptr);
+            const float* rbase = pix_ok ? resid + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride) : p.zeros;
+            const int cmul = pix_ok ? cs32 : 0;
+#pragma unroll
+            for (int b = 0; b < NBW; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int co = nblk * NB + b * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                    rv[i][b][r] = rbase[co < p.Cout ? co * cmul : 0];
+                }
+        }
+    };
     const vec_t* sIn4 = reinterpret_cast<const vec_t*>(sIn);
     const vec_t* sW4 = reinterpret_cast<const vec_t*>(sW);
     const vec_t* __restrict__ gW4 = reinterpret_cast<const vec_t*>(wsrc);   // weights straight from L1/L2 (WLDS == false)
 
-    prefetch(0);
-    for (int ch = 0; ch < nchunks; ch++) {
-        __syncthreads();   // everyone finished reading the previous chunk from LDS
+#ifdef RT_KERNEL_TIMING
+    unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
+    int dbi = 0;
+#endif
+    // registers -> LDS for the chunk that was prefetched last
+    auto stage_to_lds = [&]() {
 #pragma unroll
         for (int h = 0; h < NPAR; h++)
 #pragma unroll
@@ -195,11 +231,10 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
                 if (idx < Cfg::W_ELEMS / 4) reinterpret_cast<f32x4*>(sW)[idx] = rw[k];
             }
         }
-        __syncthreads();
-        if (ch + 1 < nchunks) prefetch(ch + 1);   // global loads fly while the MFMAs below run
-
+    };
+    // all MFMAs of one chunk; operands of tap t+1 are fetched before the MFMAs of tap t
+    auto compute = [&](int ch) {
         const vec_t* wq = WLDS ? sW4 : gW4 + (int64_t)ch * (TAPS * 2 * NB);
-        // operands of tap t+1 are fetched before the MFMAs of tap t
         vec_t a_cur[NBW], b_cur[WT], a_nxt[NBW], b_nxt[WT];
 #pragma unroll
         for (int b = 0; b < NBW; b++) a_cur[b] = wq[a_base[b]];
@@ -228,10 +263,32 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
                 for (int i = 0; i < WT; i++) b_cur[i] = b_nxt[i];
             }
         }
-    }
+    };
 
-    // ---- epilogue: bias (+ residual) + activation, 128-byte coalesced stores per half-wave ----------
-    const int64_t ybase = (int64_t)n * p.y_bstride + (int64_t)zi * p.y_zstride + p.y_off;
+    RT_TSTAMP();
+    prefetch(0);
+    for (int ch = 0; ch + 1 < nchunks; ch++) {
+        __syncthreads();   // everyone finished reading the previous chunk from LDS
+        RT_TSTAMP();
+        stage_to_lds();
+        __syncthreads();
+        RT_TSTAMP();
+        prefetch(ch + 1);  // global loads fly while the MFMAs below run
+        compute(ch);
+    }
+    // last chunk, peeled: the staging registers are dead now, so the residual (skip connection) values of
+    // this lane's outputs are fetched into them and arrive under the last chunk's MFMAs
+    __syncthreads();
+    RT_TSTAMP();
+    stage_to_lds();
+    __syncthreads();
+    RT_TSTAMP();
+    prefetch_resid();
+    compute(nchunks - 1);
+
+    RT_TSTAMP();
+    // ---- epilogue: bias + residual (already in registers) + activation, 128-byte coalesced stores ---------
+    float* __restrict__ yout = p.y;
 #pragma unroll
     for (int b = 0; b < NBW; b++) {
         // accumulator register r holds channel (r&3) + 8*(r>>2) + 4*half of this 32-block
@@ -245,19 +302,19 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
             const int oy = ty0 + t / TXW;
             const int ox = tx0 + (t % TXW) * 32 + l31;
             const bool pix_ok = oy < p.Ho && ox < p.Wo;
-            const int64_t pbase = ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride;
+            float* ybp = yout + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = cbase + (r & 3) + 8 * (r >> 2);
-                if (pix_ok && co < p.Cout) {
-                    const int64_t addr = pbase + (int64_t)co * p.y_cstride;
-                    float v = acc[i][b][r] + bv[r >> 2][r & 3];
-                    if (p.resid) v += p.resid[addr];
-                    p.y[addr] = apply_act_rt(v, act);
-                }
+                const float v = apply_act_fast(acc[i][b][r] + bv[r >> 2][r & 3] + rv[i][b][r], act);
+                if (pix_ok && co < p.Cout) ybp[co * cs32] = v;
             }
         }
     }
+#ifdef RT_KERNEL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RT_TSTAMP();
 }
 
 }  // namespace rt

@@ -769,6 +769,10 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.w = sc.w_dev;
         a.bias = plan->bias_dev;
         a.zeros = plan->zeros_dev;
+        a.dbg = nullptr;
+#ifdef RT_KERNEL_TIMING
+        if (const char* e = getenv("RT_DBG_PTR")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
         a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
         a.ch_off = sc.choff_dev;
         a.CinPad = sc.CinPad; a.Cout = sc.Cout;
@@ -782,6 +786,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
+        RT_REQUIRE(sc.y_cstride * (int64_t)rt::round_up(sc.Cout, 64) < (1ll << 31), "rt_conv_enqueue: output sample exceeds 2^31 elements");
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (int rc = launch_sub(sc, a, grid, S(s))) return rc;
     }

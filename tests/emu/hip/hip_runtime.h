@@ -105,6 +105,7 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_32x32x16f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32f16(a, b, c)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)

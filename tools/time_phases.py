@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-phase timing of conv_mfma_f32_kernel on the 3x3 32->32 @185x629 layer (s_memtime stamps of
+thread 0 of every workgroup; instrumented library built by redtail_amd.build.build_hip_timing)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redtail_amd import build, capi  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+k = capi.KernelLib.__new__(capi.KernelLib)
+import ctypes  # noqa: E402
+k.path = os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so")
+k.lib = ctypes.CDLL(k.path)
+for name, (res, args) in capi.KERNEL_SYMBOLS.items():
+    fn = getattr(k.lib, name)
+    fn.restype, fn.argtypes = res, args
+cin = cout = 32
+h, w = 185, 629
+wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
+bias = np.random.randn(cout).astype(np.float32)
+plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+x = torch.randn(b, cin, h, w, device="cuda")
+y = torch.empty_like(x)
+r = torch.randn_like(x)
+nwg = 47 * 10 * b
+dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
+for _ in range(3):
+    plan.enqueue(x, y, r, b)
+torch.cuda.synchronize()
+os.environ["RT_DBG_PTR"] = str(dbg.data_ptr())
+plan.enqueue(x, y, r, b)
+torch.cuda.synchronize()
+t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
+names = ["start", "c0 sync1", "c0 ready", "c1 sync1", "c1 ready", "c2 sync1", "c2 ready", "c3 sync1", "c3 ready",
+         "epilogue start", "end"]
+d = np.diff(t[:, :11], axis=1)
+print("batch %d: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % (b, nwg))
+for i in range(10):
+    print("  %-16s -> %-16s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10),
+                                                 np.percentile(d[:, i], 90)))
+print("  workgroup lifetime mean %.1f" % (t[:, 10] - t[:, 0]).mean())
