@@ -30,7 +30,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from redtail_amd import capi, synth  # noqa: E402
+from redtail_amd import capi, parallel, synth  # noqa: E402
 
 W, H = 1257, 369
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -88,13 +88,7 @@ def main():
         blob = capi.pack_weights(weights)
     if distributed:
         import torch.distributed as dist
-        size = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(size, 0)
-        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(buf, 0)
-        blob = bytes(buf.cpu().numpy())
+        blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
 
     lib = capi.NetLib()
     lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")

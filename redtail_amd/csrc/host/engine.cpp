@@ -338,6 +338,7 @@ private:
     rtStream side_stream_ = nullptr;
     rtStream main_stream_ = nullptr;   // execute() runs on its own stream, never on the NULL stream
     std::vector<void*> events_;        // per tensor id, lazily created
+    std::vector<void*> prof_events_;   // start/stop pair per launch (IProfiler)
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
 };
@@ -735,6 +736,8 @@ ContextImpl::~ContextImpl() {
     if (workspace_) rt_free(workspace_);
     for (void* ev : events_)
         if (ev) rt_event_destroy(ev);
+    for (void* ev : prof_events_)
+        if (ev) rt_event_destroy(ev);
     if (ev_fork_) rt_event_destroy(ev_fork_);
     if (ev_join_) rt_event_destroy(ev_join_);
     if (side_stream_) rt_stream_destroy(side_stream_);
@@ -803,7 +806,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
     }
     if (!ensureBuffers(batch)) return false;
     const bool profile = profiler_ != nullptr;
-    const bool two = eng_.two_streams_ && !profile;
+    const bool two = eng_.two_streams_;
     rtStream main = stream;
     if (two) {
         if (!side_stream_ && rt_stream_create(&side_stream_) != 0) return false;
@@ -814,8 +817,13 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         rt_event_record(ev_fork_, main);
         rt_stream_wait_event(side_stream_, ev_fork_);
     }
-    void *ev0 = nullptr, *ev1 = nullptr;
-    if (profile) { rt_event_create(&ev0); rt_event_create(&ev1); }
+    // profiling keeps the production schedule (both streams): one event pair per launch, recorded on the
+    // stream the launch goes to and read back after the final synchronisation
+    if (profile && prof_events_.size() != 2 * eng_.ops_.size()) {
+        prof_events_.assign(2 * eng_.ops_.size(), nullptr);
+        for (void*& e : prof_events_) rt_event_create(&e);
+    }
+    size_t op_index = 0;
 
     bool ok = true;
     for (const Op& op : eng_.ops_) {
@@ -823,7 +831,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         if (two)
             for (int w : op.wait_on)
                 if (events_[w]) rt_stream_wait_event(st, events_[w]);
-        if (profile) rt_event_record(ev0, st);
+        if (profile) rt_event_record(prof_events_[2 * op_index], st);
         const TensorImpl& out = *eng_.tensors_[op.out];
         void* y = addr(op.out, batch, bindings);
         int rc = 0;
@@ -875,12 +883,8 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             ok = false;
             break;
         }
-        if (profile) {
-            float ms = 0.f;
-            rt_event_record(ev1, st);
-            rt_event_elapsed_ms(ev0, ev1, &ms);
-            profiler_->reportLayerTime(op.name.c_str(), ms);
-        }
+        if (profile) rt_event_record(prof_events_[2 * op_index + 1], st);
+        op_index++;
         if (two && op.publish) {       // make the result visible to the consumer on the other stream
             int r = op.out;
             while (eng_.tensors_[r]->alias_of >= 0) r = eng_.tensors_[r]->alias_of;
@@ -893,9 +897,14 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         rt_event_record(ev_join_, side_stream_);
         rt_stream_wait_event(main, ev_join_);
     }
-    if (ev0) rt_event_destroy(ev0);
-    if (ev1) rt_event_destroy(ev1);
-    if (sync) ok = (rt_stream_sync(main) == 0) && ok;
+    if (sync || profile) ok = (rt_stream_sync(main) == 0) && ok;
+    if (profile && ok) {
+        for (size_t i = 0; i < op_index; i++) {
+            float ms = 0.f;
+            rt_event_elapsed_ms(prof_events_[2 * i], prof_events_[2 * i + 1], &ms);
+            profiler_->reportLayerTime(eng_.ops_[i].name.c_str(), ms);
+        }
+    }
     return ok;
 }
 

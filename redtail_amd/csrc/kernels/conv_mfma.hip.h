@@ -87,7 +87,7 @@ struct ConvCfg {
     static constexpr int NTHR = 64 * NW;
     static constexpr int NK_W = (W_ELEMS / 4 + NTHR - 1) / NTHR;
     static constexpr int WT = TY * TXW / NW;              // wave-tiles (32 px) per wave
-    static_assert(NW == 1 || NW == 4, "1 or 4 waves per workgroup");
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "1, 2, 4 or 8 waves per workgroup");
     static_assert((TY * TXW) % NW == 0, "tile must split evenly over the waves");
     static_assert(WLDS || true, "");
     static_assert(CC == 4 || CC == 8, "CC/2 k-steps are fetched by one ds_read_b64 / ds_read_b128");

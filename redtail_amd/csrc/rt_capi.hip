@@ -431,27 +431,40 @@ bool window_supported(int KH, int KW, int S) {
     return false;
 }
 
-// Tile variant: 0 = 4 waves, 4x64 px tile, weights via LDS;  1 = one wave per workgroup, 2x64 px,
-// weights straight from L1/L2;  2 = one wave, 4x32 px;  3 = 4 waves, 4x64 px, weights from L1/L2.
-// RT_CONV_VARIANT overrides the default for A/B measurements.
-int conv_variant() {
-    static int v = [] {
-        const char* e = getenv("RT_CONV_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
+// Workgroup tile selection.  Candidates (TY rows x 32*TXW pixels, NW waves):
+//   {4,2,4}: most reuse per staged byte;  {4,1,4} / {2,2,4}: one 32-pixel wave-tile per wave -> fewer
+//   registers (5 waves/SIMD), twice the workgroups;  {2,1,2}: smallest, for layers that cannot fill 256 CUs.
+// Measured on MI355X (tools/layer_profile.py): the whole network is fastest with one wave-tile per wave,
+// RT_CONV_VARIANT / RT_CONV_NBW override the heuristic for A/B measurements.
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+void set_tile(SubConv& sc, int variant) {
+    switch (variant) {
+        case 0: sc.TY = 4; sc.TXW = 2; sc.NW = 4; break;
+        case 4: sc.TY = 2; sc.TXW = 2; sc.NW = 4; break;
+        case 9: sc.TY = 2; sc.TXW = 1; sc.NW = 2; break;
+        default: sc.TY = 4; sc.TXW = 1; sc.NW = 4; break;     // 6
+    }
+    sc.WLDS = 1;
+}
+
+int64_t count_wgs(const SubConv& sc) {
+    return rt::cdiv(sc.Ho, sc.TY) * rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Cout, 32 * sc.NBW) * sc.nz;
 }
 
 void choose_tiling(SubConv& sc) {
-    sc.NBW = sc.Cout > 32 ? 2 : 1;
     sc.CC = 8;
+    sc.NBW = sc.Cout > 32 ? 2 : 1;
     if (sc.KH == 5) { sc.NBW = 1; sc.CC = 4; }
-    switch (conv_variant()) {
-        case 1: sc.TY = 2; sc.TXW = 2; sc.NW = 1; sc.WLDS = 0; break;
-        case 2: sc.TY = 4; sc.TXW = 1; sc.NW = 1; sc.WLDS = 0; break;
-        case 3: sc.TY = 4; sc.TXW = 2; sc.NW = 4; sc.WLDS = 0; break;
-        default: sc.TY = 4; sc.TXW = 2; sc.NW = 4; sc.WLDS = 1; break;
-    }
+    const int forced = env_int("RT_CONV_VARIANT", -1);
+    set_tile(sc, forced >= 0 ? forced : 6);
+    // (splitting low-resolution layers further -- NBW = 1 or the {2,1,2} tile below 512 workgroups -- was
+    //  measured and lost 8 % end to end: the extra patch staging per FLOP costs more than the idle CUs)
+    const int nbw = env_int("RT_CONV_NBW", 0);
+    if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
 }
 
 // weights to host fp32 (fp16 weight files are widened once; activations stay fp32 in this build)
@@ -474,7 +487,7 @@ int launch_window(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream
                            dim3(64 * nw), 0, st, a);                                                      \
         return 0;                                                                                         \
     }
-    RT_TILE(4, 2, 4, true) RT_TILE(2, 2, 1, false) RT_TILE(4, 1, 1, false) RT_TILE(4, 2, 4, false)
+    RT_TILE(4, 2, 4, true) RT_TILE(4, 1, 4, true) RT_TILE(2, 2, 4, true) RT_TILE(2, 1, 2, true)
 #undef RT_TILE
     return 1;
 }
