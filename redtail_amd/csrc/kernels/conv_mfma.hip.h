@@ -31,6 +31,18 @@
 
 namespace rt {
 
+// Optional per-z-slice overrides: lets ONE launch cover the output phases of a transposed convolution
+// (each phase = its own padding, output origin and weight slab) and/or depth positions with their
+// own gather-table row.
+struct ZSlice {
+    int pad_y, pad_x;
+    int Ho, Wo;
+    int ch_row;            // row of the ch_off table
+    int reserved;
+    int64_t y_off;         // replaces ConvArgs::y_off + zi * y_zstride
+    int64_t w_off;         // element offset of this slice's packed weights
+};
+
 struct ConvArgs {
     const float* x;
     float* y;
@@ -39,6 +51,7 @@ struct ConvArgs {
     const float* resid;    // same addressing as y, or nullptr
     unsigned long long* dbg;   // phase-timing buffer [workgroup][16]; only read when built with -DRT_KERNEL_TIMING
     const float* zeros;    // >= 16 bytes of zeros: target of every out-of-image / padded-channel gather
+    const ZSlice* zs;      // [nz] or nullptr (uniform slices)
     const int* ch_off;     // [nz][CinPad] plane offsets (elements) relative to the sample base, -1 = zeros
     int CinPad;            // multiple of CC
     int Cout;
@@ -118,27 +131,34 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
 
     const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
     const int nchunks = p.CinPad / CC;
+    // per-slice parameters (wave-uniform): uniform launch, or one entry of the ZSlice table
+    int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0;
+    if (p.zs) {
+        const ZSlice z = p.zs[zi];
+        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
+    }
 
     const int act = p.act;
 
     // ---- staging roles (see ConvCfg) ------------------------------------------------------------------
     const int sh = NW == 1 ? 0 : (wv & 1), spart = NW == 1 ? 0 : (wv >> 1);
-    const int* __restrict__ tab = p.ch_off + (int64_t)zi * p.CinPad + sh;
+    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + sh;
     int poff[NKP];      // in-plane element offset of the patch pixel, or -1 outside the image
     int lidx[NKP];      // LDS vec_t index of the patch pixel (parity 0 of this wave), or -1 if not owned
 #pragma unroll
     for (int k = 0; k < NKP; k++) {
         const int pidx = spart * (NKP * 64) + lane + 64 * k;
         const int pr = pidx / PC, pc = pidx - pr * PC;
-        const int iy = ty0 * S - p.pad_y + pr;
-        const int ix = tx0 * S - p.pad_x + pc;
+        const int iy = ty0 * S - pad_y + pr;
+        const int ix = tx0 * S - pad_x + pc;
         const bool own = pidx < NPIX;
         poff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
         lidx[k] = own ? (pr * 2 + sh) * PC + pc : -1;
     }
 
     const f32x4* __restrict__ wsrc =
-        reinterpret_cast<const f32x4*>(p.w + ((int64_t)nblk * nchunks) * Cfg::W_ELEMS);
+        reinterpret_cast<const f32x4*>(p.w + w_off + ((int64_t)nblk * nchunks) * Cfg::W_ELEMS);
 
     vec_t rin[NPAR][NKP];
     f32x4 rw[WLDS ? Cfg::NK_W : 1];
@@ -186,7 +206,7 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
         b_base[i] = ((t / TXW) * S * 2 + half) * PC + ((t % TXW) * 32 + l31) * S;
     }
     // residual (skip connection) values of this lane's outputs, fetched under the last chunk's MFMAs
-    const int64_t ybase = (int64_t)n * p.y_bstride + (int64_t)zi * p.y_zstride + p.y_off;
+    const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
     const float* __restrict__ resid = p.resid;
     float rv[WT][NBW][16];
     // (one 64-bit base per wave-tile + 32-bit channel offsets keeps this at ~1 address register per load)
@@ -197,7 +217,7 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
             const int t = wv + NW * i;
             const int oy = ty0 + t / TXW;
             const int ox = tx0 + (t % TXW) * 32 + l31;
-            const bool pix_ok = (oy < p.Ho) & (ox < p.Wo) & (resid != nullptr);
+            const bool pix_ok = (oy < Ho) & (ox < Wo) & (resid != nullptr);
             const float* rbase = pix_ok ? resid + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride) : p.zeros;
             const int cmul = pix_ok ? cs32 : 0;
 #pragma unroll
@@ -301,7 +321,7 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
             const int t = wv + NW * i;
             const int oy = ty0 + t / TXW;
             const int ox = tx0 + (t % TXW) * 32 + l31;
-            const bool pix_ok = oy < p.Ho && ox < p.Wo;
+            const bool pix_ok = oy < Ho && ox < Wo;
             float* ybp = yout + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -315,6 +335,73 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     RT_TSTAMP();
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Direct (VALU) convolution for layers with one or two output channels, where a 32-wide MFMA column
+// block would be >= 94 % padding: the last transposed convolutions of the networks (32 -> 1 at full
+// resolution, reference resnet18_2D_513x257_net.cpp:758-763, nvsmall_1025x321_net.cpp:399-408).
+// Same gather description as the MFMA kernel (window, plane table, ZSlice phases); one thread per output
+// pixel, coalesced along x, weights [co][ci][tap] read through the scalar cache.  HBM-bound.
+// grid = (ceil(Wo/256), Ho, batch*nz)
+// ------------------------------------------------------------------------------------------------------
+template <int COUT, int KH, int KW>
+__global__ void __launch_bounds__(256) conv_direct_f32_kernel(ConvArgs p, int S, int cin_real) {
+    constexpr int TAPS = KH * KW;
+    constexpr int kMaxW = 4096;                       // floats of weights cached in LDS
+    __shared__ float sw[kMaxW];
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const int zi = blockIdx.z % p.nz, n = blockIdx.z / p.nz;
+    int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0;
+    if (p.zs) {
+        const ZSlice z = p.zs[zi];
+        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
+    }
+    if (oy >= Ho) return;                             // uniform per workgroup
+    const float* __restrict__ w = p.w + w_off;        // [co][ci][tap]
+    const int nw = COUT * cin_real * TAPS;            // launcher guarantees nw <= kMaxW
+    for (int i = threadIdx.x; i < nw; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
+    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad;
+    // window offsets of this output pixel, -1 outside the image
+    int poff[TAPS];
+#pragma unroll
+    for (int u = 0; u < KH; u++)
+#pragma unroll
+        for (int v = 0; v < KW; v++) {
+            const int iy = oy * S + u - pad_y, ix = ox * S + v - pad_x;
+            poff[u * KW + v] = (ox < Wo && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
+        }
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) acc[co] = p.bias[co];
+#pragma unroll 4
+    for (int ci = 0; ci < cin_real; ci++) {
+        const int off = tab[ci];                      // wave-uniform
+        if (off < 0) continue;
+        float xv[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) xv[t] = *(poff[t] >= 0 ? xb + ((int64_t)off + poff[t]) : p.zeros);
+#pragma unroll
+        for (int t = 0; t < TAPS; t++)
+#pragma unroll
+            for (int co = 0; co < COUT; co++) acc[co] = fmaf(xv[t], sw[(co * cin_real + ci) * TAPS + t], acc[co]);
+    }
+    if (ox >= Wo) return;
+    const int64_t base = (int64_t)n * p.y_bstride + y_off + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride;
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+        if (co < p.Cout) {
+            const int64_t addr = base + (int64_t)co * p.y_cstride;
+            float v = acc[co];
+            if (p.resid) v += p.resid[addr];
+            p.y[addr] = apply_act_rt(v, p.act);
+        }
+    }
 }
 
 }  // namespace rt

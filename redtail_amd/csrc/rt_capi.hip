@@ -346,6 +346,8 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int y_ystride = 0, y_xstride = 1;
     float* w_dev = nullptr;
     int* choff_dev = nullptr;
+    rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
+    int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
 };
 
 }  // namespace
@@ -380,14 +382,26 @@ Phase1D phase1d(int s, int p, int k, int phi) {
     return ph;
 }
 
-// Packs weights for one launch in the exact order of the kernel's LDS slab:
-// [nblk][chunk][tap][h][NB][CC/2] with gathered channel ci = chunk*CC + 2*j + h;
-// wfun(co, ci, u, v) returns the weight of output channel co, gathered channel ci, window tap (u, v).
+// Appends the weights of one launch (or of one phase of a multi-phase launch) to `packed`, in the exact
+// order of the kernel's LDS slab: [nblk][chunk][tap][h][NB][CC/2] with gathered channel
+// ci = chunk*CC + 2*j + h; wfun(co, ci, u, v) = weight of output channel co, gathered channel ci, window
+// tap (u, v).  The direct (Cout <= 2) kernel takes plain [co][ci][tap].  Returns the element offset.
 template <typename F>
-int upload_packed(SubConv& sc, int cin_real, F wfun) {
-    const int NB = 32 * sc.NBW, taps = sc.KH * sc.KW, cpg = sc.CC / 2;
+int64_t pack_into(std::vector<float>& packed, const SubConv& sc, int cin_real, F wfun) {
+    const int64_t base = (int64_t)packed.size();
+    const int taps = sc.KH * sc.KW;
+    if (sc.direct) {
+        packed.resize(base + (size_t)sc.Cout * cin_real * taps, 0.f);
+        for (int co = 0; co < sc.Cout; co++)
+            for (int ci = 0; ci < cin_real; ci++)
+                for (int u = 0; u < sc.KH; u++)
+                    for (int v = 0; v < sc.KW; v++)
+                        packed[base + ((size_t)co * cin_real + ci) * taps + u * sc.KW + v] = wfun(co, ci, u, v);
+        return base;
+    }
+    const int NB = 32 * sc.NBW, cpg = sc.CC / 2;
     const int nblk = (int)rt::cdiv(sc.Cout, NB), nch = sc.CinPad / sc.CC;
-    std::vector<float> packed((size_t)nblk * nch * taps * sc.CC * NB, 0.f);
+    packed.resize(base + (size_t)nblk * nch * taps * sc.CC * NB, 0.f);
     for (int nb = 0; nb < nblk; nb++)
         for (int ch = 0; ch < nch; ch++)
             for (int u = 0; u < sc.KH; u++)
@@ -396,14 +410,31 @@ int upload_packed(SubConv& sc, int cin_real, F wfun) {
                         for (int nn = 0; nn < NB; nn++) {
                             const int co = nb * NB + nn;
                             if (co >= sc.Cout) continue;
-                            float* dst = &packed[(((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * NB + nn) * cpg];
+                            float* dst = &packed[base + (((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * NB + nn) * cpg];
                             for (int j = 0; j < cpg; j++) {
                                 const int ci = ch * sc.CC + 2 * j + h;
                                 if (ci < cin_real) dst[j] = wfun(co, ci, u, v);
                             }
                         }
+    return base;
+}
+
+int upload_weights(SubConv& sc, const std::vector<float>& packed) {
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * sizeof(float)));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename F>
+int upload_packed(SubConv& sc, int cin_real, F wfun) {
+    std::vector<float> packed;
+    pack_into(packed, sc, cin_real, wfun);
+    return upload_weights(sc, packed);
+}
+
+int upload_zslices(SubConv& sc, const std::vector<rt::ZSlice>& zs) {
+    RT_HIP(hipMalloc((void**)&sc.zs_dev, zs.size() * sizeof(rt::ZSlice)));
+    RT_HIP(hipMemcpy(sc.zs_dev, zs.data(), zs.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -455,7 +486,15 @@ int64_t count_wgs(const SubConv& sc) {
     return rt::cdiv(sc.Ho, sc.TY) * rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Cout, 32 * sc.NBW) * sc.nz;
 }
 
+// the direct kernel caches all weights of a slice in LDS and exists for a fixed set of windows
+void check_direct(SubConv& sc, int cin_real) {
+    const bool win = (sc.KH == sc.KW && (sc.KH == 1 || sc.KH == 2 || sc.KH == 3 || sc.KH == 5)) ||
+                     (sc.KH == 1 && sc.KW == 2) || (sc.KH == 2 && sc.KW == 1);
+    if (!win || (int64_t)sc.Cout * cin_real * sc.KH * sc.KW > 4096) sc.direct = 0;
+}
+
 void choose_tiling(SubConv& sc) {
+    sc.direct = (sc.Cout <= 2 && env_int("RT_CONV_NO_DIRECT", 0) == 0) ? 1 : 0;    // re-checked against the LDS weight cache below
     sc.CC = 8;
     sc.NBW = sc.Cout > 32 ? 2 : 1;
     if (sc.KH == 5) { sc.NBW = 1; sc.CC = 4; }
@@ -516,6 +555,7 @@ void free_plan(rtConvPlan* p) {
     for (auto& s : p->subs) {
         if (s.w_dev) (void)hipFree(s.w_dev);
         if (s.choff_dev) (void)hipFree(s.choff_dev);
+        if (s.zs_dev) (void)hipFree(s.zs_dev);
     }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
     delete p;
@@ -546,7 +586,9 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     sc.pad_y = d->pad_h; sc.pad_x = d->pad_w; sc.nz = 1;
     sc.y_cstride = (int64_t)Ho * Wo; sc.y_ystride = Wo; sc.y_xstride = 1;
     choose_tiling(sc);
-    sc.CinPad = rt::round_up(d->Cin, sc.CC);
+    sc.cin_real = d->Cin;
+    check_direct(sc, d->Cin);
+    sc.CinPad = sc.direct ? d->Cin : rt::round_up(d->Cin, sc.CC);
     if (sc.CinPad > 512) { free_plan(plan); return fail(RT_E_UNSUPPORTED, "conv2d: Cin > 512"); }
     const std::vector<float> w = to_f32(weights, (size_t)d->Cout * d->Cin * d->KH * d->KW, d->dtype);
     const int Cin = d->Cin, KH = d->KH, KW = d->KW;
@@ -585,31 +627,56 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
     const std::vector<float> w = to_f32(weights, (size_t)d->Cin * d->Cout * d->KH * d->KW, d->dtype);
     const int Cin = d->Cin, Cout = d->Cout, KH = d->KH, KW = d->KW;
+
+    // All s*s output phases go into ONE launch: the window is the largest phase window (2x2 for a 3x3
+    // stride-2 kernel), phases with fewer taps get zero weights for the missing ones, and a ZSlice per
+    // phase carries its padding, output origin and weight slab.
+    std::vector<Phase1D> py_ph, px_ph;
+    int wy = 1, wx = 1;
+    for (int ph = 0; ph < s; ph++) {
+        py_ph.push_back(phase1d(s, d->pad_h, KH, ph));
+        px_ph.push_back(phase1d(s, d->pad_w, KW, ph));
+        wy = std::max(wy, py_ph.back().K);
+        wx = std::max(wx, px_ph.back().K);
+    }
+    SubConv sc;
+    sc.KH = wy; sc.KW = wx; sc.S = 1; sc.Cout = Cout; sc.Hi = d->Hin; sc.Wi = d->Win;
+    sc.Ho = (Ho + s - 1) / s; sc.Wo = (Wo + s - 1) / s;
+    sc.y_cstride = (int64_t)Ho * Wo; sc.y_ystride = s * Wo; sc.y_xstride = s;
+    sc.nz = 0;
+    for (int py = 0; py < s; py++)
+        for (int px = 0; px < s; px++)
+            if (py < Ho && px < Wo) sc.nz++;
+    choose_tiling(sc);
+    sc.cin_real = Cin;
+    check_direct(sc, Cin);
+    sc.CinPad = sc.direct ? Cin : rt::round_up(Cin, sc.CC);
     int rc = 0;
+    if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) rc = fail(RT_E_UNSUPPORTED, "deconv2d: unsupported shape");
+    std::vector<float> packed;
+    std::vector<rt::ZSlice> zs;
     for (int py = 0; py < s && !rc; py++)
         for (int px = 0; px < s && !rc; px++) {
             if (py >= Ho || px >= Wo) continue;
-            const Phase1D ay = phase1d(s, d->pad_h, KH, py), ax = phase1d(s, d->pad_w, KW, px);
-            SubConv sc;
-            const bool empty = ay.K == 0 || ax.K == 0;          // bias-only phase: 1x1 window, zero weights
-            sc.KH = empty ? 1 : ay.K; sc.KW = empty ? 1 : ax.K; sc.S = 1;
-            sc.Cout = Cout; sc.Hi = d->Hin; sc.Wi = d->Win;
-            sc.Ho = (Ho - py + s - 1) / s; sc.Wo = (Wo - px + s - 1) / s;
-            sc.pad_y = empty ? 0 : ay.pad; sc.pad_x = empty ? 0 : ax.pad; sc.nz = 1;
-            sc.y_cstride = (int64_t)Ho * Wo; sc.y_ystride = s * Wo; sc.y_xstride = s;
-            sc.y_off = (int64_t)py * Wo + px;
-            choose_tiling(sc);
-            sc.CinPad = rt::round_up(Cin, sc.CC);
-            if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "deconv2d: unsupported shape"); break; }
-            rc = upload_packed(sc, Cin, [&](int co, int ci, int u, int v) {
-                if (empty) return 0.f;
+            const Phase1D &ay = py_ph[py], &ax = px_ph[px];
+            rt::ZSlice z{};
+            z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
+            z.Ho = (Ho - py + s - 1) / s; z.Wo = (Wo - px + s - 1) / s;
+            z.ch_row = 0;
+            z.y_off = (int64_t)py * Wo + px;
+            z.w_off = pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) {
+                if (u >= ay.K || v >= ax.K) return 0.f;                               // padded tap / empty phase
                 return w[(((size_t)ci * Cout + co) * KH + ay.tap[u]) * KW + ax.tap[v]];   // (Cin,Cout,R,S)
             });
-            std::vector<int> table(sc.CinPad, -1);
-            for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
-            if (!rc) rc = upload_table(sc, table);
-            plan->subs.push_back(sc);
+            zs.push_back(z);
         }
+    if (!rc) rc = upload_weights(sc, packed);
+    if (!rc && (s > 1)) rc = upload_zslices(sc, zs);
+    if (!rc && s == 1) { sc.pad_y = zs[0].pad_y; sc.pad_x = zs[0].pad_x; sc.Ho = zs[0].Ho; sc.Wo = zs[0].Wo; sc.y_off = zs[0].y_off; }
+    std::vector<int> table(sc.CinPad, -1);
+    for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
+    if (!rc) rc = upload_table(sc, table);
+    plan->subs.push_back(sc);
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, Cout, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, Cout);
@@ -663,7 +730,9 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     else { sc.y_cstride = (int64_t)Do * Ho * Wo; sc.y_zstride = (int64_t)Ho * Wo; }
     choose_tiling(sc);
     const int cin_real = V * C;
-    sc.CinPad = rt::round_up(cin_real, sc.CC);
+    sc.cin_real = cin_real;
+    check_direct(sc, cin_real);
+    sc.CinPad = sc.direct ? cin_real : rt::round_up(cin_real, sc.CC);
     if (sc.CinPad > 512) { free_plan(plan); return fail(RT_E_UNSUPPORTED, "conv3d: V*C = %d > 512", cin_real); }
     const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
     int rc = upload_packed(sc, cin_real, [&](int co, int ci, int u, int v) {
@@ -697,12 +766,12 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     RT_REQUIRE(!d->out_dchw, "conv3d_transpose: output is always (D,C,H,W)");
     const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
     const int sd = d->stride[0], sh = d->stride[1];
-    const int pd = d->pad_start[0], ph = d->pad_start[1], pw = d->pad_start[2];
+    const int pd = d->pad_start[0], ph_ = d->pad_start[1], pw = d->pad_start[2];
     const int Dy = in_dims[0], Hy = in_dims[1], Wy = in_dims[2];
     const int Dx = d->D, Hx = d->H, Wx = d->W, K = d->K, C = d->C;
     // the reference verifies that the forward conv of the output gives the input dims
     // (lib/conv3d_transpose_plugin.cpp:108-111)
-    RT_REQUIRE((Dx + 2 * pd - V) / sd + 1 == Dy && (Hx + 2 * ph - R) / sh + 1 == Hy && (Wx + 2 * pw - Sk) / sh + 1 == Wy,
+    RT_REQUIRE((Dx + 2 * pd - V) / sd + 1 == Dy && (Hx + 2 * ph_ - R) / sh + 1 == Hy && (Wx + 2 * pw - Sk) / sh + 1 == Wy,
                "conv3d_transpose: out dims (%d,%d,%d) inconsistent with in dims (%d,%d,%d)", Dx, Hx, Wx, Dy, Hy, Wy);
     RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 31), "conv3d_transpose: input sample exceeds 2^31 elements");
 
@@ -714,46 +783,77 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
     const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
     int rc = 0;
+    // One launch per output-depth class (depths cls, cls+sd, ... share the same set of depth taps); inside
+    // it every (depth position, y/x output phase) is a ZSlice -- see rt_deconv2d_plan_create.
+    std::vector<Phase1D> py_ph, px_ph;
+    int wy = 1, wx = 1;
+    for (int ph = 0; ph < sh; ph++) {
+        py_ph.push_back(phase1d(sh, ph_, R, ph));
+        px_ph.push_back(phase1d(sh, pw, Sk, ph));
+        wy = std::max(wy, py_ph.back().K);
+        wx = std::max(wx, px_ph.back().K);
+    }
     for (int cls = 0; cls < sd && !rc; cls++) {          // output depths dx = cls, cls + sd, ...
         if (cls >= Dx) continue;
         const Phase1D az = phase1d(sd, pd, V, cls);
-        const int nz = (Dx - cls + sd - 1) / sd;
+        const int nzd = (Dx - cls + sd - 1) / sd;
         const int nv = std::max(az.K, 1);
-        for (int py = 0; py < sh && !rc; py++)
-            for (int px = 0; px < sh && !rc; px++) {
+        SubConv sc;
+        sc.KH = wy; sc.KW = wx; sc.S = 1; sc.Cout = C; sc.Hi = Hy; sc.Wi = Wy;
+        sc.Ho = (Hx + sh - 1) / sh; sc.Wo = (Wx + sh - 1) / sh;
+        sc.y_cstride = out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
+        int nph = 0;
+        for (int py = 0; py < sh; py++)
+            for (int px = 0; px < sh; px++)
+                if (py < Hx && px < Wx) nph++;
+        sc.nz = nzd * nph;
+        choose_tiling(sc);
+        const int cin_real = nv * K;
+        sc.cin_real = cin_real;
+        check_direct(sc, cin_real);
+    sc.CinPad = sc.direct ? cin_real : rt::round_up(cin_real, sc.CC);
+        if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
+        std::vector<float> packed;
+        std::vector<int64_t> w_offs;
+        for (int py = 0; py < sh; py++)
+            for (int px = 0; px < sh; px++) {
                 if (py >= Hx || px >= Wx) continue;
-                const Phase1D ay = phase1d(sh, ph, R, py), ax = phase1d(sh, pw, Sk, px);
-                const bool empty = az.K == 0 || ay.K == 0 || ax.K == 0;
-                SubConv sc;
-                sc.KH = empty ? 1 : ay.K; sc.KW = empty ? 1 : ax.K; sc.S = 1; sc.Cout = C;
-                sc.Hi = Hy; sc.Wi = Wy;
-                sc.Ho = (Hx - py + sh - 1) / sh; sc.Wo = (Wx - px + sh - 1) / sh;
-                sc.pad_y = empty ? 0 : ay.pad; sc.pad_x = empty ? 0 : ax.pad; sc.nz = nz;
-                sc.y_cstride = out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
-                sc.y_zstride = (int64_t)sd * C * out_plane;
-                sc.y_off = (int64_t)cls * C * out_plane + (int64_t)py * Wx + px;
-                choose_tiling(sc);
-                const int cin_real = nv * K;
-                sc.CinPad = rt::round_up(cin_real, sc.CC);
-                if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
-                rc = upload_packed(sc, cin_real, [&](int co, int ci, int u, int v) {
-                    if (empty) return 0.f;
+                const Phase1D &ay = py_ph[py], &ax = px_ph[px];
+                w_offs.push_back(pack_into(packed, sc, cin_real, [&](int co, int ci, int u, int v) {
+                    if (az.K == 0 || u >= ay.K || v >= ax.K) return 0.f;
                     const int j = ci / K, k = ci % K;                        // gathered channel = (depth tap j, input channel k)
                     return w[((((size_t)k * V + az.tap[j]) * C + co) * R + ay.tap[u]) * Sk + ax.tap[v]];   // KVCRS
-                });
-                // z-slice m <-> output depth dx = cls + m*sd, which reads input depth m + j - az.pad for tap j
-                std::vector<int> table((size_t)nz * sc.CinPad, -1);
-                if (!empty)
-                    for (int m = 0; m < nz; m++)
-                        for (int j = 0; j < az.K; j++) {
-                            const int dy = m + j - az.pad;
-                            if (dy < 0 || dy >= Dy) continue;
-                            for (int k = 0; k < K; k++)
-                                table[(size_t)m * sc.CinPad + j * K + k] = (int)(((int64_t)k * Dy + dy) * in_plane);
-                        }
-                if (!rc) rc = upload_table(sc, table);
-                plan->subs.push_back(sc);
+                }));
             }
+        std::vector<rt::ZSlice> zs;
+        for (int m = 0; m < nzd; m++) {
+            int iph = 0;
+            for (int py = 0; py < sh; py++)
+                for (int px = 0; px < sh; px++) {
+                    if (py >= Hx || px >= Wx) continue;
+                    const Phase1D &ay = py_ph[py], &ax = px_ph[px];
+                    rt::ZSlice z{};
+                    z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
+                    z.Ho = (Hx - py + sh - 1) / sh; z.Wo = (Wx - px + sh - 1) / sh;
+                    z.ch_row = m;
+                    z.y_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
+                    z.w_off = w_offs[iph++];
+                    zs.push_back(z);
+                }
+        }
+        // table row m <-> output depth dx = cls + m*sd, which reads input depth m + j - az.pad for depth tap j
+        std::vector<int> table((size_t)nzd * sc.CinPad, -1);
+        for (int m = 0; m < nzd; m++)
+            for (int j = 0; j < az.K; j++) {
+                const int dy = m + j - az.pad;
+                if (dy < 0 || dy >= Dy) continue;
+                for (int k = 0; k < K; k++)
+                    table[(size_t)m * sc.CinPad + j * K + k] = (int)(((int64_t)k * Dy + dy) * in_plane);
+            }
+        rc = upload_weights(sc, packed);
+        if (!rc) rc = upload_zslices(sc, zs);
+        if (!rc) rc = upload_table(sc, table);
+        plan->subs.push_back(sc);
     }
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
@@ -788,6 +888,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
 #endif
         a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
         a.ch_off = sc.choff_dev;
+        a.zs = sc.zs_dev;
         a.CinPad = sc.CinPad; a.Cout = sc.Cout;
         a.Hi = sc.Hi; a.Wi = sc.Wi; a.Ho = sc.Ho; a.Wo = sc.Wo;
         a.pad_y = sc.pad_y; a.pad_x = sc.pad_x; a.nz = sc.nz;
@@ -800,6 +901,22 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
         RT_REQUIRE(sc.y_cstride * (int64_t)rt::round_up(sc.Cout, 64) < (1ll << 31), "rt_conv_enqueue: output sample exceeds 2^31 elements");
+        if (sc.direct) {
+            RT_REQUIRE(sc.Ho <= 65535, "rt_conv_enqueue: output too tall for the direct kernel");
+            dim3 dgrid((unsigned)rt::cdiv(sc.Wo, 256), (unsigned)sc.Ho, (unsigned)gz);
+            bool launched = false;
+#define RT_DIRECT(co, kh, kw)                                                                                         \
+    if (!launched && sc.Cout <= co && sc.KH == kh && sc.KW == kw) {                                                   \
+        hipLaunchKernelGGL((rt::conv_direct_f32_kernel<co, kh, kw>), dgrid, dim3(256), 0, S(s), a, sc.S, sc.cin_real); \
+        launched = true;                                                                                              \
+    }
+            RT_DIRECT(1, 1, 1) RT_DIRECT(1, 1, 2) RT_DIRECT(1, 2, 1) RT_DIRECT(1, 2, 2) RT_DIRECT(1, 3, 3) RT_DIRECT(1, 5, 5)
+            RT_DIRECT(2, 1, 1) RT_DIRECT(2, 1, 2) RT_DIRECT(2, 2, 1) RT_DIRECT(2, 2, 2) RT_DIRECT(2, 3, 3) RT_DIRECT(2, 5, 5)
+#undef RT_DIRECT
+            if (!launched) return fail(RT_E_UNSUPPORTED, "conv (direct): window %dx%d not instantiated", sc.KH, sc.KW);
+            RT_LAUNCH_CHECK("conv_direct_f32_kernel");
+            continue;
+        }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (int rc = launch_sub(sc, a, grid, S(s))) return rc;
     }
