@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
-network (61 fused launches) with the inputs already resident in HBM (the reference times
+network (49 fused launches) with the inputs already resident in HBM (the reference times
 context->execute the same way, sample_app/main.cpp:303-309).  Stereo pairs are independent, so ranks
 share nothing but the weights: rank 0 builds the weight-file image and broadcasts it over RCCL
 (torch.distributed backend "nccl"); there is no data-path collective and scaling is weak (each rank
@@ -36,15 +36,41 @@ W, H = 1257, 369
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HALF_W, HALF_H = 629, 185
 DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
+DOMINANT_BYTES = 4.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9 + 32)     # x, residual, y, weights, bias
 
 
 def dominant(name):
     return "resblock" in name or name.endswith("encoder2D_out")
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/rNN_traffic.json,
+    written by tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this
+    command; counters cannot be read from inside the timed process).  None when no such file is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    t = json.load(open(files[-1]))
+    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(weights, budget_s=12.0):
     """Bounded CPU sample of the same workload through the oracle (kind = "port")."""
     from oracle import stereo_oracle as O
+    torch.set_num_threads(host_cores())                     # more threads than the quota only adds throttling
     l, r = synth.synth_pair(H, W, 1234)
     L, R = torch.from_numpy(l)[None], torch.from_numpy(r)[None]
     with torch.no_grad():
@@ -54,7 +80,7 @@ def cpu_baseline(weights, budget_s=12.0):
             O.resnet18_2d(L, R, weights)
             n += 1
             dt = time.perf_counter() - t0
-            if dt >= budget_s or n >= 64:
+            if dt >= budget_s or n >= 512:
                 break
     return dict(value=n / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
@@ -133,6 +159,7 @@ def main():
                     cnt += 1
         avg_s = tot / cnt * 1e-3
         achieved = DOMINANT_FLOPS * b / avg_s / 1e12
+        traffic, traffic_src = measured_traffic() if b == 1 else (None, None)
         out = {
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,7 +170,9 @@ def main():
                        "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<3,3,1> 32->32 @629x185 (+bias,+residual,+ELU)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
+                         "algorithmic_bytes": DOMINANT_BYTES * b,
                          "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
                          "flops_per_launch": DOMINANT_FLOPS * b},
         }

@@ -61,6 +61,7 @@ struct ConvArgs {
     int nz;                // z-slices per sample (3-D depth positions / 1 for 2-D)
     int tiles_x;           // number of tiles along x (grid.x = tiles_x * tiles_y)
     int act;
+    int xcd_order;         // 1 = contiguous tile range per XCD (see kernel), 0 = dispatch order
     int64_t x_bstride;     // per-sample strides (elements)
     int64_t y_bstride;
     int64_t y_cstride;     // output channel stride
@@ -122,7 +123,15 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), each
+    // XCD has its own L2, and neighbouring tiles share input halo rows and partially written cache lines.
+    // Give every XCD a contiguous range of tiles (bijective for any grid size) so that sharing stays in one L2.
+    int tile = blockIdx.x;
+    if (p.xcd_order) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tx0 = (tile % p.tiles_x) * TX;
     const int ty0 = (tile / p.tiles_x) * TY;
     const int nblk = blockIdx.y;

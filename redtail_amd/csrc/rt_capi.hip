@@ -894,6 +894,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.pad_y = sc.pad_y; a.pad_x = sc.pad_x; a.nz = sc.nz;
         a.tiles_x = (int)rt::cdiv(sc.Wo, 32 * sc.TXW);
         a.act = plan->act;
+        a.xcd_order = env_int("RT_CONV_XCD", 1);
         a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
         a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;

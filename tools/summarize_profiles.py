@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of one round (gpurun_out/<run>/...) into the tracked files under profiles/.
+
+    python tools/summarize_profiles.py gpurun_out/r01b r01
+
+Inputs (written on the GPU box, see profiles/README.md for the exact commands):
+    <run>/trace/bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats
+    <run>/trace/bench_kernel_trace.csv
+    <run>/pmc_FETCH_SIZE, pmc_WRITE_SIZE, pmc_sq/p_counter_collection.csv     one --pmc pass each
+    <run>/bench_plain.json                    the un-profiled bench line
+Outputs: profiles/<tag>_kernel_stats.csv, <tag>_pmc.csv, <tag>_traffic.json, <tag>_bench.json, <tag>_timeline.txt
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+DOMINANT = "conv_mfma_f32_kernel<3, 3, 1, 4, 1, 1, 8, 4, true>"
+# gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
+# with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
+# 14546 KiB read, 14575 for 29091); WRITE_SIZE is exact (14545.6 KB for 14545.6 KiB written).
+FETCH_SCALE, WRITE_SCALE = 2.0, 1.0
+ALGO_READ = 4.0 * (2 * 32 * 185 * 629 + 32 * 32 * 9 + 32)      # x + residual + weights + bias
+ALGO_WRITE = 4.0 * 32 * 185 * 629
+
+
+def short(name):
+    name = name.replace("void rt::", "").replace("rt::", "")
+    return name.split("(")[0]
+
+
+def main():
+    run, tag = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(run, "bench_plain.json"), os.path.join(out, tag + "_bench.json"))
+
+    # ---- counters: mean per launch and kernel ---------------------------------------------------------
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(os.listdir(run)):
+        f = os.path.join(run, d, "p_counter_collection.csv")
+        if d.startswith("pmc_") and os.path.exists(f):
+            for r in csv.DictReader(open(f)):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for k in acc.values() for c in k})
+    with open(os.path.join(out, tag + "_pmc.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches"] + ["mean_" + c for c in counters])
+        for k in sorted(acc, key=lambda k: -sum(acc[k].get("FETCH_SIZE", [0]))):
+            n = max(len(v) for v in acc[k].values())
+            w.writerow([k, n] + ["%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else "" for c in counters])
+
+    dom = acc[DOMINANT]
+    fetch = sum(dom["FETCH_SIZE"]) / len(dom["FETCH_SIZE"]) * 1024 * FETCH_SCALE
+    write = sum(dom["WRITE_SIZE"]) / len(dom["WRITE_SIZE"]) * 1024 * WRITE_SCALE
+
+    # ---- durations of the dominant kernel from the trace ----------------------------------------------
+    rows = list(csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if short(r["Kernel_Name"]) == DOMINANT]
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    t1 = max(int(r["End_Timestamp"]) for r in rows)
+    traffic = dict(kernel=DOMINANT, launches_counted=len(dom["FETCH_SIZE"]),
+                   fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
+                   algorithmic_read_bytes=ALGO_READ, algorithmic_write_bytes=ALGO_WRITE,
+                   fetch_scale=FETCH_SCALE, write_scale=WRITE_SCALE,
+                   rocprof_avg_launch_us=sum(durs) / len(durs) / 1e3, rocprof_launches=len(durs))
+    json.dump(traffic, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
+
+    # ---- one steady-state step as a timeline (last full step of the trace) -----------------------------
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per_step = 49
+    last = rows[-per_step:]
+    base = int(last[0]["Start_Timestamp"])
+    with open(os.path.join(out, tag + "_timeline.txt"), "w") as f:
+        f.write("# last step of the traced run: start_us  dur_us  stream/queue  kernel\n")
+        for r in last:
+            f.write("%9.1f %8.1f  q%-3s %s\n" % ((int(r["Start_Timestamp"]) - base) / 1e3,
+                                               (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                               r.get("Queue_Id", "?"), short(r["Kernel_Name"])))
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
+        span = int(last[-1]["End_Timestamp"]) - base
+        f.write("# span %.1f us, sum of kernel durations %.1f us (two streams overlap)\n" % (span / 1e3, busy / 1e3))
+    print(json.dumps(traffic, indent=1))
+    print("trace span %.1f ms for %d launches" % ((t1 - t0) / 1e6, len(rows)))
+
+
+if __name__ == "__main__":
+    main()
