@@ -6,7 +6,10 @@
 
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
 network (49 fused launches) with the inputs already resident in HBM (the reference times
-context->execute the same way, sample_app/main.cpp:303-309).  Stereo pairs are independent, so ranks
+context->execute the same way, sample_app/main.cpp:303-309).  Steps are issued round-robin over
+--contexts execution contexts of the same engine configuration, each on its own stream (default 4, the
+usual TensorRT throughput set-up): the serial low-resolution tail of one pair then overlaps the encoder
+of the next.  "single_context" on the JSON line is the same workload through one context.  Stereo pairs are independent, so ranks
 share nothing but the weights: rank 0 builds the weight-file image and broadcasts it over RCCL
 (torch.distributed backend "nccl"); there is no data-path collective and scaling is weak (each rank
 processes its own K pairs).
@@ -92,6 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)       # the reference averages over 200 images
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "4")),
+                    help="IExecutionContexts per GPU, each with its own stream; steps are issued round-robin "
+                         "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,15 +124,21 @@ def main():
 
     lib = capi.NetLib()
     lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
-    net = lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob)
+    nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob) for _ in range(args.contexts)]
+    net = nets[0]
 
     b = args.batch
     ls, rs = zip(*(synth.synth_pair(H, W, 1234 + rank * 64 + i) for i in range(b)))
     left = torch.from_numpy(np.stack(ls)).to(dev)
     right = torch.from_numpy(np.stack(rs)).to(dev)
-    disp = torch.empty(b, 1, H, W, device=dev)
-    stream = torch.cuda.Stream(device=dev)
-    sh = stream.cuda_stream
+    disps = [torch.empty(b, 1, H, W, device=dev) for _ in nets]
+    disp = disps[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+    nctx = len(nets)
+
+    def step(i):
+        c = i % nctx
+        nets[c].execute(left, right, disps[c], b, stream=streams[c].cuda_stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -134,12 +146,12 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        net.execute(left, right, disp, b, stream=sh)
+    for i in range(args.warmup):
+        step(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net.execute(left, right, disp, b, stream=sh)
+    for i in range(args.steps):
+        step(i)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -147,7 +159,20 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     barrier()
-    assert torch.isfinite(disp).all(), "non-finite disparity"
+    # the reference's own loop for comparison (sample_app/main.cpp:303-309): one context, one pair in flight
+    single = None
+    if nctx > 1 and rank == 0:
+        n1 = min(args.steps, 200)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            nets[0].execute(left, right, disps[0], b, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        dt1 = time.perf_counter() - t1
+        single = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3, "steps": n1}
+    for d in disps:
+        assert torch.isfinite(d).all(), "non-finite disparity"
+        assert torch.equal(d, disps[0]), "contexts disagree"
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream ------
@@ -166,7 +191,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ResNet-18 2D Stereo DNN fp32, 1257x369, batch=%d per step, one MI355X per rank" % b,
-                       "pairs_per_step": b, "launches_per_step": net.num_launches, "layers": net.num_layers,
+                       "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,
                        "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<3,3,1> 32->32 @629x185 (+bias,+residual,+ELU)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -176,10 +201,13 @@ def main():
                          "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
                          "flops_per_launch": DOMINANT_FLOPS * b},
         }
+        if single is not None:
+            out["single_context"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth.synth_weights_resnet18_2d(seed=7))
         print(json.dumps(out), flush=True)
-    net.destroy()
+    for n in nets:
+        n.destroy()
     if distributed:
         torch.distributed.destroy_process_group()
 

@@ -65,6 +65,19 @@ def build_hip_timing(force=False):
     return out
 
 
+def build_hip_ablation(mask, force=False, timing=False):
+    """Kernel library with parts of conv_mfma_f32_kernel compiled out (tools/ablate_conv.py; never the product)."""
+    outdir = os.path.join(ROOT, "tools", "build")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "librt_stereo_hip_abl%d%s.so" % (mask, "_timing" if timing else ""))
+    deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
+    if force or _newer(out, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRT_ABLATE=%d" % mask, "-w"] +
+             (["-DRT_KERNEL_TIMING"] if timing else []) + [
+              os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+    return out
+
+
 def build_emu(force=False):
     """Host build of the same kernel sources on top of tests/emu (test infrastructure)."""
     os.makedirs(EMU_BUILD, exist_ok=True)

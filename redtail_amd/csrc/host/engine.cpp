@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -727,6 +728,7 @@ IHostMemory* EngineImpl::serialize() const {
 ContextImpl::ContextImpl(EngineImpl& e) : eng_(e) {
     buffers_.assign(e.tensors_.size(), nullptr);
     events_.assign(e.tensors_.size(), nullptr);
+    debug_sync_ = getenv("RT_DEBUG_SYNC") != nullptr;      // serialise every launch (A/B measurements only)
 }
 
 ContextImpl::~ContextImpl() {
@@ -903,6 +905,12 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             float ms = 0.f;
             rt_event_elapsed_ms(prof_events_[2 * i], prof_events_[2 * i + 1], &ms);
             profiler_->reportLayerTime(eng_.ops_[i].name.c_str(), ms);
+            if (getenv("RT_PROFILE_TIMELINE")) {            // start/end of every launch relative to the first one
+                float t0 = 0.f, t1 = 0.f;
+                rt_event_elapsed_ms(prof_events_[0], prof_events_[2 * i], &t0);
+                rt_event_elapsed_ms(prof_events_[0], prof_events_[2 * i + 1], &t1);
+                std::fprintf(stderr, "timeline s%d %9.1f %9.1f  %s\n", eng_.ops_[i].stream, t0 * 1e3f, t1 * 1e3f, eng_.ops_[i].name.c_str());
+            }
         }
     }
     return ok;

@@ -40,4 +40,27 @@ __device__ static __forceinline__ float apply_act_rt(float v, int act) {
     return act == 1 ? elu1(v) : (act == 2 ? sigmoid1(v) : v);
 }
 
+// ---- buffer addressing ------------------------------------------------------------------------------------
+// On gfx950 the fp32 MFMA shares the SIMD's issue slot with every other VALU instruction (measured,
+// tools/micro/mfma_valu.hip: the two do not overlap), so per-element 64-bit address arithmetic and bounds
+// selects are paid in MFMA time.  Raw buffer instructions take the address as
+//   base (4 SGPRs) + soffset (SGPR: plane / channel offset, scalar ALU) + voffset (VGPR: in-plane offset),
+// and the hardware range check turns out-of-image lanes into zeros / dropped stores: voffset = kBufOOB.
+// Valid voffset + soffset stay below 2^31 (checked when a plan is created).
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+constexpr unsigned kBufOOB = 0x80000000u;     // voffset of a lane that must read 0 / must not store
+constexpr unsigned kBufSpan = 0x80000000u;    // num_records of every resource
+__device__ static __forceinline__ buf_rsrc make_buf(const void* base, bool valid = true) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, valid ? kBufSpan : 0u, 0x00020000);
+}
+__device__ static __forceinline__ float buf_load(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ static __forceinline__ f32x4 buf_load4(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 }  // namespace rt

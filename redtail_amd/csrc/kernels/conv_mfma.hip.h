@@ -78,6 +78,20 @@ struct ConvArgs {
 #define RT_TSTAMP() do { } while (0)
 #endif
 
+// Ablation switches for tools/ablate_conv.py (separate instrumented builds, -DRT_ABLATE=<mask>; the product
+// build has RT_ABLATE == 0 and every switch folds away).  Results are wrong by construction.
+#ifndef RT_ABLATE
+#define RT_ABLATE 0
+#endif
+constexpr bool kAblGather = (RT_ABLATE & 1) != 0;    // no global input gathers
+constexpr bool kAblWLoad = (RT_ABLATE & 2) != 0;     // no global weight loads
+constexpr bool kAblLdsWr = (RT_ABLATE & 4) != 0;     // no LDS writes
+constexpr bool kAblBarrier = (RT_ABLATE & 8) != 0;   // no workgroup barriers
+constexpr bool kAblResid = (RT_ABLATE & 16) != 0;    // no residual loads
+constexpr bool kAblStore = (RT_ABLATE & 32) != 0;    // no output stores
+constexpr bool kAblLdsRd = (RT_ABLATE & 64) != 0;    // MFMA operands from registers instead of LDS
+__device__ __forceinline__ void wg_barrier() { if (!kAblBarrier) __syncthreads(); }
+
 template <int N> struct VecOf;
 template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -101,6 +115,8 @@ struct ConvCfg {
     static constexpr int NTHR = 64 * NW;
     static constexpr int NK_W = (W_ELEMS / 4 + NTHR - 1) / NTHR;
     static constexpr int WT = TY * TXW / NW;              // wave-tiles (32 px) per wave
+    // one 32x32 accumulator per wave: ask the register allocator for 5 waves/SIMD (<= 100 VGPR+AGPR)
+    static constexpr int MINW = (WT * NBW == 1 && NW == 4 && TY == 4) ? 5 : 1;
     static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "1, 2, 4 or 8 waves per workgroup");
     static_assert((TY * TXW) % NW == 0, "tile must split evenly over the waves");
     static_assert(WLDS || true, "");
@@ -109,9 +125,10 @@ struct ConvCfg {
 };
 
 template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS>
-__global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(64 * NW, (ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>::MINW))
+conv_mfma_f32_kernel(ConvArgs p) {
     using Cfg = ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>;
-    constexpr int TX = Cfg::TX, NB = Cfg::NB, PR = Cfg::PR, PC = Cfg::PC, WT = Cfg::WT, CPG = Cfg::CPG;
+    constexpr int TX = Cfg::TX, NB = Cfg::NB, PC = Cfg::PC, WT = Cfg::WT, CPG = Cfg::CPG;
     constexpr int NPIX = Cfg::NPIX, NKP = Cfg::NKP, TAPS = Cfg::TAPS, NPAR = Cfg::NPAR, NTHR = Cfg::NTHR;
     typedef typename VecOf<CPG>::type vec_t;
 
@@ -153,7 +170,7 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
     // ---- staging roles (see ConvCfg) ------------------------------------------------------------------
     const int sh = NW == 1 ? 0 : (wv & 1), spart = NW == 1 ? 0 : (wv >> 1);
     const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + sh;
-    int poff[NKP];      // in-plane element offset of the patch pixel, or -1 outside the image
+    unsigned voff[NKP]; // in-plane byte offset of the patch pixel, kBufOOB outside the image (buffer load returns 0)
     int lidx[NKP];      // LDS vec_t index of the patch pixel (parity 0 of this wave), or -1 if not owned
 #pragma unroll
     for (int k = 0; k < NKP; k++) {
@@ -162,45 +179,59 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
         const int iy = ty0 * S - pad_y + pr;
         const int ix = tx0 * S - pad_x + pc;
         const bool own = pidx < NPIX;
-        poff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.Wi + ix) * 4u : kBufOOB;
         lidx[k] = own ? (pr * 2 + sh) * PC + pc : -1;
     }
 
-    const f32x4* __restrict__ wsrc =
-        reinterpret_cast<const f32x4*>(p.w + w_off + ((int64_t)nblk * nchunks) * Cfg::W_ELEMS);
+    const float* __restrict__ wsrc = p.w + w_off + ((int64_t)nblk * nchunks) * Cfg::W_ELEMS;
 
     vec_t rin[NPAR][NKP];
     f32x4 rw[WLDS ? Cfg::NK_W : 1];
 
+    // accumulators start at the bias (accumulator register r holds channel (r&3) + 8*(r>>2) + 4*half of its
+    // 32-block; p.bias is padded to a multiple of 64), so the epilogue has no loads of its own
     f32x16 acc[WT][NBW];
 #pragma unroll
-    for (int i = 0; i < WT; i++)
+    for (int b = 0; b < NBW; b++) {
+        const float* bsrc = p.bias + blockIdx.y * NB + b * 32 + 4 * half;
 #pragma unroll
-        for (int b = 0; b < NBW; b++)
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bsrc + 8 * q);
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][b][r] = 0.f;
+            for (int i = 0; i < WT; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][b][4 * q + e] = bv[e];
+        }
+    }
 
-    // Loads only: invalid gathers are redirected to a zero word, so nothing has to be selected
-    // afterwards and the results are not touched until they are written to LDS one iteration later.
+    // Loads only.  Address = sample base + plane offset (SGPR, from the gather table) + in-plane offset (VGPR,
+    // fixed per lane for the whole kernel): no vector ALU work per load.  Out-of-image lanes carry kBufOOB and
+    // padded / out-of-range planes (table entry -1) use an empty resource, so both read 0.
+    const buf_rsrc rs_w = make_buf(wsrc);
+    unsigned wvoff[WLDS ? Cfg::NK_W : 1];
+#pragma unroll
+    for (int k = 0; k < (WLDS ? Cfg::NK_W : 1); k++) {
+        const int idx = tid + NTHR * k;
+        wvoff[k] = idx < Cfg::W_ELEMS / 4 ? (unsigned)idx * 16u : kBufOOB;
+    }
     auto prefetch = [&](int ch) {
 #pragma unroll
         for (int h = 0; h < NPAR; h++)
 #pragma unroll
             for (int j = 0; j < CPG; j++) {
                 const int off = tab[ch * CC + 2 * j + h];          // wave-uniform scalar load
+                const buf_rsrc rs = make_buf(xb, off >= 0);
+                const unsigned so = (unsigned)off * 4u;
 #pragma unroll
-                for (int k = 0; k < NKP; k++) {
-                    const bool ok = (poff[k] >= 0) & (off >= 0);
-                    const float* src = ok ? xb + ((int64_t)off + poff[k]) : p.zeros;
-                    rin[h][k][j] = *src;
-                }
+                for (int k = 0; k < NKP; k++)
+                    rin[h][k][j] = kAblGather ? (float)(off + (int)voff[k]) : buf_load(rs, voff[k], so);
             }
         if (WLDS) {
-            const f32x4* ws = wsrc + (int64_t)ch * (Cfg::W_ELEMS / 4);
+            const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_ELEMS * 4);
 #pragma unroll
             for (int k = 0; k < Cfg::NK_W; k++) {
-                const int idx = tid + NTHR * k;
-                rw[k] = ws[idx < Cfg::W_ELEMS / 4 ? idx : 0];
+                if (kAblWLoad) rw[k] = f32x4{(float)wvoff[k], 1.f, 2.f, (float)ch};
+                else rw[k] = buf_load4(rs_w, wvoff[k], so);
             }
         }
     };
@@ -214,29 +245,37 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
         const int t = wv + NW * i;
         b_base[i] = ((t / TXW) * S * 2 + half) * PC + ((t % TXW) * 32 + l31) * S;
     }
-    // residual (skip connection) values of this lane's outputs, fetched under the last chunk's MFMAs
+    // Output addressing (residual loads and stores): sample/slice base in the resource, channel offset in an
+    // SGPR, and ONE per-lane byte offset per wave-tile (pixel + the 4-channel shift of the upper half-wave).
+    // Accumulator register r of 32-block b holds channel cb + (r&3) + 8*(r>>2) + 4*half.
     const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
+    const int cs32 = (int)p.y_cstride;
+    const bool tail8 = (p.Cout & 7) != 0;          // only then is channel validity lane dependent
+    unsigned yvoff[WT];
+#pragma unroll
+    for (int i = 0; i < WT; i++) {
+        const int t = wv + NW * i;
+        const int oy = ty0 + t / TXW;
+        const int ox = tx0 + (t % TXW) * 32 + l31;
+        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * 4u : kBufOOB;
+    }
+    auto out_voff = [&](int i, int cs) {           // cs = scalar part of the channel index
+        return (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
+    };
+    // residual (skip connection) values of this lane's outputs, fetched under the last chunk's MFMAs
     const float* __restrict__ resid = p.resid;
     float rv[WT][NBW][16];
-    // (one 64-bit base per wave-tile + 32-bit channel offsets keeps this at ~1 address register per load)
-    const int cs32 = (int)p.y_cstride;
     auto prefetch_resid = [&]() {
 #pragma unroll
-        for (int i = 0; i < WT; i++) {
-            const int t = wv + NW * i;
-            const int oy = ty0 + t / TXW;
-            const int ox = tx0 + (t % TXW) * 32 + l31;
-            const bool pix_ok = (oy < Ho) & (ox < Wo) & (resid != nullptr);
-            const float* rbase = pix_ok ? resid + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride) : p.zeros;
-            const int cmul = pix_ok ? cs32 : 0;
+        for (int b = 0; b < NBW; b++)
 #pragma unroll
-            for (int b = 0; b < NBW; b++)
+            for (int r = 0; r < 16; r++) {
+                const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
+                const buf_rsrc rs = make_buf(resid + ybase, (resid != nullptr) & (cs < p.Cout));
+                const unsigned so = (unsigned)(cs * cs32) * 4u;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int co = nblk * NB + b * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
-                    rv[i][b][r] = rbase[co < p.Cout ? co * cmul : 0];
-                }
-        }
+                for (int i = 0; i < WT; i++) rv[i][b][r] = kAblResid ? (float)cs : buf_load(rs, out_voff(i, cs), so);
+            }
     };
     const vec_t* sIn4 = reinterpret_cast<const vec_t*>(sIn);
     const vec_t* sW4 = reinterpret_cast<const vec_t*>(sW);
@@ -248,6 +287,17 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
 #endif
     // registers -> LDS for the chunk that was prefetched last
     auto stage_to_lds = [&]() {
+        if (kAblLdsWr) {        // keep the staged values alive without touching LDS
+#pragma unroll
+            for (int h = 0; h < NPAR; h++)
+#pragma unroll
+                for (int k = 0; k < NKP; k++) asm volatile("" ::"v"(rin[h][k]));
+            if (WLDS) {
+#pragma unroll
+                for (int k = 0; k < Cfg::NK_W; k++) asm volatile("" ::"v"(rw[k]));
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < NPAR; h++)
 #pragma unroll
@@ -265,18 +315,20 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
     auto compute = [&](int ch) {
         const vec_t* wq = WLDS ? sW4 : gW4 + (int64_t)ch * (TAPS * 2 * NB);
         vec_t a_cur[NBW], b_cur[WT], a_nxt[NBW], b_nxt[WT];
+        auto lds_a = [&](int idx) { vec_t v; if (kAblLdsRd) { for (int e = 0; e < CPG; e++) v[e] = (float)(idx + e); } else v = wq[idx]; return v; };
+        auto lds_b = [&](int idx) { vec_t v; if (kAblLdsRd) { for (int e = 0; e < CPG; e++) v[e] = (float)(idx - e); } else v = sIn4[idx]; return v; };
 #pragma unroll
-        for (int b = 0; b < NBW; b++) a_cur[b] = wq[a_base[b]];
+        for (int b = 0; b < NBW; b++) a_cur[b] = lds_a(a_base[b]);
 #pragma unroll
-        for (int i = 0; i < WT; i++) b_cur[i] = sIn4[b_base[i]];
+        for (int i = 0; i < WT; i++) b_cur[i] = lds_b(b_base[i]);
 #pragma unroll
         for (int t = 0; t < TAPS; t++) {
             if (t + 1 < TAPS) {
                 const int r = (t + 1) / KW, s = (t + 1) % KW;
 #pragma unroll
-                for (int b = 0; b < NBW; b++) a_nxt[b] = wq[a_base[b] + (t + 1) * 2 * NB];
+                for (int b = 0; b < NBW; b++) a_nxt[b] = lds_a(a_base[b] + (t + 1) * 2 * NB);
 #pragma unroll
-                for (int i = 0; i < WT; i++) b_nxt[i] = sIn4[b_base[i] + r * 2 * PC + s];
+                for (int i = 0; i < WT; i++) b_nxt[i] = lds_b(b_base[i] + r * 2 * PC + s);
             }
 #pragma unroll
             for (int j = 0; j < CPG; j++)
@@ -297,49 +349,40 @@ __global__ void __launch_bounds__(64 * NW) conv_mfma_f32_kernel(ConvArgs p) {
     RT_TSTAMP();
     prefetch(0);
     for (int ch = 0; ch + 1 < nchunks; ch++) {
-        __syncthreads();   // everyone finished reading the previous chunk from LDS
+        wg_barrier();      // everyone finished reading the previous chunk from LDS
         RT_TSTAMP();
         stage_to_lds();
-        __syncthreads();
+        wg_barrier();
         RT_TSTAMP();
         prefetch(ch + 1);  // global loads fly while the MFMAs below run
         compute(ch);
     }
     // last chunk, peeled: the staging registers are dead now, so the residual (skip connection) values of
     // this lane's outputs are fetched into them and arrive under the last chunk's MFMAs
-    __syncthreads();
+    wg_barrier();
     RT_TSTAMP();
     stage_to_lds();
-    __syncthreads();
+    wg_barrier();
     RT_TSTAMP();
     prefetch_resid();
     compute(nchunks - 1);
 
     RT_TSTAMP();
-    // ---- epilogue: bias + residual (already in registers) + activation, 128-byte coalesced stores ---------
-    float* __restrict__ yout = p.y;
+    // ---- epilogue: residual (already in registers) + activation, 128-byte coalesced stores ----------------
+    // (the bias went in with the accumulator init)
 #pragma unroll
-    for (int b = 0; b < NBW; b++) {
-        // accumulator register r holds channel (r&3) + 8*(r>>2) + 4*half of this 32-block
-        const int cbase = nblk * NB + b * 32 + 4 * half;
-        f32x4 bv[4];
+    for (int b = 0; b < NBW; b++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 8 * q);
+        for (int r = 0; r < 16; r++) {
+            const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
+            const buf_rsrc rs = make_buf(p.y + ybase, cs < p.Cout);
+            const unsigned so = (unsigned)(cs * cs32) * 4u;
 #pragma unroll
-        for (int i = 0; i < WT; i++) {
-            const int t = wv + NW * i;
-            const int oy = ty0 + t / TXW;
-            const int ox = tx0 + (t % TXW) * 32 + l31;
-            const bool pix_ok = oy < Ho && ox < Wo;
-            float* ybp = yout + (ybase + (int64_t)oy * p.y_ystride + (int64_t)ox * p.y_xstride);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int co = cbase + (r & 3) + 8 * (r >> 2);
-                const float v = apply_act_fast(acc[i][b][r] + bv[r >> 2][r & 3] + rv[i][b][r], act);
-                if (pix_ok && co < p.Cout) ybp[co * cs32] = v;
+            for (int i = 0; i < WT; i++) {
+                const float v = apply_act_fast(acc[i][b][r] + rv[i][b][r], act);
+                if (!kAblStore || v == 12345.678f) buf_store(v, rs, out_voff(i, cs), so);
             }
         }
-    }
 #ifdef RT_KERNEL_TIMING
     __builtin_amdgcn_s_waitcnt(0);
 #endif

@@ -496,12 +496,14 @@ void check_direct(SubConv& sc, int cin_real) {
 void choose_tiling(SubConv& sc) {
     sc.direct = (sc.Cout <= 2 && env_int("RT_CONV_NO_DIRECT", 0) == 0) ? 1 : 0;    // re-checked against the LDS weight cache below
     sc.CC = 8;
-    sc.NBW = sc.Cout > 32 ? 2 : 1;
-    if (sc.KH == 5) { sc.NBW = 1; sc.CC = 4; }
+    // one 32-channel block per workgroup (NBW = 1): the 64-channel block halves the patch staging per FLOP but
+    // also halves the workgroup count, and every layer of the Stereo DNN graphs with Cout >= 64 runs at
+    // 1/4 .. 1/8 resolution where workgroups are scarce (measured: 128->128 @47x158 45.8 -> 29.0 us,
+    // 64->128 stride 2 28.6 -> 19.4 us, whole network +6 %).  The 2-wave {2,1,2} tile is slower everywhere.
+    sc.NBW = 1;
+    if (sc.KH == 5) sc.CC = 4;
     const int forced = env_int("RT_CONV_VARIANT", -1);
     set_tile(sc, forced >= 0 ? forced : 6);
-    // (splitting low-resolution layers further -- NBW = 1 or the {2,1,2} tile below 512 workgroups -- was
-    //  measured and lost 8 % end to end: the extra patch staging per FLOP costs more than the idle CUs)
     const int nbw = env_int("RT_CONV_NBW", 0);
     if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
 }

@@ -105,6 +105,33 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_32x32x16f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32f16(a, b, c)
+// raw buffer resources: base + num_records, range check on voffset + soffset (out of range reads 0, stores vanish)
+namespace hipemu {
+struct buffer_rsrc { char* base; unsigned num_records; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+static inline buffer_rsrc make_buffer_rsrc(void* p, int, unsigned num, int) { return buffer_rsrc{static_cast<char*>(p), num}; }
+static inline bool buffer_ok(const buffer_rsrc& r, unsigned voff, unsigned soff, unsigned bytes) {
+    return (unsigned long long)voff + soff + bytes <= r.num_records;
+}
+static inline unsigned buffer_load_b32(const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    unsigned v = 0;
+    if (buffer_ok(r, voff, soff, 4)) std::memcpy(&v, r.base + (size_t)voff + soff, 4);
+    return v;
+}
+static inline u32x4 buffer_load_b128(const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    u32x4 v = {0, 0, 0, 0};
+    if (buffer_ok(r, voff, soff, 16)) std::memcpy(&v, r.base + (size_t)voff + soff, 16);
+    return v;
+}
+static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    if (buffer_ok(r, voff, soff, 4)) std::memcpy(r.base + (size_t)voff + soff, &v, 4);
+}
+}  // namespace hipemu
+#define __amdgpu_buffer_rsrc_t hipemu::buffer_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) hipemu::make_buffer_rsrc(p, stride, num, flags)
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hipemu::buffer_load_b32(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu::buffer_load_b128(r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, aux) hipemu::buffer_store_b32(d, r, v, s)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

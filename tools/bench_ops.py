@@ -64,6 +64,7 @@ def main():
         ("conv3x3 32->32 @185x629 +res+ELU b1", 32, 32, 185, 629, 3, 1, 1, True, 1, False),
         ("conv3x3 32->32 @185x629 +res+ELU b2", 32, 32, 185, 629, 3, 1, 1, True, 2, False),
         ("conv3x3 32->32 @185x629 +res+ELU b8", 32, 32, 185, 629, 3, 1, 1, True, 8, False),
+        ("conv3x3 32->32 @185x629 +ELU (no residual) b8", 32, 32, 185, 629, 3, 1, 1, False, 8, False),
         ("conv3x3 32->32 @185x640 (aligned rows) b8", 32, 32, 185, 640, 3, 1, 1, True, 8, False),
         ("conv3x3 32->32 @185x640 (aligned rows) b1", 32, 32, 185, 640, 3, 1, 1, True, 1, False),
         ("conv5x5s2 3->32 @369x1257 +ELU b2", 3, 32, 369, 1257, 5, 2, 2, False, 2, False),

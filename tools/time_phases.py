@@ -13,7 +13,7 @@ from redtail_amd import build, capi  # noqa: E402
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 k = capi.KernelLib.__new__(capi.KernelLib)
 import ctypes  # noqa: E402
-k.path = os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so")
+k.path = os.environ.get("RT_TIMING_LIB", os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so"))
 k.lib = ctypes.CDLL(k.path)
 for name, (res, args) in capi.KERNEL_SYMBOLS.items():
     fn = getattr(k.lib, name)
@@ -26,7 +26,7 @@ plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, ha
 x = torch.randn(b, cin, h, w, device="cuda")
 y = torch.empty_like(x)
 r = torch.randn_like(x)
-nwg = 47 * 10 * b
+nwg = 47 * 20 * b          # 4 x 32 pixel tiles
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     plan.enqueue(x, y, r, b)
@@ -43,3 +43,7 @@ for i in range(10):
     print("  %-16s -> %-16s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10),
                                                  np.percentile(d[:, i], 90)))
 print("  workgroup lifetime mean %.1f" % (t[:, 10] - t[:, 0]).mean())
+print("  kernel span (first start .. last end) %.1f; starts: p50 %.1f p90 %.1f max %.1f after the first" % (
+    t[:, 10].max() - t[:, 0].min(), np.percentile(t[:, 0] - t[:, 0].min(), 50), np.percentile(t[:, 0] - t[:, 0].min(), 90),
+    (t[:, 0] - t[:, 0].min()).max()))
+print("  ends: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(t[:, 10] - t[:, 0].min(), q) for q in (10, 50, 90, 100)))
