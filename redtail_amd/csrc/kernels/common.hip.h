@@ -33,7 +33,7 @@ __device__ static __forceinline__ float apply_act(float v) {
 __device__ static __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ static __forceinline__ float apply_act_fast(float v, int act) {
     if (act == 1) return v > 0.f ? v : fast_exp(v) - 1.f;
-    if (act == 2) return 1.f / (1.f + fast_exp(-v));
+    if (act == 2) return __builtin_amdgcn_rcpf(1.f + fast_exp(-v));      // v_rcp_f32: 1 ulp
     return v;
 }
 __device__ static __forceinline__ float apply_act_rt(float v, int act) {

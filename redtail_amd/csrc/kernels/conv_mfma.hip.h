@@ -27,6 +27,7 @@
 //   reads of tap t+1 are issued before the MFMAs of tap t: the kernel is MFMA-bound,
 //   roofline = 157.3 TFLOP/s (MI355X_MICROARCH.md).
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 namespace rt {
@@ -115,8 +116,11 @@ struct ConvCfg {
     static constexpr int NTHR = 64 * NW;
     static constexpr int NK_W = (W_ELEMS / 4 + NTHR - 1) / NTHR;
     static constexpr int WT = TY * TXW / NW;              // wave-tiles (32 px) per wave
+    // LDS stages.  2 = double buffer with one barrier per chunk: measured slower (b8 197 vs 179 us, 5 instead of
+    // 7 waves/SIMD for the extra 15.7 KB) -- barriers are not what bounds the kernel -- so 1 everywhere.
+    static constexpr int NBUF = 1;
     // one 32x32 accumulator per wave: ask the register allocator for 5 waves/SIMD (<= 100 VGPR+AGPR)
-    static constexpr int MINW = (WT * NBW == 1 && NW == 4 && TY == 4) ? 5 : 1;
+    static constexpr int MINW = (WT * NBW == 1 && NW == 4 && TY == 4) ? 5 : (WT * NBW == 1 && NW == 8 ? 4 : 1);
     static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "1, 2, 4 or 8 waves per workgroup");
     static_assert((TY * TXW) % NW == 0, "tile must split evenly over the waves");
     static_assert(WLDS || true, "");
@@ -132,8 +136,10 @@ conv_mfma_f32_kernel(ConvArgs p) {
     constexpr int NPIX = Cfg::NPIX, NKP = Cfg::NKP, TAPS = Cfg::TAPS, NPAR = Cfg::NPAR, NTHR = Cfg::NTHR;
     typedef typename VecOf<CPG>::type vec_t;
 
-    __shared__ __attribute__((aligned(16))) float sIn[Cfg::IN_ELEMS];   // [row][h][col][CPG]
-    __shared__ __attribute__((aligned(16))) float sW[WLDS ? Cfg::W_ELEMS : 4];   // [tap][h][co][CPG]
+    // NBUF == 2: the chunk being staged never aliases the one being read and one barrier per chunk is enough
+    constexpr int NBUF = Cfg::NBUF;
+    __shared__ __attribute__((aligned(16))) float sIn[NBUF][Cfg::IN_ELEMS];            // [row][h][col][CPG]
+    __shared__ __attribute__((aligned(16))) float sW[NBUF][WLDS ? Cfg::W_ELEMS : 4];   // [tap][h][co][CPG]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -187,6 +193,47 @@ conv_mfma_f32_kernel(ConvArgs p) {
 
     vec_t rin[NPAR][NKP];
     f32x4 rw[WLDS ? Cfg::NK_W : 1];
+
+    // Output addressing (residual loads and stores): sample/slice base in the resource, channel offset in an
+    // SGPR, and ONE per-lane byte offset per wave-tile (pixel + the 4-channel shift of the upper half-wave).
+    // Accumulator register r of 32-block b holds channel cb + (r&3) + 8*(r>>2) + 4*half.
+    const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
+    const int cs32 = (int)p.y_cstride;
+    const bool tail8 = (p.Cout & 7) != 0;          // only then is channel validity lane dependent
+    unsigned yvoff[WT];
+#pragma unroll
+    for (int i = 0; i < WT; i++) {
+        const int t = wv + NW * i;
+        const int oy = ty0 + t / TXW;
+        const int ox = tx0 + (t % TXW) * 32 + l31;
+        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * 4u : kBufOOB;
+    }
+    // residual (skip connection) values of this lane's outputs: requested first thing, so their (HBM) latency
+    // overlaps the first gather, and added to the accumulators before the first MFMA -- no registers are held
+    // for them afterwards and the epilogue has no loads.
+    // TAIL = channel count not a multiple of 8 (the only case with lane-dependent channel validity); both
+    // versions are behind one scalar branch so the common one carries no selects.
+    const float* __restrict__ resid = p.resid;
+    float rv[WT][NBW][16];
+    auto prefetch_resid_t = [&](auto TAIL) {
+#pragma unroll
+        for (int b = 0; b < NBW; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
+                const buf_rsrc rs = make_buf(resid + ybase, (resid != nullptr) & (cs < p.Cout));
+                const unsigned so = (unsigned)(cs * cs32) * 4u;
+#pragma unroll
+                for (int i = 0; i < WT; i++) {
+                    const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
+                    rv[i][b][r] = kAblResid ? (float)cs : buf_load(rs, vo, so);
+                }
+            }
+    };
+    auto prefetch_resid = [&]() {
+        if (tail8) prefetch_resid_t(std::true_type{});
+        else prefetch_resid_t(std::false_type{});
+    };
 
     // accumulators start at the bias (accumulator register r holds channel (r&3) + 8*(r>>2) + 4*half of its
     // 32-block; p.bias is padded to a multiple of 64), so the epilogue has no loads of its own
@@ -245,48 +292,15 @@ conv_mfma_f32_kernel(ConvArgs p) {
         const int t = wv + NW * i;
         b_base[i] = ((t / TXW) * S * 2 + half) * PC + ((t % TXW) * 32 + l31) * S;
     }
-    // Output addressing (residual loads and stores): sample/slice base in the resource, channel offset in an
-    // SGPR, and ONE per-lane byte offset per wave-tile (pixel + the 4-channel shift of the upper half-wave).
-    // Accumulator register r of 32-block b holds channel cb + (r&3) + 8*(r>>2) + 4*half.
-    const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
-    const int cs32 = (int)p.y_cstride;
-    const bool tail8 = (p.Cout & 7) != 0;          // only then is channel validity lane dependent
-    unsigned yvoff[WT];
-#pragma unroll
-    for (int i = 0; i < WT; i++) {
-        const int t = wv + NW * i;
-        const int oy = ty0 + t / TXW;
-        const int ox = tx0 + (t % TXW) * 32 + l31;
-        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * 4u : kBufOOB;
-    }
-    auto out_voff = [&](int i, int cs) {           // cs = scalar part of the channel index
-        return (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
-    };
-    // residual (skip connection) values of this lane's outputs, fetched under the last chunk's MFMAs
-    const float* __restrict__ resid = p.resid;
-    float rv[WT][NBW][16];
-    auto prefetch_resid = [&]() {
-#pragma unroll
-        for (int b = 0; b < NBW; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
-                const buf_rsrc rs = make_buf(resid + ybase, (resid != nullptr) & (cs < p.Cout));
-                const unsigned so = (unsigned)(cs * cs32) * 4u;
-#pragma unroll
-                for (int i = 0; i < WT; i++) rv[i][b][r] = kAblResid ? (float)cs : buf_load(rs, out_voff(i, cs), so);
-            }
-    };
-    const vec_t* sIn4 = reinterpret_cast<const vec_t*>(sIn);
-    const vec_t* sW4 = reinterpret_cast<const vec_t*>(sW);
     const vec_t* __restrict__ gW4 = reinterpret_cast<const vec_t*>(wsrc);   // weights straight from L1/L2 (WLDS == false)
 
 #ifdef RT_KERNEL_TIMING
     unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
     int dbi = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // registers -> LDS for the chunk that was prefetched last
-    auto stage_to_lds = [&]() {
+    auto stage_to_lds = [&](int buf) {
         if (kAblLdsWr) {        // keep the staged values alive without touching LDS
 #pragma unroll
             for (int h = 0; h < NPAR; h++)
@@ -302,18 +316,19 @@ conv_mfma_f32_kernel(ConvArgs p) {
         for (int h = 0; h < NPAR; h++)
 #pragma unroll
             for (int k = 0; k < NKP; k++)
-                if (lidx[k] >= 0) reinterpret_cast<vec_t*>(sIn)[lidx[k] + h * PC] = rin[h][k];
+                if (lidx[k] >= 0) reinterpret_cast<vec_t*>(sIn[buf])[lidx[k] + h * PC] = rin[h][k];
         if (WLDS) {
 #pragma unroll
             for (int k = 0; k < Cfg::NK_W; k++) {
                 const int idx = tid + NTHR * k;
-                if (idx < Cfg::W_ELEMS / 4) reinterpret_cast<f32x4*>(sW)[idx] = rw[k];
+                if (idx < Cfg::W_ELEMS / 4) reinterpret_cast<f32x4*>(sW[buf])[idx] = rw[k];
             }
         }
     };
     // all MFMAs of one chunk; operands of tap t+1 are fetched before the MFMAs of tap t
-    auto compute = [&](int ch) {
-        const vec_t* wq = WLDS ? sW4 : gW4 + (int64_t)ch * (TAPS * 2 * NB);
+    auto compute = [&](int ch, int buf) {
+        const vec_t* sIn4 = reinterpret_cast<const vec_t*>(sIn[buf]);
+        const vec_t* wq = WLDS ? reinterpret_cast<const vec_t*>(sW[buf]) : gW4 + (int64_t)ch * (TAPS * 2 * NB);
         vec_t a_cur[NBW], b_cur[WT], a_nxt[NBW], b_nxt[WT];
         auto lds_a = [&](int idx) { vec_t v; if (kAblLdsRd) { for (int e = 0; e < CPG; e++) v[e] = (float)(idx + e); } else v = wq[idx]; return v; };
         auto lds_b = [&](int idx) { vec_t v; if (kAblLdsRd) { for (int e = 0; e < CPG; e++) v[e] = (float)(idx - e); } else v = sIn4[idx]; return v; };
@@ -347,46 +362,70 @@ conv_mfma_f32_kernel(ConvArgs p) {
     };
 
     RT_TSTAMP();
-    prefetch(0);
-    for (int ch = 0; ch + 1 < nchunks; ch++) {
-        wg_barrier();      // everyone finished reading the previous chunk from LDS
-        RT_TSTAMP();
-        stage_to_lds();
-        wg_barrier();
-        RT_TSTAMP();
-        prefetch(ch + 1);  // global loads fly while the MFMAs below run
-        compute(ch);
-    }
-    // last chunk, peeled: the staging registers are dead now, so the residual (skip connection) values of
-    // this lane's outputs are fetched into them and arrive under the last chunk's MFMAs
-    wg_barrier();
-    RT_TSTAMP();
-    stage_to_lds();
-    wg_barrier();
-    RT_TSTAMP();
     prefetch_resid();
-    compute(nchunks - 1);
+    prefetch(0);
+#pragma unroll
+    for (int i = 0; i < WT; i++)
+#pragma unroll
+        for (int b = 0; b < NBW; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][b][r] += rv[i][b][r];
+    stage_to_lds(0);
+    wg_barrier();
+    RT_TSTAMP();
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int cur = NBUF == 2 ? (ch & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
+        const bool more = ch + 1 < nchunks;
+        if (more) prefetch(ch + 1);        // global loads fly while the MFMAs below run
+        compute(ch, cur);
+        RT_TSTAMP();
+        if (more) {
+            if (NBUF == 1) wg_barrier();   // single stage: everyone must be done reading it first
+            stage_to_lds(nxt);
+            wg_barrier();
+            RT_TSTAMP();
+        }
+    }
 
     RT_TSTAMP();
-    // ---- epilogue: residual (already in registers) + activation, 128-byte coalesced stores ----------------
-    // (the bias went in with the accumulator init)
+    // ---- epilogue: activation, 128-byte coalesced stores -------------------------------------------------------
+    // (bias and residual went in with the accumulator init; one scalar branch per activation / tail case keeps the
+    //  16-element loops free of selects)
+    auto epilogue = [&](auto ACT, auto TAIL) {
 #pragma unroll
-    for (int b = 0; b < NBW; b++)
+        for (int b = 0; b < NBW; b++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
-            const buf_rsrc rs = make_buf(p.y + ybase, cs < p.Cout);
-            const unsigned so = (unsigned)(cs * cs32) * 4u;
+            for (int r = 0; r < 16; r++) {
+                const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
+                const buf_rsrc rs = make_buf(p.y + ybase, cs < p.Cout);
+                const unsigned so = (unsigned)(cs * cs32) * 4u;
 #pragma unroll
-            for (int i = 0; i < WT; i++) {
-                const float v = apply_act_fast(acc[i][b][r] + rv[i][b][r], act);
-                if (!kAblStore || v == 12345.678f) buf_store(v, rs, out_voff(i, cs), so);
+                for (int i = 0; i < WT; i++) {
+                    const float v = apply_act_fast(acc[i][b][r], decltype(ACT)::value);
+                    const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
+                    if (!kAblStore || v == 12345.678f) buf_store(v, rs, vo, so);
+                }
             }
-        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (tail8) {
+        if (act == 1) epilogue(I1{}, std::true_type{});
+        else if (act == 2) epilogue(I2{}, std::true_type{});
+        else epilogue(I0{}, std::true_type{});
+    } else {
+        if (act == 1) epilogue(I1{}, std::false_type{});
+        else if (act == 2) epilogue(I2{}, std::false_type{});
+        else epilogue(I0{}, std::false_type{});
+    }
 #ifdef RT_KERNEL_TIMING
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     RT_TSTAMP();
+#ifdef RT_KERNEL_TIMING
+    if (dbgp && tid == 0) dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0;   // 100 MHz reference clock
+#endif
 }
 
 

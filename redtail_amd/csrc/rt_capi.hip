@@ -477,6 +477,8 @@ void set_tile(SubConv& sc, int variant) {
         case 0: sc.TY = 4; sc.TXW = 2; sc.NW = 4; break;
         case 4: sc.TY = 2; sc.TXW = 2; sc.NW = 4; break;
         case 9: sc.TY = 2; sc.TXW = 1; sc.NW = 2; break;
+        case 8: sc.TY = 8; sc.TXW = 1; sc.NW = 8; break;
+        case 10: sc.TY = 8; sc.TXW = 1; sc.NW = 4; break;
         default: sc.TY = 4; sc.TXW = 1; sc.NW = 4; break;     // 6
     }
     sc.WLDS = 1;
@@ -528,7 +530,7 @@ int launch_window(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream
                            dim3(64 * nw), 0, st, a);                                                      \
         return 0;                                                                                         \
     }
-    RT_TILE(4, 2, 4, true) RT_TILE(4, 1, 4, true) RT_TILE(2, 2, 4, true) RT_TILE(2, 1, 2, true)
+    RT_TILE(4, 2, 4, true) RT_TILE(4, 1, 4, true) RT_TILE(2, 2, 4, true) RT_TILE(2, 1, 2, true) RT_TILE(8, 1, 8, true) RT_TILE(8, 1, 4, true)
 #undef RT_TILE
     return 1;
 }

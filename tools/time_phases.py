@@ -43,6 +43,8 @@ for i in range(10):
     print("  %-16s -> %-16s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10),
                                                  np.percentile(d[:, i], 90)))
 print("  workgroup lifetime mean %.1f" % (t[:, 10] - t[:, 0]).mean())
+print("  shader clock during the kernel: %.0f MHz (s_memtime ticks per 100 MHz s_memrealtime tick)" % (
+    (t[:, 10] - t[:, 0]).sum() / t[:, 15].sum() * 100.0))
 print("  kernel span (first start .. last end) %.1f; starts: p50 %.1f p90 %.1f max %.1f after the first" % (
     t[:, 10].max() - t[:, 0].min(), np.percentile(t[:, 0] - t[:, 0].min(), 50), np.percentile(t[:, 0] - t[:, 0].min(), 90),
     (t[:, 0] - t[:, 0].min()).max()))
