@@ -1,0 +1,253 @@
+// Winograd F(2x2, 3x3) convolution on the gfx950 matrix cores, fp32 (v_mfma_f32_16x16x4_f32).
+//
+// Serves the stride-1 3x3 windows of the hot path -- 40 of the 49 launches of ResNet-18 2D (reference
+// resnet18_2D_513x257_net.cpp:48-719) and, through the same gather table as conv_mfma_f32_kernel, the
+// (D*C)-merged 3x3x3 Conv3DPlugin layers (reference lib/conv3d_plugin.cpp:187-216) -- with 16 instead of 36
+// multiplies per 2x2 output tile and input channel (the minimal-filtering algorithm cuDNN / TensorRT pick for
+// fp32 3x3 convolutions on the reference's side):
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d = 4x4 input tile, g = 3x3 filter, Y = 2x2 outputs
+// On gfx950 the fp32 MFMA and the vector ALU share one issue slot (tools/micro/mfma_valu.hip), so the contraction
+// is priced in MFMA cycles + VALU cycles; this formulation needs 16 MFMA k-steps of 32 cycles per 4 input
+// channels and 16 cout x 16 tiles, against 36 equivalent ones for the direct form.
+//
+// GEMM view: one GEMM per Winograd position p = 4*pr + pc:   M_p[cout][tile] = sum_cin U_p[cout][cin] V_p[cin][tile]
+//   A operand = U_p (G g G^T, transformed on the host, exact: G holds only 0, 1, +-1/2)
+//   B operand = V_p (B^T d B), computed by the lane that feeds it: lane (k4 = lane>>4, t = lane&15) owns tile t
+//               of its wave and input channel 4*j + k4 -> 16 LDS words in, 32 adds, 16 MFMA operands out.
+//   Accumulators: 16 positions x 4 registers (16 cout x 16 tiles per wave) stay live over all input channels,
+//               so the output transform A^T M A runs once, in the epilogue (24 adds per output 2x2).
+// Bias and the residual (skip connection) are folded into the accumulator init: M_0, M_3, M_12, M_15 are the
+// positions that reach exactly one of the four outputs (with signs +, -, -, +).
+//
+// Workgroup = NW waves = (NW/2 tile rows) x (2 blocks of 16 output channels): tile = NW rows x 32 pixels x 32
+// channels.  LDS per chunk of 8 input channels: raw patch [ch][row][36] (channel stride = 32 mod 64 words, so the
+// ds_read_b64 of the four k4 groups hit disjoint banks) + transformed weights [k-step][k4][p/4][cout][p%4]
+// (one conflict-free ds_read_b128 per 4 positions).  Staging and addressing as in conv_mfma.hip.h.
+#pragma once
+#include <type_traits>
+#include "common.hip.h"
+#include "conv_mfma.hip.h"
+
+namespace rt {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef RT_WINO_MINW
+#define RT_WINO_MINW 3
+#endif
+template <int NW>
+struct WinoCfg {
+    static constexpr int CC = 8;                          // input channels per chunk (2 MFMA k-steps of 4)
+    static constexpr int TR = NW / 2;                     // tile rows (of 2 output rows) per workgroup
+    static constexpr int TY = 2 * TR, TX = 32;            // output tile
+    static constexpr int PR = TY + 2, PC = TX + 2;        // input patch
+    static constexpr int PCP = 36;                        // LDS row pitch (words)
+    static constexpr int CHS = ((PR * PCP - 32 + 63) / 64) * 64 + 32;   // channel stride: >= PR*PCP, = 32 (mod 64)
+    static constexpr int NPIX = PR * PC;
+    static constexpr int CPW = CC / NW > 0 ? CC / NW : 1; // channels staged per wave
+    static constexpr int NKP = (NPIX + 63) / 64;          // patch pixels per lane and channel
+    static constexpr int U_ELEMS = 2 * 4 * 4 * 32 * 4;    // transformed weights per chunk and 32-channel block
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int NK_W = U_ELEMS / 4 / NTHR;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(CC % NW == 0 || NW == 8, "");
+    static_assert(U_ELEMS / 4 % NTHR == 0, "weight slab is copied as whole float4 rounds");
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(ConvArgs p) {
+    using Cfg = WinoCfg<NW>;
+    constexpr int CC = Cfg::CC, TY = Cfg::TY, TX = Cfg::TX, PC = Cfg::PC, PCP = Cfg::PCP, CHS = Cfg::CHS;
+    constexpr int NPIX = Cfg::NPIX, CPW = Cfg::CPW, NKP = Cfg::NKP, NTHR = Cfg::NTHR, NK_W = Cfg::NK_W;
+
+    __shared__ __attribute__((aligned(16))) float sIn[CC * CHS];
+    __shared__ __attribute__((aligned(16))) float sU[Cfg::U_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int k4 = lane >> 4, t = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wv & 1, tg = wv >> 1;          // 16-channel block / tile row of this wave
+
+    int tile = blockIdx.x;
+    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (tile % p.tiles_x) * TX;
+    const int ty0 = (tile / p.tiles_x) * TY;
+    const int nblk = blockIdx.y;
+    const int zi = blockIdx.z % p.nz;
+    const int n = blockIdx.z / p.nz;
+    const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
+    const int nchunks = p.CinPad / CC;
+    const int Ho = p.Ho, Wo = p.Wo;
+    const int64_t ybase = (int64_t)n * p.y_bstride + p.y_off + (int64_t)zi * p.y_zstride;
+    const int act = p.act;
+
+    // ---- staging roles: wave w gathers channels w*CPW .. of each chunk (NW = 8: one channel per wave) ----------
+    const int* __restrict__ tab = p.ch_off + (int64_t)zi * p.CinPad + (wv % CC) * CPW;
+    unsigned voff[NKP];
+    int loff[NKP];
+#pragma unroll
+    for (int k = 0; k < NKP; k++) {
+        const int pidx = lane + 64 * k;
+        const int pr = pidx / PC, pc = pidx - pr * PC;
+        const int iy = ty0 - p.pad_y + pr, ix = tx0 - p.pad_x + pc;
+        const bool own = pidx < NPIX;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.Wi + ix) * 4u : kBufOOB;
+        loff[k] = own ? ((wv % CC) * CPW) * CHS + pr * PCP + pc : -1;
+    }
+    const float* __restrict__ wsrc = p.w + ((int64_t)nblk * nchunks) * Cfg::U_ELEMS;
+    const buf_rsrc rs_w = make_buf(wsrc);
+
+    float rin[CPW][NKP];
+    f32x4 rw[NK_W];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < CPW; q++) {
+            const int off = tab[ch * CC + q];             // wave-uniform scalar load
+            const buf_rsrc rs = make_buf(xb, off >= 0);
+            const unsigned so = (unsigned)off * 4u;
+#pragma unroll
+            for (int k = 0; k < NKP; k++) rin[q][k] = buf_load(rs, voff[k], so);
+        }
+        const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) rw[k] = buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
+    };
+    auto stage_to_lds = [&]() {
+#pragma unroll
+        for (int q = 0; q < CPW; q++)
+#pragma unroll
+            for (int k = 0; k < NKP; k++)
+                if (loff[k] >= 0) sIn[loff[k] + q * CHS] = rin[q][k];
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) reinterpret_cast<f32x4*>(sU)[tid + NTHR * k] = rw[k];
+    };
+
+    // ---- output addressing + accumulator init (bias, residual) -------------------------------------------------
+    // lane (k4, t) ends up with channels cbase + i (i = 0..3) of tile t: outputs (2*tg + a, 2*t + b)
+    const int cs32 = (int)p.y_cstride;
+    const int cbase = nblk * 32 + cb * 16 + 4 * k4;       // + i
+    const bool tail4 = (p.Cout & 3) != 0;                 // only then does validity depend on i
+    unsigned yvoff[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t + b;
+            const bool ok = oy < Ho && ox < Wo && cbase < p.Cout;
+            yvoff[a][b] = ok ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u : kBufOOB;
+        }
+    // residual values are requested first (HBM latency overlaps the first gather) and consumed after prefetch(0)
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
+    float rr[4][2][2];
+    {
+        const buf_rsrc rs_r = make_buf(p.resid + ybase, p.resid != nullptr);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const unsigned vo = (tail4 && cbase + i >= p.Cout) ? kBufOOB : yvoff[a][b];
+                    rr[i][a][b] = buf_load(rs_r, vo, so);
+                }
+        }
+    }
+    f32x4 acc[16];
+
+    // ---- one chunk: 2 k-steps x (input transform of this lane's tile + 16 MFMAs) --------------------------------
+    const float* dbase = sIn + k4 * CHS + (2 * tg) * PCP + 2 * t;
+    const f32x4* ubase = reinterpret_cast<const f32x4*>(sU) + (k4 * 4) * 32 + cb * 16 + t;
+    auto compute = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float* dp = dbase + (4 * j) * CHS;
+            f32x2 d[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                d[r][0] = *reinterpret_cast<const f32x2*>(dp + r * PCP);
+                d[r][1] = *reinterpret_cast<const f32x2*>(dp + r * PCP + 2);
+            }
+            f32x4 a4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) a4[q] = ubase[(j * 16 + q) * 32];
+            // rows: w = B^T d  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), two columns at a time
+            f32x2 w[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                w[0][h] = d[0][h] - d[2][h];
+                w[1][h] = d[1][h] + d[2][h];
+                w[2][h] = d[2][h] - d[1][h];
+                w[3][h] = d[1][h] - d[3][h];
+            }
+            // columns: V = w B
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float x0 = w[r][0][0], x1 = w[r][0][1], x2 = w[r][1][0], x3 = w[r][1][1];
+                v[4 * r + 0] = x0 - x2;
+                v[4 * r + 1] = x1 + x2;
+                v[4 * r + 2] = x2 - x1;
+                v[4 * r + 3] = x1 - x3;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q >> 2][q & 3], v[q], acc[q], 0, 0, 0);
+        }
+    };
+
+    prefetch(0);
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        acc[0][i] = rr[i][0][0] + bv[i];
+        acc[3][i] = -(rr[i][0][1] + bv[i]);
+        acc[12][i] = -(rr[i][1][0] + bv[i]);
+        acc[15][i] = rr[i][1][1] + bv[i];
+    }
+    for (int ch = 0; ch < nchunks; ch++) {
+        if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
+        stage_to_lds();
+        __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+        compute();
+    }
+
+    // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
+    const buf_rsrc rs_y = make_buf(p.y + ybase);
+    auto epilogue = [&](auto ACT) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                t0[c] = acc[c][i] + acc[4 + c][i] + acc[8 + c][i];
+                t1[c] = acc[4 + c][i] - acc[8 + c][i] - acc[12 + c][i];
+            }
+            float y[2][2];
+            y[0][0] = t0[0] + t0[1] + t0[2];
+            y[0][1] = t0[1] - t0[2] - t0[3];
+            y[1][0] = t1[0] + t1[1] + t1[2];
+            y[1][1] = t1[1] - t1[2] - t1[3];
+            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const unsigned vo = (tail4 && cbase + i >= p.Cout) ? kBufOOB : yvoff[a][b];
+                    buf_store(apply_act_fast(y[a][b], decltype(ACT)::value), rs_y, vo, so);
+                }
+        }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+}  // namespace rt

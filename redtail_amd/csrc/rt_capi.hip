@@ -14,6 +14,7 @@
 #include "../../include/rt_stereo.h"
 #include "kernels/common.hip.h"
 #include "kernels/conv_mfma.hip.h"
+#include "kernels/conv_wino.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -348,6 +349,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int* choff_dev = nullptr;
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
+    int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
 };
 
 }  // namespace
@@ -397,6 +399,29 @@ int64_t pack_into(std::vector<float>& packed, const SubConv& sc, int cin_real, F
                 for (int u = 0; u < sc.KH; u++)
                     for (int v = 0; v < sc.KW; v++)
                         packed[base + ((size_t)co * cin_real + ci) * taps + u * sc.KW + v] = wfun(co, ci, u, v);
+        return base;
+    }
+    if (sc.wino) {
+        // U = G g G^T per (co, ci), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; slab order of conv_wino_f32_kernel:
+        // [nblk of 32 co][chunk of 8 ci][k-step j][k4][p/4][co % 32][p % 4],  ci = chunk*8 + 4*j + k4, p = 4*pr + pc
+        static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+        const int nblk = (int)rt::cdiv(sc.Cout, 32), nch = sc.CinPad / 8;
+        packed.resize(base + (size_t)nblk * nch * 4096, 0.f);
+        for (int co = 0; co < sc.Cout; co++)
+            for (int ci = 0; ci < cin_real; ci++) {
+                double g[3][3], tmp[4][3];
+                for (int u = 0; u < 3; u++)
+                    for (int v = 0; v < 3; v++) g[u][v] = wfun(co, ci, u, v);
+                for (int a = 0; a < 4; a++)
+                    for (int v = 0; v < 3; v++) tmp[a][v] = G[a][0] * g[0][v] + G[a][1] * g[1][v] + G[a][2] * g[2][v];
+                const int nb = co / 32, cc = co % 32, ch = ci / 8, j = (ci % 8) / 4, k4 = ci % 4;
+                for (int pr = 0; pr < 4; pr++)
+                    for (int pc = 0; pc < 4; pc++) {
+                        const double u = tmp[pr][0] * G[pc][0] + tmp[pr][1] * G[pc][1] + tmp[pr][2] * G[pc][2];
+                        const int pp = 4 * pr + pc;
+                        packed[base + ((size_t)nb * nch + ch) * 4096 + ((((size_t)j * 4 + k4) * 4 + pp / 4) * 32 + cc) * 4 + pp % 4] = (float)u;
+                    }
+            }
         return base;
     }
     const int NB = 32 * sc.NBW, cpg = sc.CC / 2;
@@ -495,7 +520,7 @@ void check_direct(SubConv& sc, int cin_real) {
     if (!win || (int64_t)sc.Cout * cin_real * sc.KH * sc.KW > 4096) sc.direct = 0;
 }
 
-void choose_tiling(SubConv& sc) {
+void choose_tiling(SubConv& sc, bool allow_wino = true) {
     sc.direct = (sc.Cout <= 2 && env_int("RT_CONV_NO_DIRECT", 0) == 0) ? 1 : 0;    // re-checked against the LDS weight cache below
     sc.CC = 8;
     // one 32-channel block per workgroup (NBW = 1): the 64-channel block halves the patch staging per FLOP but
@@ -506,6 +531,9 @@ void choose_tiling(SubConv& sc) {
     if (sc.KH == 5) sc.CC = 4;
     const int forced = env_int("RT_CONV_VARIANT", -1);
     set_tile(sc, forced >= 0 ? forced : 6);
+    // Winograd F(2x2,3x3) for the stride-1 3x3 windows with at least one full pair of 16-channel blocks
+    sc.wino = (allow_wino && !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.Cout >= 24 && env_int("RT_CONV_NO_WINO", 0) == 0) ? 1 : 0;
+    if (sc.wino) { sc.CC = 8; sc.NBW = 1; sc.TY = env_int("RT_WINO_WAVES", 4); sc.TXW = 1; sc.NW = sc.TY; }
     const int nbw = env_int("RT_CONV_NBW", 0);
     if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
 }
@@ -651,7 +679,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     for (int py = 0; py < s; py++)
         for (int px = 0; px < s; px++)
             if (py < Ho && px < Wo) sc.nz++;
-    choose_tiling(sc);
+    choose_tiling(sc, false);      // phase launches carry ZSlice tables
     sc.cin_real = Cin;
     check_direct(sc, Cin);
     sc.CinPad = sc.direct ? Cin : rt::round_up(Cin, sc.CC);
@@ -811,7 +839,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             for (int px = 0; px < sh; px++)
                 if (py < Hx && px < Wx) nph++;
         sc.nz = nzd * nph;
-        choose_tiling(sc);
+        choose_tiling(sc, false);      // phase launches carry ZSlice tables
         const int cin_real = nv * K;
         sc.cin_real = cin_real;
         check_direct(sc, cin_real);
@@ -923,6 +951,13 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.wino) {
+            RT_REQUIRE(!sc.zs_dev, "rt_conv_enqueue: Winograd kernel takes uniform slices only");
+            if (sc.NW == 8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
+            else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
+            RT_LAUNCH_CHECK("conv_wino_f32_kernel");
+            continue;
+        }
         if (int rc = launch_sub(sc, a, grid, S(s))) return rc;
     }
     return 0;
