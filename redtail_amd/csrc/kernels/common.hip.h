@@ -59,6 +59,15 @@ __device__ static __forceinline__ float buf_load(buf_rsrc r, unsigned voff, unsi
 __device__ static __forceinline__ f32x4 buf_load4(buf_rsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// 8-byte forms: the address only has to be 4-byte aligned (odd image widths)
+__device__ static __forceinline__ f32x2_t buf_load2(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ static __forceinline__ void buf_store2(f32x2_t v, buf_rsrc r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
+}
 __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }

@@ -132,15 +132,18 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const int cs32 = (int)p.y_cstride;
     const int cbase = nblk * 32 + cb * 16 + 4 * k4;       // + i
     const bool tail4 = (p.Cout & 3) != 0;                 // only then does validity depend on i
-    unsigned yvoff[2][2];
+    // each lane owns output pixel pairs (2t, 2t+1) of rows 2*tg + a: one 8-byte access per pair; the pair that
+    // straddles the right image edge (odd widths) falls back to a 4-byte access behind a scalar branch
+    const bool edge_tile = tx0 + TX > Wo;                 // wave-uniform
+    unsigned yv2[2], yv1[2];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t + b;
-            const bool ok = oy < Ho && ox < Wo && cbase < p.Cout;
-            yvoff[a][b] = ok ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u : kBufOOB;
-        }
+    for (int a = 0; a < 2; a++) {
+        const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t;
+        const bool row_ok = oy < Ho && cbase < p.Cout;
+        const unsigned off = (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u;
+        yv2[a] = (row_ok && ox + 1 < Wo) ? off : kBufOOB;
+        yv1[a] = (row_ok && ox + 1 == Wo) ? off : kBufOOB;
+    }
     // residual values are requested first (HBM latency overlaps the first gather) and consumed after prefetch(0)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
     float rr[4][2][2];
@@ -149,13 +152,22 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+            const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+            for (int a = 0; a < 2; a++) {
+                const f32x2 v = buf_load2(rs_r, dead ? kBufOOB : yv2[a], so);
+                rr[i][a][0] = v[0];
+                rr[i][a][1] = v[1];
+            }
+        }
+        if (edge_tile) {
 #pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const unsigned vo = (tail4 && cbase + i >= p.Cout) ? kBufOOB : yvoff[a][b];
-                    rr[i][a][b] = buf_load(rs_r, vo, so);
-                }
+            for (int i = 0; i < 4; i++) {
+                const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+                const bool dead = tail4 && cbase + i >= p.Cout;
+#pragma unroll
+                for (int a = 0; a < 2; a++) rr[i][a][0] += buf_load(rs_r, dead ? kBufOOB : yv1[a], so);
+            }
         }
     }
     f32x4 acc[16];
@@ -236,13 +248,13 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             y[1][0] = t1[0] + t1[1] + t1[2];
             y[1][1] = t1[1] - t1[2] - t1[3];
             const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+            const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const unsigned vo = (tail4 && cbase + i >= p.Cout) ? kBufOOB : yvoff[a][b];
-                    buf_store(apply_act_fast(y[a][b], decltype(ACT)::value), rs_y, vo, so);
-                }
+            for (int a = 0; a < 2; a++) {
+                const f32x2 o = {apply_act_fast(y[a][0], decltype(ACT)::value), apply_act_fast(y[a][1], decltype(ACT)::value)};
+                buf_store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
+                if (edge_tile) buf_store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
+            }
         }
     };
     if (act == 1) epilogue(std::integral_constant<int, 1>{});

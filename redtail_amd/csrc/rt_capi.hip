@@ -952,7 +952,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (sc.wino) {
-            RT_REQUIRE(!sc.zs_dev, "rt_conv_enqueue: Winograd kernel takes uniform slices only");
+            RT_REQUIRE(!sc.zs_dev && sc.y_xstride == 1, "rt_conv_enqueue: Winograd kernel takes uniform, x-contiguous slices only");
             if (sc.NW == 8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
             else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("conv_wino_f32_kernel");

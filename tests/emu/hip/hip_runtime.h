@@ -123,6 +123,23 @@ static inline u32x4 buffer_load_b128(const buffer_rsrc& r, unsigned voff, unsign
     if (buffer_ok(r, voff, soff, 16)) std::memcpy(&v, r.base + (size_t)voff + soff, 16);
     return v;
 }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// multi-dword accesses are range-checked per dword, like the hardware does for raw buffers
+static inline u32x2 buffer_load_b64(const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    u32x2 v = {0, 0};
+    for (int i = 0; i < 2; i++) {
+        unsigned w = 0;
+        if (buffer_ok(r, voff + 4 * i, soff, 4)) std::memcpy(&w, r.base + (size_t)voff + 4 * i + soff, 4);
+        v[i] = w;
+    }
+    return v;
+}
+static inline void buffer_store_b64(u32x2 v, const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    for (int i = 0; i < 2; i++) {
+        unsigned w = v[i];
+        if (buffer_ok(r, voff + 4 * i, soff, 4)) std::memcpy(r.base + (size_t)voff + 4 * i + soff, &w, 4);
+    }
+}
 static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned voff, unsigned soff) {
     if (buffer_ok(r, voff, soff, 4)) std::memcpy(r.base + (size_t)voff + soff, &v, 4);
 }
@@ -132,6 +149,8 @@ static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned v
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hipemu::buffer_load_b32(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu::buffer_load_b128(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, aux) hipemu::buffer_store_b32(d, r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hipemu::buffer_load_b64(r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b64(d, r, v, s, aux) hipemu::buffer_store_b64(d, r, v, s)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -128,6 +128,33 @@ def test_resnet18_2d_full_size(w, h, batch):
 
 
 @pytest.mark.gpu
+def test_resnet18_2d_interleaved_contexts():
+    """Four engines on four streams, pairs issued round-robin with no synchronisation in between (what bench.py
+    times): every context must reproduce the oracle for ITS pair, i.e. no buffers are shared between contexts."""
+    lib = netlib("gpu")
+    weights = O.synth_weights_resnet18_2d()
+    w, h, nctx = 513, 257, 4
+    nets = [lib.create("resnet18_2D", w, h, max_batch=1, weights=weights) for _ in range(nctx)]
+    streams = [torch.cuda.Stream() for _ in range(nctx)]
+    ins = [pairs(1, h, w, seed=100 + i) for i in range(nctx)]
+    dl = [torch.from_numpy(l).cuda() for l, _ in ins]
+    dr = [torch.from_numpy(r).cuda() for _, r in ins]
+    outs = [torch.full((1, 1, h, w), float("nan"), device="cuda") for _ in range(nctx)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(nctx):
+            nets[i].execute(dl[i], dr[i], outs[i], 1, stream=streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i in range(nctx):
+            ref = O.resnet18_2d(torch.from_numpy(ins[i][0]), torch.from_numpy(ins[i][1]), weights)
+            err = (outs[i].cpu() - ref).abs().max().item()
+            assert err <= 1e-3, (i, err)
+    for n in nets:
+        n.destroy()
+
+
+@pytest.mark.gpu
 def test_nvtiny_full_size():
     lib = netlib("gpu")
     path = os.path.join(REF_W, "NVTiny/TensorRT/trt_weights.bin")

@@ -1,0 +1,82 @@
+"""Parity of the Winograd F(2x2,3x3) MFMA kernel (conv_wino_f32_kernel) against the oracle and against the
+direct implicit-GEMM kernel on the same inputs: image edges that cut tiles and pixel pairs (odd widths),
+channel tails (Cout not a multiple of 4 / 16 / 32), several chunks and 32-channel blocks, batch > 1, and the
+(D*C)-merged Conv3DPlugin form (reference lib/conv3d_plugin.cpp:187-216).  RT_CONV_NO_WINO selects the path
+when the plan is created.  Runs on the SIMT emulator (CPU tier) and on the GPU (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import capi
+from test_ops_parity import T, near, rnd
+
+WINO_CASES = [
+    # cin, cout, h, w, act, resid, batch
+    (32, 32, 9, 33, capi.RT_ACT_ELU, True, 1),        # one pixel past a 32-wide tile
+    (32, 32, 5, 63, capi.RT_ACT_ELU, True, 2),        # odd width: last pixel pair straddles the edge
+    (8, 32, 3, 5, capi.RT_ACT_NONE, False, 1),        # image smaller than one tile
+    (33, 32, 7, 64, capi.RT_ACT_ELU, False, 1),       # padded input channels (5 chunks)
+    (16, 26, 6, 35, capi.RT_ACT_ELU, True, 1),        # Cout % 4 != 0: per-channel validity inside a lane
+    (24, 40, 8, 31, capi.RT_ACT_SIGMOID, False, 2),   # two 32-channel blocks, second half empty past 40
+    (64, 64, 10, 37, capi.RT_ACT_ELU, False, 1),
+    (128, 128, 4, 18, capi.RT_ACT_ELU, False, 1),
+]
+
+
+def run_conv(backend, monkeypatch, no_wino, x, wt, b, act, res, batch):
+    monkeypatch.setenv("RT_CONV_NO_WINO", "1" if no_wino else "0")
+    cout, cin = wt.shape[:2]
+    h, w = x.shape[2:]
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=res is not None)
+    y = backend.empty((batch, cout, h, w))
+    plan.enqueue(backend.dev(x), y, backend.dev(res) if res is not None else None, batch)
+    out = backend.host(y).copy()
+    plan.destroy()
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,resid,batch", WINO_CASES)
+def test_wino_conv2d(backend, monkeypatch, cin, cout, h, w, act, resid, batch):
+    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
+    res = rnd(batch, cout, h, w) if resid else None
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1)
+    if resid:
+        ref = ref + T(res)
+    ref = O.elu(ref) if act == capi.RT_ACT_ELU else (torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref)
+    y_w = run_conv(backend, monkeypatch, False, x, wt, b, act, res, batch)
+    y_d = run_conv(backend, monkeypatch, True, x, wt, b, act, res, batch)
+    near(y_w, ref.numpy(), 2e-5)
+    near(y_d, ref.numpy(), 2e-5)
+    near(y_w, y_d, 2e-5)
+
+
+def test_wino_large_values(backend, monkeypatch):
+    """The transforms add before they multiply: outputs of a few hundred keep a relative error of ~1e-6."""
+    x, wt, b = rnd(1, 32, 12, 40) * np.float32(30), rnd(32, 32, 3, 3), rnd(32)
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1).numpy()
+    y = run_conv(backend, monkeypatch, False, x, wt, b, capi.RT_ACT_NONE, None, 1)
+    assert np.abs(ref).max() > 300
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("out_dchw", [False, True])
+def test_wino_conv3d(backend, monkeypatch, out_dchw):
+    """3x3x3 stride-1 Conv3D with K = 32: depth taps ride the gather table, the 3x3 window is Winograd."""
+    n, d, c, h, w, k = 1, 5, 8, 9, 35, 32
+    x, wt, b = rnd(n, d, c, h, w), rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * c)), rnd(k)
+    ref = O.conv3d_tf(T(x), T(wt), T(b), (1, 1, 1), (1, 1, 1), (1, 1, 1))           # N K D H W
+    if out_dchw:
+        ref = O.transform(ref)
+    ref = O.elu(ref).numpy()
+    outs = []
+    for no_wino in (False, True):
+        monkeypatch.setenv("RT_CONV_NO_WINO", "1" if no_wino else "0")
+        plan = backend.klib.conv3d_plan(wt, b, c, k, (d, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1),
+                                        act=capi.RT_ACT_ELU, out_dchw=out_dchw)
+        y = backend.empty((n,) + plan.out_dims)
+        plan.enqueue(backend.dev(x), y, None, n)
+        outs.append(backend.host(y).copy())
+        plan.destroy()
+    near(outs[0], ref, 2e-5)
+    near(outs[1], ref, 2e-5)

@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-DOMINANT = "conv_mfma_f32_kernel<3, 3, 1, 4, 1, 1, 8, 4, true>"
+DOMINANT = "conv_wino_f32_kernel<4>"
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
 # with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
 # 14546 KiB read, 14575 for 29091); WRITE_SIZE is exact (14545.6 KB for 14545.6 KiB written).
