@@ -91,6 +91,7 @@ constexpr bool kAblBarrier = (RT_ABLATE & 8) != 0;   // no workgroup barriers
 constexpr bool kAblResid = (RT_ABLATE & 16) != 0;    // no residual loads
 constexpr bool kAblStore = (RT_ABLATE & 32) != 0;    // no output stores
 constexpr bool kAblLdsRd = (RT_ABLATE & 64) != 0;    // MFMA operands from registers instead of LDS
+constexpr bool kAblXform = (RT_ABLATE & 128) != 0;   // Winograd kernel: no input transform
 __device__ __forceinline__ void wg_barrier() { if (!kAblBarrier) __syncthreads(); }
 
 template <int N> struct VecOf;

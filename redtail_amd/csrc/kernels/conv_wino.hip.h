@@ -111,11 +111,11 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             const buf_rsrc rs = make_buf(xb, off >= 0);
             const unsigned so = (unsigned)off * 4u;
 #pragma unroll
-            for (int k = 0; k < NKP; k++) rin[q][k] = buf_load(rs, voff[k], so);
+            for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : buf_load(rs, voff[k], so);
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
 #pragma unroll
-        for (int k = 0; k < NK_W; k++) rw[k] = buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
+        for (int k = 0; k < NK_W; k++) rw[k] = kAblWLoad ? f32x4{(float)tid, 1.f, 2.f, (float)ch} : buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
     };
     auto stage_to_lds = [&]() {
 #pragma unroll
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const f32x2 v = buf_load2(rs_r, dead ? kBufOOB : yv2[a], so);
+                const f32x2 v = kAblResid ? f32x2{(float)i, (float)a} : buf_load2(rs_r, dead ? kBufOOB : yv2[a], so);
                 rr[i][a][0] = v[0];
                 rr[i][a][1] = v[1];
             }
@@ -197,15 +197,19 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
                 w[2][h] = d[2][h] - d[1][h];
                 w[3][h] = d[1][h] - d[3][h];
             }
-            // columns: V = w B
+            // columns: V = w B, two outputs per packed add:  (v0, v1) = (x0, x1) + (-x2, x2),
+            //                                                  (v2, v3) = (x2, -x3) + (-x1, x1)
             float v[16];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float x0 = w[r][0][0], x1 = w[r][0][1], x2 = w[r][1][0], x3 = w[r][1][1];
-                v[4 * r + 0] = x0 - x2;
-                v[4 * r + 1] = x1 + x2;
-                v[4 * r + 2] = x2 - x1;
-                v[4 * r + 3] = x1 - x3;
+                const f32x2 lo = kAblXform ? d[r][0] : w[r][0], hi = kAblXform ? d[r][1] : w[r][1];
+                if (kAblXform) { v[4 * r] = lo[0]; v[4 * r + 1] = lo[1]; v[4 * r + 2] = hi[0]; v[4 * r + 3] = hi[1]; continue; }
+                const f32x2 v01 = lo + f32x2{-hi[0], hi[0]};
+                const f32x2 v23 = f32x2{hi[0], -hi[1]} + f32x2{-lo[1], lo[1]};
+                v[4 * r + 0] = v01[0];
+                v[4 * r + 1] = v01[1];
+                v[4 * r + 2] = v23[0];
+                v[4 * r + 3] = v23[1];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++)
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const f32x2 o = {apply_act_fast(y[a][0], decltype(ACT)::value), apply_act_fast(y[a][1], decltype(ACT)::value)};
-                buf_store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
+                if (!kAblStore || o[0] == 12345.678f) buf_store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
                 if (edge_tile) buf_store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
             }
         }

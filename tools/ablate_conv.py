@@ -9,9 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from redtail_amd import build, capi  # noqa: E402
 
-VARIANTS = [(0, "full kernel"), (1, "no input gathers"), (2, "no weight loads"), (3, "no global loads in the loop"),
-            (4, "no LDS writes"), (8, "no barriers"), (16, "no residual loads"), (32, "no stores"), (48, "no resid, no stores"),
-            (64, "no LDS reads"), (12, "no LDS writes, no barriers"), (127, "MFMA + epilogue math only")]
+VARIANTS = [(0, "full kernel"), (1, "no input gathers"), (2, "no weight loads"), (16, "no residual loads"), (32, "no stores"),
+            (51, "no global memory traffic"), (128, "no input transform (Winograd)"), (179, "no memory, no transform")]
 
 
 def main():

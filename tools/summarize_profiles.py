@@ -18,6 +18,7 @@ import shutil
 import sys
 
 DOMINANT = "conv_wino_f32_kernel<4>"
+DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (the kernel also runs the low-resolution layers)
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
 # with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
 # 14546 KiB read, 14575 for 29091); WRITE_SIZE is exact (14545.6 KB for 14545.6 KiB written).
@@ -44,7 +45,10 @@ def main():
         f = os.path.join(run, d, "p_counter_collection.csv")
         if d.startswith("pmc_") and os.path.exists(f):
             for r in csv.DictReader(open(f)):
-                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                name = short(r["Kernel_Name"])
+                if name == DOMINANT and int(r["Grid_Size"]) != DOMINANT_GRID:
+                    name += " (other layers)"
+                acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for k in acc.values() for c in k})
     with open(os.path.join(out, tag + "_pmc.csv"), "w", newline="") as f:
         w = csv.writer(f)
@@ -59,7 +63,8 @@ def main():
 
     # ---- durations of the dominant kernel from the trace ----------------------------------------------
     rows = list(csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))))
-    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if short(r["Kernel_Name"]) == DOMINANT]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows
+            if short(r["Kernel_Name"]) == DOMINANT and int(r["Grid_Size_X"]) == DOMINANT_GRID]
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
     t1 = max(int(r["End_Timestamp"]) for r in rows)
     traffic = dict(kernel=DOMINANT, launches_counted=len(dom["FETCH_SIZE"]),
