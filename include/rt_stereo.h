@@ -98,6 +98,11 @@ int rt_softargmax(const void* vol, void* out, int batch, int D, int H, int W, in
  * (sample_app/resnet18_2D_513x257_net.cpp:601-615). */
 int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,
                        int max_disp, int is_min, int64_t out_batch_stride, int dtype, rtStream stream);
+/* Same with row pitches (elements, 0 = dense) for the feature maps and for the output plane; see
+ * rt_conv_plan_set_pitch. */
+int rt_corr_softargmax_pitched(const void* left, const void* right, void* out, int batch, int C, int H, int W,
+                               int max_disp, int is_min, int in_pitch, int out_pitch, int64_t out_batch_stride,
+                               int dtype, rtStream stream);
 
 /* ---- layout glue of the 3-D models ------------------------------------------------------- */
 /* 4-D permute of a (N, d0,d1,d2,d3) tensor: out dim i = in dim order[i].  Replaces
@@ -141,6 +146,11 @@ int rt_conv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const voi
  * (scripts/tensorrt_model_builder.py:230-288).  Hout = (Hin-1)*stride - 2*pad + KH. */
 int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const void* weights_host,
                             const void* bias_host);
+
+/* Row pitch (in elements, >= the row length; 0 = dense) of the input and of the output/residual planes of a 2-D
+ * plan.  Not in the reference (TensorRT owns its internal layouts): lets the executor keep internal activations
+ * 128-byte aligned per row.  Tensors are then (N, C, H, pitch) in memory with W valid columns. */
+int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
 
 typedef struct rtConv3dDesc {
     int C, K;               /* conv: input channels C, output channels K.  Transposed op: K = INPUT   */

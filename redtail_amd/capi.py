@@ -59,6 +59,7 @@ KERNEL_SYMBOLS = {
     "rt_cost_volume": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rt_softargmax": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rt_corr_softargmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int64, c_int, c_void_p]),
+    "rt_corr_softargmax_pitched": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
     "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_slice_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -69,6 +70,7 @@ KERNEL_SYMBOLS = {
     "rt_conv3d_transpose_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), POINTER(c_int), c_void_p,
                                                 c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
+    "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_plan_destroy": (c_int, [c_void_p]),
 }
@@ -125,6 +127,12 @@ class KernelLib:
     def corr_cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, fmt=RT_NCHW, stream=None):
         self.check(self.lib.rt_corr_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, stream),
                    "rt_corr_cost_volume")
+
+    def corr_softargmax_pitched(self, l, r, out, batch, C, H, W, D, is_min, in_pitch, out_pitch, out_bstride=0,
+                                dtype=RT_F32, stream=None):
+        self.check(self.lib.rt_corr_softargmax_pitched(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min),
+                                                       in_pitch, out_pitch, out_bstride, dtype, stream),
+                   "rt_corr_softargmax_pitched")
 
     def cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, stream=None):
         self.check(self.lib.rt_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, stream),
@@ -183,6 +191,9 @@ class ConvPlan:
         dims = (c_int * 4)()
         klib.check(klib.lib.rt_conv_plan_out_dims(handle, dims), "rt_conv_plan_out_dims")
         self.out_dims = tuple(dims)
+
+    def set_pitch(self, in_pitch, out_pitch):
+        self.klib.check(self.klib.lib.rt_conv_plan_set_pitch(self.handle, in_pitch, out_pitch), "rt_conv_plan_set_pitch")
 
     def enqueue(self, x, y, residual=None, batch=1, stream=None):
         self.klib.check(self.klib.lib.rt_conv_enqueue(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream),

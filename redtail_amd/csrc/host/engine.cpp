@@ -57,6 +57,7 @@ struct TensorImpl : public ITensor {
     int64_t bstride = 0;        // per-sample stride in elements (0 = dense volume)
     void* dev = nullptr;
     int stream = 0;             // which of the two execution streams produces it
+    int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
 
     void setName(const char* n) override { name = n ? n : ""; }
     const char* getName() const override { return name.c_str(); }
@@ -414,6 +415,7 @@ private:
     static bool isKind(LayerData* l, Kind k) { auto* s = stereo(l); return s && s->kind() == k; }
     bool lower();
     void assignStreams();
+    void assignPitch();
     bool ok_ = false;
     bool half2_ = false;
 };
@@ -451,6 +453,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
         workspace_bytes_ = std::max(workspace_bytes_, l->plugin->getWorkspaceSize(max_batch_));
     }
     ok_ = lower();
+    if (ok_) assignPitch();
     if (ok_) assignStreams();
 }
 
@@ -662,6 +665,63 @@ bool EngineImpl::lower() {
 
 // Two-stream schedule: everything that depends only on the SECOND network input runs on the side
 // stream (the right-image encoder); ops that mix both wait on events.
+// Internal activations that only pitch-aware launches touch (2-D convolution plans, the fused correlation, channel
+// concatenation) get a row pitch of a multiple of 32 floats: W is odd in every Stereo DNN network, so dense rows
+// start at arbitrary 4-byte offsets and every 128-byte access of a tile straddles two cache lines (measured
+// +6 % on the 3x3 layers with aligned rows).  Bindings and everything a generic plugin launch sees stay dense,
+// as TensorRT's plugin contract requires.
+void EngineImpl::assignPitch() {
+    if (getenv("RT_NO_PITCH")) return;
+    std::vector<char> ok(tensors_.size(), 1);
+    for (auto& t : tensors_) {
+        if (t->is_input || t->is_output || t->alias_of >= 0 || t->dims.nbDims != 3 || t->bstride != 0) ok[t->id] = 0;
+        if (t->alias_of >= 0) ok[root(t->id)] = 0;         // shared buffers stay dense
+    }
+    auto clear = [&](int t) { if (t >= 0) ok[root(t)] = 0; };
+    auto P = [&](int t) { return t >= 0 && ok[root(t)] != 0; };
+    for (auto& op : ops_) {
+        const bool aware = op.kind == OpKind::kConv || op.kind == OpKind::kCorrSoftargmax || op.kind == OpKind::kConcat;
+        if (aware) continue;
+        for (int i : op.in) clear(i);
+        clear(op.out);
+        clear(op.resid);
+    }
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (auto& op : ops_) {
+            if (op.kind == OpKind::kConv && op.resid >= 0 && P(op.resid) != P(op.out)) {
+                clear(op.resid); clear(op.out); changed = true;
+            }
+            if (op.kind == OpKind::kCorrSoftargmax && P(op.in[0]) != P(op.in[1])) {
+                clear(op.in[0]); clear(op.in[1]); changed = true;
+            }
+            if (op.kind == OpKind::kConcat) {
+                bool all = P(op.out), any = P(op.out);
+                for (int i : op.in) { all = all && P(i); any = any || P(i); }
+                if (any && !all) {
+                    clear(op.out);
+                    for (int i : op.in) clear(i);
+                    changed = true;
+                }
+            }
+        }
+    }
+    for (auto& t : tensors_) {
+        if (!ok[t->id]) continue;
+        const int w = t->dims.d[2], pitch = (w + 31) / 32 * 32;
+        t->pitch = pitch == w ? 0 : pitch;
+    }
+    for (auto& op : ops_) {
+        if (op.kind != OpKind::kConv) continue;
+        const int ip = tensors_[root(op.in[0])]->pitch, opi = tensors_[root(op.out)]->pitch;
+        if ((ip || opi) && rt_conv_plan_set_pitch(op.plan, ip, opi) != 0) {
+            log_.log(ILogger::Severity::kERROR, (op.name + ": " + rt_last_error_string()).c_str());
+            ok_ = false;
+            return;
+        }
+    }
+}
+
 void EngineImpl::assignStreams() {
     if (getenv("RT_SINGLE_STREAM")) return;
     int n_inputs = 0;
@@ -762,7 +822,8 @@ bool ContextImpl::ensureBuffers(int batch) {
             for (int i : op.in) used |= i == t->id;
         }
         if (!used) continue;
-        if (rt_malloc(&buffers_[t->id], volume(t->dims) * sizeof(float) * (size_t)batch) != 0) {
+        const size_t elems = t->pitch ? (size_t)t->dims.d[0] * t->dims.d[1] * t->pitch : (size_t)volume(t->dims);
+        if (rt_malloc(&buffers_[t->id], elems * sizeof(float) * (size_t)batch) != 0) {
             eng_.log_.log(ILogger::Severity::kERROR, (std::string("engine: device allocation failed: ") + rt_last_error_string()).c_str());
             return false;
         }
@@ -861,7 +922,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 break;
             case OpKind::kConcat: {
                 const int ctot = out.dims.d[0];
-                const int64_t inner = (int64_t)volume(out.dims) / ctot;
+                const int64_t inner = out.pitch ? (int64_t)out.dims.d[1] * out.pitch : (int64_t)volume(out.dims) / ctot;
                 int coff = 0;
                 for (int i : op.in) {
                     const Dims& d = eng_.tensors_[i]->dims;
@@ -873,8 +934,9 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             }
             case OpKind::kCorrSoftargmax: {
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
-                rc = rt_corr_softargmax(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
-                                        f.d[2], op.max_disp, op.is_min, 0, RT_F32, st);
+                rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
+                                                f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
+                                                0, RT_F32, st);
                 break;
             }
             case OpKind::kCopy:

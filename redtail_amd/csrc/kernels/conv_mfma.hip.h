@@ -56,7 +56,8 @@ struct ConvArgs {
     const int* ch_off;     // [nz][CinPad] plane offsets (elements) relative to the sample base, -1 = zeros
     int CinPad;            // multiple of CC
     int Cout;
-    int Hi, Wi;            // input plane (row pitch = Wi)
+    int Hi, Wi;            // input plane
+    int x_pitch;           // input row pitch in elements (>= Wi; internal tensors may be padded to 128 B)
     int Ho, Wo;            // output grid of this launch
     int pad_y, pad_x;
     int nz;                // z-slices per sample (3-D depth positions / 1 for 2-D)
@@ -186,7 +187,7 @@ conv_mfma_f32_kernel(ConvArgs p) {
         const int iy = ty0 * S - pad_y + pr;
         const int ix = tx0 * S - pad_x + pc;
         const bool own = pidx < NPIX;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.Wi + ix) * 4u : kBufOOB;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB;
         lidx[k] = own ? (pr * 2 + sh) * PC + pc : -1;
     }
 
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(256) conv_direct_f32_kernel(ConvArgs p, int S,
 #pragma unroll
         for (int v = 0; v < KW; v++) {
             const int iy = oy * S + u - pad_y, ix = ox * S + v - pad_x;
-            poff[u * KW + v] = (ox < Wo && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
+            poff[u * KW + v] = (ox < Wo && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.x_pitch + ix : -1;
         }
     float acc[COUT];
 #pragma unroll

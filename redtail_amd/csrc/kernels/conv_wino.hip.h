@@ -33,7 +33,7 @@ namespace rt {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef RT_WINO_MINW
-#define RT_WINO_MINW 3
+#define RT_WINO_MINW 4
 #endif
 template <int NW>
 struct WinoCfg {
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 - p.pad_y + pr, ix = tx0 - p.pad_x + pc;
         const bool own = pidx < NPIX;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.Wi + ix) * 4u : kBufOOB;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB;
         loff[k] = own ? ((wv % CC) * CPW) * CHS + pr * PCP + pc : -1;
     }
     const float* __restrict__ wsrc = p.w + ((int64_t)nblk * nchunks) * Cfg::U_ELEMS;

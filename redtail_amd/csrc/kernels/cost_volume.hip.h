@@ -30,7 +30,7 @@ constexpr int kCorrRS = 32;     // 16-byte slots per (channel, parity, row) regi
 template <int DT, bool FUSED, bool ISMIN>
 __global__ void __launch_bounds__(256)
 corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out, int C,
-                int H, int W, int D, int d_base, int64_t out_bstride) {
+                int H, int W, int D, int d_base, int64_t out_bstride, int in_pitch, int out_pitch) {
     constexpr int RY = kCorrRY, TX = kCorrTX, CC = kCorrCC, RS = kCorrRS;
     constexpr int DPAD = 4 * DT;          // disparities covered by the 4 waves of this workgroup
     constexpr int RW = DPAD + TX;         // R tile row width (floats), starts at x0 - d_base - DPAD + 1 - 1
@@ -45,7 +45,7 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
     const int lane = tid & 63, dg = tid >> 6;
     const int r = lane >> 4, xg = lane & 15;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z;
-    const int64_t plane = (int64_t)H * W;
+    const int64_t plane = (int64_t)H * in_pitch;         // row pitch >= W (dense: == W)
     const float* __restrict__ lb = left + (int64_t)n * C * plane;
     const float* __restrict__ rb = right + (int64_t)n * C * plane;
 
@@ -71,14 +71,14 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
         const int idx = lane + 64 * k;
         const int rr = idx / RW, i = idx - rr * RW;
         const int gx = x0 - d_base - DPAD + i, gyy = y0 + rr;
-        roff[k] = (idx < RY * RW && gyy < H && gx >= 0 && gx < W) ? gyy * W + gx : -1;
+        roff[k] = (idx < RY * RW && gyy < H && gx >= 0 && gx < W) ? gyy * in_pitch + gx : -1;
     }
 #pragma unroll
     for (int k = 0; k < NKL; k++) {
         const int idx = lane + 64 * k;
         const int rr = idx / TX, i = idx - rr * TX;
         const int gx = x0 + i, gyy = y0 + rr;
-        loff[k] = (gyy < H && gx < W) ? gyy * W + gx : -1;
+        loff[k] = (gyy < H && gx < W) ? gyy * in_pitch + gx : -1;
     }
     float pr_[CPW][NKR], pl_[CPW][NKL];
     auto prefetch = [&](int c0) {
@@ -155,7 +155,7 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
             for (int q = 0; q < DT; q++) {
                 const int d = d_base + DT * dg + q;
                 if (d < D) {
-                    float* o = out + (int64_t)n * out_bstride + (int64_t)d * plane + (int64_t)gy * W + gx0;
+                    float* o = out + (int64_t)n * out_bstride + (int64_t)d * H * out_pitch + (int64_t)gy * out_pitch + gx0;
 #pragma unroll
                     for (int pq = 0; pq < 8; pq++)
                         if (gx0 + pq < W) o[pq] = acc[pq][q];
@@ -206,7 +206,7 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
                 ws += red[(2 * 4 + w4) * NPX + px] * sc;
             }
             const int yy = y0 + px / TX, xx = x0 + px % TX;
-            if (yy < H && xx < W) out[(int64_t)n * out_bstride + (int64_t)yy * W + xx] = ws / s;
+            if (yy < H && xx < W) out[(int64_t)n * out_bstride + (int64_t)yy * out_pitch + xx] = ws / s;
         }
     }
 }

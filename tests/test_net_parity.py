@@ -85,6 +85,17 @@ def test_resnet18_2d_unfused_equals_fused(rt, monkeypatch):
     assert np.abs(fused - unfused).max() <= 1e-5
 
 
+def test_resnet18_2d_pitched_equals_dense(rt, monkeypatch):
+    """internal activations with 128-byte aligned rows (default) vs dense rows (RT_NO_PITCH): same disparity"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 25, 41)
+    pitched, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    monkeypatch.setenv("RT_NO_PITCH", "1")
+    dense, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    assert not np.isnan(pitched).any()
+    assert np.array_equal(pitched, dense)
+
+
 def test_nvtiny_tiny(rt):
     """3-D path: default cost volume, Conv3D/Transform/Pad/ELU, Conv3DTranspose/Slice/add, softargmin"""
     w = O.synth_weights_3d(O.NVTINY_3D)
