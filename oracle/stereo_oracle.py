@@ -44,6 +44,28 @@ def corr_cost_volume(left, right, max_disp):
     return out
 
 
+def to_nc2hw2(x):
+    """(N,C,H,W) float -> TensorRT kNC2HW2 fp16 packing: (N, ceil(C/2), H, W, 2) float16, channel pair (2i, 2i+1)
+    of a pixel in one 4-byte slot, odd C zero padded (lib/kernels.cu:203-250 reads it as __half2 per channel pair)."""
+    n, c, h, w = x.shape
+    xp = torch.zeros((n, (c + 1) // 2 * 2, h, w), dtype=torch.float16)
+    xp[:, :c] = x.to(torch.float16)
+    return xp.reshape(n, (c + 1) // 2, 2, h, w).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_nc2hw2(x, c):
+    """inverse of to_nc2hw2: (N, ceil(C/2), H, W, 2) float16 -> (N, C, H, W) float32"""
+    n, c2, h, w, _ = x.shape
+    return x.permute(0, 1, 4, 2, 3).reshape(n, 2 * c2, h, w)[:, :c].to(torch.float32)
+
+
+def corr_cost_volume_fp16(left_h2, right_h2, c, max_disp):
+    """corrCostVolumeFP16NC2HW2Kernel (lib/kernels.cu:203-250): fp16 NC2HW2 in and out, fp32 arithmetic
+    (:219-221 'using FP32 arithmetic for better precision'), one rounding to half at the end (:247)."""
+    cv = corr_cost_volume(from_nc2hw2(left_h2, c), from_nc2hw2(right_h2, c), max_disp)
+    return to_nc2hw2(cv)
+
+
 def cost_volume(left, right, max_disp):
     """Default (concatenation) cost volume (lib/kernels.cu:50-97,136-161;
     test_data_generator.py:223-240).  (N,C,H,W) x2 -> (N, D, 2C, H, W):

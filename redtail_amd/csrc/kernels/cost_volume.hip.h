@@ -27,7 +27,20 @@ constexpr int kCorrTX = 128;    // pixels per tile row
 constexpr int kCorrCC = 8;      // channels per LDS stage
 constexpr int kCorrRS = 32;     // 16-byte slots per (channel, parity, row) region of the R tile
 
-template <int DT, bool FUSED, bool ISMIN>
+// H2 = fp16 tensors in TensorRT's NC2HW2 packing (reference corrCostVolumeFP16NC2HW2Kernel, lib/kernels.cu:203-250):
+// a 4-byte slot holds channels (2i, 2i+1) of one pixel -- on output disparities (2i, 2i+1) -- so the pointers keep
+// their 4-byte element type; arithmetic is fp32 as in the reference (:219-221), results are rounded once.
+__device__ static __forceinline__ float half_of_slot(float slot, int hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, slot);
+    const unsigned short h = (unsigned short)(hi ? (u >> 16) : (u & 0xffffu));
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ static __forceinline__ float pack_half2(float lo, float hi) {
+    const unsigned a = __builtin_bit_cast(unsigned short, (_Float16)lo), b = __builtin_bit_cast(unsigned short, (_Float16)hi);
+    return __builtin_bit_cast(float, a | (b << 16));
+}
+
+template <int DT, bool FUSED, bool ISMIN, bool H2 = false>
 __global__ void __launch_bounds__(256)
 corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out, int C,
                 int H, int W, int D, int d_base, int64_t out_bstride, int in_pitch, int out_pitch) {
@@ -46,8 +59,9 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
     const int r = lane >> 4, xg = lane & 15;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z;
     const int64_t plane = (int64_t)H * in_pitch;         // row pitch >= W (dense: == W)
-    const float* __restrict__ lb = left + (int64_t)n * C * plane;
-    const float* __restrict__ rb = right + (int64_t)n * C * plane;
+    const int cslots = H2 ? (C + 1) / 2 : C;              // planes per sample
+    const float* __restrict__ lb = left + (int64_t)n * cslots * plane;
+    const float* __restrict__ rb = right + (int64_t)n * cslots * plane;
 
     float acc[8][DT];
 #pragma unroll
@@ -86,18 +100,21 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
         for (int j = 0; j < CPW; j++) {
             const int c = c0 + wv * CPW + j;
             const bool cok = c < C;
-            const float* rp = rb + (int64_t)(cok ? c : 0) * plane;
-            const float* lp = lb + (int64_t)(cok ? c : 0) * plane;
+            const int cp = cok ? (H2 ? c >> 1 : c) : 0;
+            const float* rp = rb + (int64_t)cp * plane;
+            const float* lp = lb + (int64_t)cp * plane;
 #pragma unroll
             for (int k = 0; k < NKR; k++) {
                 const bool ok = cok & (roff[k] >= 0);
-                const float v = rp[ok ? roff[k] : 0];
+                float v = rp[ok ? roff[k] : 0];
+                if (H2) v = half_of_slot(v, c & 1);
                 pr_[j][k] = ok ? v : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < NKL; k++) {
                 const bool ok = cok & (loff[k] >= 0);
-                const float v = lp[ok ? loff[k] : 0];
+                float v = lp[ok ? loff[k] : 0];
+                if (H2) v = half_of_slot(v, c & 1);
                 pl_[j][k] = ok ? v : 0.f;
             }
         }
@@ -152,13 +169,13 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
         // cv[n][d][y][x]; x < d comes out as 0 because the R tile is zero-filled left of column 0.
         if (gy < H) {
 #pragma unroll
-            for (int q = 0; q < DT; q++) {
+            for (int q = 0; q < DT; q += H2 ? 2 : 1) {
                 const int d = d_base + DT * dg + q;
                 if (d < D) {
-                    float* o = out + (int64_t)n * out_bstride + (int64_t)d * H * out_pitch + (int64_t)gy * out_pitch + gx0;
+                    float* o = out + (int64_t)n * out_bstride + (int64_t)(H2 ? d >> 1 : d) * H * out_pitch + (int64_t)gy * out_pitch + gx0;
 #pragma unroll
                     for (int pq = 0; pq < 8; pq++)
-                        if (gx0 + pq < W) o[pq] = acc[pq][q];
+                        if (gx0 + pq < W) o[pq] = H2 ? pack_half2(acc[pq][q], acc[pq][q + 1 < DT ? q + 1 : q]) : acc[pq][q];
                 }
             }
         }

@@ -206,7 +206,7 @@ extern "C" int rt_activation(const void* x, void* y, int64_t n, int act, int dty
 // cost volumes / soft-argmax
 // =================================================================================================
 namespace {
-template <bool FUSED, bool ISMIN>
+template <bool FUSED, bool ISMIN, bool H2 = false>
 int launch_corr(const float* l, const float* r, float* out, int batch, int C, int H, int W, int D, int64_t obs,
                 hipStream_t st, int in_pitch = 0, int out_pitch = 0) {
     const int ip = in_pitch ? in_pitch : W, op = out_pitch ? out_pitch : W;
@@ -215,10 +215,10 @@ int launch_corr(const float* l, const float* r, float* out, int batch, int C, in
     dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)batch);
     for (int d_base = 0; d_base < D; d_base += 4 * dt) {
         switch (dt) {
-            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
         }
         RT_LAUNCH_CHECK("corr cost volume kernel");
     }
@@ -230,8 +230,12 @@ extern "C" int rt_corr_cost_volume(const void* left, const void* right, void* cv
                                    int D, int dtype, int format, rtStream s) {
     RT_REQUIRE(left && right && cv, "rt_corr_cost_volume: null pointer");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_cost_volume: bad dims");
+    // the two combinations the reference plugin accepts (lib/cost_volume_plugin.cpp:60-66): fp32 NCHW, fp16 NC2HW2
+    if (dtype == RT_F16 && format == RT_NC2HW2)
+        return launch_corr<false, false, true>(static_cast<const float*>(left), static_cast<const float*>(right),
+                                               static_cast<float*>(cv), batch, C, H, W, D, (int64_t)((D + 1) / 2) * H * W, S(s));
     if (dtype != RT_F32 || format != RT_NCHW)
-        return fail(RT_E_UNSUPPORTED, "rt_corr_cost_volume: only fp32 NCHW in this build (dtype %d format %d)", dtype, format);
+        return fail(RT_E_UNSUPPORTED, "rt_corr_cost_volume: fp32 NCHW or fp16 NC2HW2 (dtype %d format %d)", dtype, format);
     return launch_corr<false, false>(static_cast<const float*>(left), static_cast<const float*>(right),
                                      static_cast<float*>(cv), batch, C, H, W, D, (int64_t)D * H * W, S(s));
 }

@@ -97,6 +97,35 @@ def test_corr_softargmax_fused(backend, shape, D, is_min):
     near(backend.host(out), ref, 2e-4)
 
 
+def run_corr_fp16(backend, l, r, D):
+    """fp16 NC2HW2 tensors travel as 4-byte slots (numpy float32 views of the float16 pairs)"""
+    n, c, h, w = l.shape
+    lh, rh = O.to_nc2hw2(T(l)), O.to_nc2hw2(T(r))
+    as_slots = lambda t: np.ascontiguousarray(t.numpy()).view(np.float32).reshape(t.shape[:-1])
+    cv = backend.empty((n, (D + 1) // 2, h, w))
+    backend.klib.corr_cost_volume(backend.dev(as_slots(lh)), backend.dev(as_slots(rh)), cv, n, c, h, w, D,
+                                  dtype=capi.RT_F16, fmt=capi.RT_NC2HW2)
+    out = torch.from_numpy(np.ascontiguousarray(backend.host(cv)).view(np.float16).reshape(n, (D + 1) // 2, h, w, 2))
+    return O.from_nc2hw2(out, D).numpy(), O.from_nc2hw2(O.corr_cost_volume_fp16(lh, rh, c, D), D).numpy()
+
+
+def test_corr_golden_fp16_nc2hw2(backend, golden):                 # tests_main.cpp:988-1026, tolerance 0.01
+    cv = golden["corr_cost_vol_01_cv"]
+    got, ref16 = run_corr_fp16(backend, golden["corr_cost_vol_01_l"], golden["corr_cost_vol_01_r"], cv.shape[1])
+    near(got, cv.reshape(got.shape), 1e-2)
+    near(got, ref16, 2e-3)                                         # one half ulp at |x| < 4 is 2e-3
+
+
+@pytest.mark.parametrize("shape,D", [((2, 5, 7, 45), 7), ((1, 32, 9, 133), 48)])
+def test_corr_random_fp16_nc2hw2(backend, shape, D):
+    """odd channel and disparity counts (zero padded half of the last slot), several tiles"""
+    l, r = rnd(*shape) * np.float32(0.5), rnd(*shape) * np.float32(0.5)
+    got, ref16 = run_corr_fp16(backend, l, r, D)
+    scale = max(1.0, float(np.abs(ref16).max()))
+    near(got, ref16, 1e-3 * scale)
+    near(got, O.corr_cost_volume(T(l), T(r), D).numpy(), 1e-2 * scale)
+
+
 def test_corr_softargmax_into_concat_buffer(backend):
     """out_batch_stride places the result in channel 32 of a 33-channel buffer (resnet18_2D net :601-615)"""
     n, c, h, w, D = 2, 8, 6, 40, 12
