@@ -708,7 +708,8 @@ void EngineImpl::assignPitch() {
     }
     for (auto& t : tensors_) {
         if (!ok[t->id]) continue;
-        const int w = t->dims.d[2], pitch = (w + 31) / 32 * 32;
+        const char* ex = getenv("RT_PITCH_EXTRA");          // A/B knob: extra 128-byte lines per row
+        const int w = t->dims.d[2], pitch = (w + 31) / 32 * 32 + 32 * (ex ? atoi(ex) : 0);
         t->pitch = pitch == w ? 0 : pitch;
     }
     for (auto& op : ops_) {

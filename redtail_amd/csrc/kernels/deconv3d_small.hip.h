@@ -1,0 +1,94 @@
+// 3x3x3 stride-2 transposed 3-D convolution with one or two output channels: the last layer of the 3-D Stereo
+// DNN models (reference lib/conv3d_transpose_plugin.cpp:205-243 via cudnnConvolutionBackwardData;
+// nvsmall_1025x321_net.cpp:399-408: (32,48,161,513) -> (97,1,321,1025)).  With a single output channel a
+// 32-wide MFMA column block would be 97 % padding, so this is a vector-ALU kernel shaped for HBM/L1 traffic:
+//
+//   every output voxel o = 2m + phi (phi in {0,1}^3) of a 2x2x2 block reads inputs from the SAME 2x2x2 input
+//   neighbourhood of m, so one thread owns a block: 8 loads per input channel feed all 8 outputs (the per-phase
+//   form loads 27 values for them), the 64 phase x neighbour weights of a channel are wave-uniform and come
+//   through the scalar cache (zero where a phase has no tap), and the two x-phases of a row are stored as one
+//   8-byte access.  Addressing as in conv_mfma.hip.h: per-lane byte offsets computed once (out-of-range = 2^31,
+//   the buffer range check returns zeros), channel stride in an SGPR.
+#pragma once
+#include "common.hip.h"
+
+namespace rt {
+
+struct Deconv3dSmallArgs {
+    const float* x;        // (N, K, Dy, Hy, Wy)
+    float* y;              // (N, Dx, C, Hx, Wx)
+    const float* w;        // packed [K][COUT][phase 8][neighbour 8], phase = 4*pz + 2*py + px, neighbour = 4*jz + 2*jy + jx
+    const float* bias;     // [C], padded
+    const float* resid;    // like y, or nullptr
+    int K, Dy, Hy, Wy;
+    int Dx, Hx, Wx, C;
+    int bz, by, bx;        // neighbourhood origin relative to m (0 or -1 per dimension)
+    int Mz;                // 2x2x2 blocks along z
+    int act;
+    int64_t x_bstride, y_bstride;
+};
+
+template <int COUT>
+__global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArgs p) {
+    const int mx = blockIdx.x * 256 + threadIdx.x;
+    const int my = blockIdx.y;
+    const int mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
+
+    // the 8 neighbours of this block in one input channel
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int iz = mz + p.bz + (j >> 2), iy = my + p.by + ((j >> 1) & 1), ix = mx + p.bx + (j & 1);
+        const bool ok = iz >= 0 && iz < p.Dy && iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy;
+        voff[j] = ok ? (unsigned)((iz * p.Hy + iy) * p.Wy + ix) * 4u : kBufOOB;
+    }
+    const buf_rsrc rs_x = make_buf(p.x + (int64_t)n * p.x_bstride);
+    const unsigned cstride = (unsigned)(p.Dy * p.Hy * p.Wy) * 4u;
+
+    float acc[COUT][8];
+#pragma unroll
+    for (int co = 0; co < COUT; co++)
+#pragma unroll
+        for (int f = 0; f < 8; f++) acc[co][f] = p.bias[co];
+
+    const float* __restrict__ wk = p.w;
+    for (int k = 0; k < p.K; k++, wk += COUT * 64) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) xv[j] = buf_load(rs_x, voff[j], (unsigned)k * cstride);
+#pragma unroll
+        for (int co = 0; co < COUT; co++)
+#pragma unroll
+            for (int f = 0; f < 8; f++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[co][f] = fmaf(xv[j], wk[(co * 8 + f) * 8 + j], acc[co][f]);
+    }
+
+    // outputs (2mz + pz, co, 2my + py, 2mx + {0,1})
+    const buf_rsrc rs_y = make_buf(p.y + (int64_t)n * p.y_bstride);
+    const buf_rsrc rs_r = make_buf(p.resid + (int64_t)n * p.y_bstride, p.resid != nullptr);
+    const int ox = 2 * mx;
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+        if (co >= p.C) break;
+#pragma unroll
+        for (int pz = 0; pz < 2; pz++)
+#pragma unroll
+            for (int py = 0; py < 2; py++) {
+                const int oz = 2 * mz + pz, oy = 2 * my + py;
+                const bool row_ok = oz < p.Dx && oy < p.Hx;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.Wx + ox) * 4u;
+                const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
+                const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
+                f32x2_t o = {acc[co][4 * pz + 2 * py], acc[co][4 * pz + 2 * py + 1]};
+                const f32x2_t r2 = buf_load2(rs_r, v2, 0);
+                const float r1 = buf_load(rs_r, v1, 0);
+                o[0] = apply_act_rt(o[0] + r2[0] + r1, p.act);
+                o[1] = apply_act_rt(o[1] + r2[1], p.act);
+                buf_store2(o, rs_y, v2, 0);
+                buf_store(o[0], rs_y, v1, 0);
+            }
+    }
+}
+
+}  // namespace rt

@@ -15,6 +15,7 @@
 #include "kernels/common.hip.h"
 #include "kernels/conv_mfma.hip.h"
 #include "kernels/conv_wino.hip.h"
+#include "kernels/deconv3d_small.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -372,6 +373,8 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
+    int small3d = 0;                    // deconv3d_s2_small_kernel (3x3x3 stride-2 transposed, <= 2 output channels)
+    rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
 
 }  // namespace
@@ -831,7 +834,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     // (lib/conv3d_transpose_plugin.cpp:108-111)
     RT_REQUIRE((Dx + 2 * pd - V) / sd + 1 == Dy && (Hx + 2 * ph_ - R) / sh + 1 == Hy && (Wx + 2 * pw - Sk) / sh + 1 == Wy,
                "conv3d_transpose: out dims (%d,%d,%d) inconsistent with in dims (%d,%d,%d)", Dx, Hx, Wx, Dy, Hy, Wy);
-    RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 31), "conv3d_transpose: input sample exceeds 2^31 elements");
+    RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 29), "conv3d_transpose: input sample exceeds 2 GB (32-bit buffer offsets)");
 
     auto plan = new rtConvPlan();
     plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
@@ -841,6 +844,53 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
     const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
     int rc = 0;
+    // Last layer of the 3-D models: one or two output channels, 3x3x3, stride 2 -> 2x2x2-block kernel
+    if (C <= 2 && V == 3 && R == 3 && Sk == 3 && sd == 2 && sh == 2 && env_int("RT_NO_DECONV3D_SMALL", 0) == 0) {
+        const Phase1D pz[2] = {phase1d(2, pd, 3, 0), phase1d(2, pd, 3, 1)};
+        const Phase1D py[2] = {phase1d(2, ph_, 3, 0), phase1d(2, ph_, 3, 1)};
+        const Phase1D px[2] = {phase1d(2, pw, 3, 0), phase1d(2, pw, 3, 1)};
+        auto base_of = [](const Phase1D* ph, bool& ok) {
+            int lo = 1 << 20, hi = -(1 << 20);
+            for (int f = 0; f < 2; f++)
+                for (int u = 0; u < ph[f].K; u++) { lo = std::min(lo, u - ph[f].pad); hi = std::max(hi, u - ph[f].pad); }
+            ok = ok && hi - lo <= 1;
+            return lo;
+        };
+        bool ok = true;
+        const int bz = base_of(pz, ok), by = base_of(py, ok), bx = base_of(px, ok);
+        if (ok) {
+            const int CO = C;      // kernel template = C
+            std::vector<float> packed((size_t)K * CO * 64, 0.f);
+            for (int k = 0; k < K; k++)
+                for (int co = 0; co < CO; co++)
+                    for (int fz = 0; fz < 2; fz++)
+                        for (int fy = 0; fy < 2; fy++)
+                            for (int fx = 0; fx < 2; fx++)
+                                for (int uz = 0; uz < pz[fz].K; uz++)
+                                    for (int uy = 0; uy < py[fy].K; uy++)
+                                        for (int ux = 0; ux < px[fx].K; ux++) {
+                                            const int jz = uz - pz[fz].pad - bz, jy = uy - py[fy].pad - by, jx = ux - px[fx].pad - bx;
+                                            const int f = 4 * fz + 2 * fy + fx, j = 4 * jz + 2 * jy + jx;
+                                            packed[(((size_t)k * CO + co) * 8 + f) * 8 + j] +=
+                                                w[((((size_t)k * V + pz[fz].tap[uz]) * C + co) * R + py[fy].tap[uy]) * Sk + px[fx].tap[ux]];
+                                        }
+            SubConv sc;
+            sc.small3d = 1; sc.Cout = C; sc.nz = 1;
+            sc.s3.K = K; sc.s3.Dy = Dy; sc.s3.Hy = Hy; sc.s3.Wy = Wy;
+            sc.s3.Dx = Dx; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
+            sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dx + 1) / 2;
+            RT_REQUIRE((int64_t)Dx * C * Hx * Wx < (1ll << 29), "conv3d_transpose: output sample exceeds 2 GB (32-bit buffer offsets)");
+            rc = upload_weights(sc, packed);
+            plan->subs.push_back(sc);
+            if (!rc) {
+                const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
+                rc = upload_bias(plan, bias ? b.data() : nullptr, C);
+            }
+            if (rc) { free_plan(plan); return rc; }
+            *out = plan;
+            return 0;
+        }
+    }
     // One launch per output-depth class (depths cls, cls+sd, ... share the same set of depth taps); inside
     // it every (depth position, y/x output phase) is a ZSlice -- see rt_deconv2d_plan_create.
     std::vector<Phase1D> py_ph, px_ph;
@@ -965,6 +1015,19 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
     RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
     RT_REQUIRE(!plan->has_resid || residual, "rt_conv_enqueue: plan expects a residual tensor");
     for (const SubConv& sc : plan->subs) {
+        if (sc.small3d) {
+            rt::Deconv3dSmallArgs a = sc.s3;
+            a.x = static_cast<const float*>(x); a.y = static_cast<float*>(y); a.w = sc.w_dev; a.bias = plan->bias_dev;
+            a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
+            a.act = plan->act; a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
+            const int64_t gz = (int64_t)batch * a.Mz;
+            RT_REQUIRE(gz <= 65535 && (a.Hx + 1) / 2 <= 65535, "rt_conv_enqueue: grid limit exceeded");
+            dim3 grid((unsigned)rt::cdiv((a.Wx + 1) / 2, 256), (unsigned)((a.Hx + 1) / 2), (unsigned)gz);
+            if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1>), grid, dim3(256), 0, S(s), a);
+            else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2>), grid, dim3(256), 0, S(s), a);
+            RT_LAUNCH_CHECK("deconv3d_s2_small_kernel");
+            continue;
+        }
         rt::ConvArgs a;
         a.x = static_cast<const float*>(x);
         a.y = static_cast<float*>(y);

@@ -221,6 +221,29 @@ def test_conv3d_tran_symmetric_pad(backend):
     near(out, ref, 2e-5)
 
 
+SMALL_DECONV_CASES = [
+    # K, C, (Dy,Hy,Wy), out (Dx,Hx,Wx), pad_start, pad_end
+    (8, 1, (3, 4, 6), (7, 7, 11), (0, 1, 1), (0, 1, 1)),        # the models' last layer: asymmetric D (then Slice)
+    (32, 1, (2, 5, 37), (3, 9, 73), (1, 1, 1), (1, 1, 1)),      # symmetric pads, odd output dims, 2 workgroups in x
+    (6, 2, (3, 3, 5), (7, 5, 9), (0, 1, 1), (0, 1, 1)),         # two output channels
+]
+
+
+@pytest.mark.parametrize("k,c,ydims,xdims,ps,pe", SMALL_DECONV_CASES)
+@pytest.mark.parametrize("batch", [1, 2])
+def test_conv3d_tran_small_output(backend, monkeypatch, k, c, ydims, xdims, ps, pe, batch):
+    """deconv3d_s2_small_kernel (<= 2 output channels, 2x2x2 output block per thread) vs the oracle and vs the
+    generic per-phase path on the same inputs (RT_NO_DECONV3D_SMALL)"""
+    y, w, b = rnd(batch, k, *ydims), rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * k / 8)), rnd(c)
+    od = (xdims[0], c, xdims[1], xdims[2])
+    ref = O.elu(O.conv3d_transpose_tf(T(y), T(w), T(b), od, (2, 2, 2), ps, pe)).numpy()
+    out = conv3d_tran_run(backend, y, w, b, od, (2, 2, 2), ps, pe, act=capi.RT_ACT_ELU)
+    monkeypatch.setenv("RT_NO_DECONV3D_SMALL", "1")
+    gen = conv3d_tran_run(backend, y, w, b, od, (2, 2, 2), ps, pe, act=capi.RT_ACT_ELU)
+    near(out, ref, 2e-5)
+    near(gen, ref, 2e-5)
+
+
 def test_conv_rejects_bad_descriptors(backend):
     w = rnd(4, 4, 7, 7)
     with pytest.raises(capi.RtError):
