@@ -24,44 +24,48 @@ struct Deconv3dSmallArgs {
     int Dx, Hx, Wx, C;
     int bz, by, bx;        // neighbourhood origin relative to m (0 or -1 per dimension)
     int Mz;                // 2x2x2 blocks along z
+    int xp, yp;            // row pitch (elements) of the input / output planes (2-D plans may be re-pitched)
     int act;
     int64_t x_bstride, y_bstride;
 };
 
-template <int COUT>
+// Z = false: the 2-D form (TensorRT addDeconvolution 3x3 stride 2, resnet18_2D_513x257_net.cpp:758-763): Dy = Dx = 1,
+// 2x2 output blocks, weights packed [K][COUT][phase 4][neighbour 4].
+template <int COUT, bool Z = true>
 __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArgs p) {
+    constexpr int NJ = Z ? 8 : 4;          // neighbours = phases per block
     const int mx = blockIdx.x * 256 + threadIdx.x;
     const int my = blockIdx.y;
     const int mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
 
     // the 8 neighbours of this block in one input channel
-    unsigned voff[8];
+    unsigned voff[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int iz = mz + p.bz + (j >> 2), iy = my + p.by + ((j >> 1) & 1), ix = mx + p.bx + (j & 1);
+    for (int j = 0; j < NJ; j++) {
+        const int iz = Z ? mz + p.bz + (j >> 2) : 0, iy = my + p.by + ((j >> 1) & 1), ix = mx + p.bx + (j & 1);
         const bool ok = iz >= 0 && iz < p.Dy && iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy;
-        voff[j] = ok ? (unsigned)((iz * p.Hy + iy) * p.Wy + ix) * 4u : kBufOOB;
+        voff[j] = ok ? (unsigned)((iz * p.Hy + iy) * p.xp + ix) * 4u : kBufOOB;
     }
     const buf_rsrc rs_x = make_buf(p.x + (int64_t)n * p.x_bstride);
-    const unsigned cstride = (unsigned)(p.Dy * p.Hy * p.Wy) * 4u;
+    const unsigned cstride = (unsigned)(p.Dy * p.Hy * p.xp) * 4u;
 
-    float acc[COUT][8];
+    float acc[COUT][NJ];
 #pragma unroll
     for (int co = 0; co < COUT; co++)
 #pragma unroll
-        for (int f = 0; f < 8; f++) acc[co][f] = p.bias[co];
+        for (int f = 0; f < NJ; f++) acc[co][f] = p.bias[co];
 
     const float* __restrict__ wk = p.w;
-    for (int k = 0; k < p.K; k++, wk += COUT * 64) {
-        float xv[8];
+    for (int k = 0; k < p.K; k++, wk += COUT * NJ * NJ) {
+        float xv[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; j++) xv[j] = buf_load(rs_x, voff[j], (unsigned)k * cstride);
+        for (int j = 0; j < NJ; j++) xv[j] = buf_load(rs_x, voff[j], (unsigned)k * cstride);
 #pragma unroll
         for (int co = 0; co < COUT; co++)
 #pragma unroll
-            for (int f = 0; f < 8; f++)
+            for (int f = 0; f < NJ; f++)
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[co][f] = fmaf(xv[j], wk[(co * 8 + f) * 8 + j], acc[co][f]);
+                for (int j = 0; j < NJ; j++) acc[co][f] = fmaf(xv[j], wk[(co * NJ + f) * NJ + j], acc[co][f]);
     }
 
     // outputs (2mz + pz, co, 2my + py, 2mx + {0,1})
@@ -72,12 +76,12 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
     for (int co = 0; co < COUT; co++) {
         if (co >= p.C) break;
 #pragma unroll
-        for (int pz = 0; pz < 2; pz++)
+        for (int pz = 0; pz < (Z ? 2 : 1); pz++)
 #pragma unroll
             for (int py = 0; py < 2; py++) {
-                const int oz = 2 * mz + pz, oy = 2 * my + py;
+                const int oz = Z ? 2 * mz + pz : 0, oy = 2 * my + py;
                 const bool row_ok = oz < p.Dx && oy < p.Hx;
-                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.Wx + ox) * 4u;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
                 const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
                 const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
                 f32x2_t o = {acc[co][4 * pz + 2 * py], acc[co][4 * pz + 2 * py + 1]};

@@ -373,7 +373,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
-    int small3d = 0;                    // deconv3d_s2_small_kernel (3x3x3 stride-2 transposed, <= 2 output channels)
+    int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
 
@@ -689,6 +689,48 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     const std::vector<float> w = to_f32(weights, (size_t)d->Cin * d->Cout * d->KH * d->KW, d->dtype);
     const int Cin = d->Cin, Cout = d->Cout, KH = d->KH, KW = d->KW;
 
+    // Last layer of ResNet-18 2D (32 -> 1, 3x3, stride 2): 2x2-output-block kernel, see deconv3d_small.hip.h
+    if (Cout <= 2 && KH == 3 && KW == 3 && s == 2 && env_int("RT_NO_DECONV3D_SMALL", 0) == 0) {
+        const Phase1D qy[2] = {phase1d(2, d->pad_h, 3, 0), phase1d(2, d->pad_h, 3, 1)};
+        const Phase1D qx[2] = {phase1d(2, d->pad_w, 3, 0), phase1d(2, d->pad_w, 3, 1)};
+        auto base_of = [](const Phase1D* ph, bool& ok) {
+            int lo = 1 << 20, hi = -(1 << 20);
+            for (int f = 0; f < 2; f++)
+                for (int u = 0; u < ph[f].K; u++) { lo = std::min(lo, u - ph[f].pad); hi = std::max(hi, u - ph[f].pad); }
+            ok = ok && hi - lo <= 1;
+            return lo;
+        };
+        bool ok = true;
+        const int by = base_of(qy, ok), bx = base_of(qx, ok);
+        if (ok) {
+            std::vector<float> packed((size_t)Cin * Cout * 16, 0.f);
+            for (int k = 0; k < Cin; k++)
+                for (int co = 0; co < Cout; co++)
+                    for (int fy = 0; fy < 2; fy++)
+                        for (int fx = 0; fx < 2; fx++)
+                            for (int uy = 0; uy < qy[fy].K; uy++)
+                                for (int ux = 0; ux < qx[fx].K; ux++) {
+                                    const int jy = uy - qy[fy].pad - by, jx = ux - qx[fx].pad - bx;
+                                    packed[(((size_t)k * Cout + co) * 4 + 2 * fy + fx) * 4 + 2 * jy + jx] +=
+                                        w[(((size_t)k * Cout + co) * KH + qy[fy].tap[uy]) * KW + qx[fx].tap[ux]];   // (Cin,Cout,R,S)
+                                }
+            SubConv sc;
+            sc.small3d = 2; sc.Cout = Cout; sc.nz = 1;
+            sc.s3.K = Cin; sc.s3.Dy = 1; sc.s3.Hy = d->Hin; sc.s3.Wy = d->Win;
+            sc.s3.Dx = 1; sc.s3.Hx = Ho; sc.s3.Wx = Wo; sc.s3.C = Cout;
+            sc.s3.bz = 0; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = 1;
+            sc.s3.xp = d->Win; sc.s3.yp = Wo;
+            int rc = upload_weights(sc, packed);
+            plan->subs.push_back(sc);
+            if (!rc) {
+                const std::vector<float> b = bias ? to_f32(bias, Cout, d->dtype) : std::vector<float>();
+                rc = upload_bias(plan, bias ? b.data() : nullptr, Cout);
+            }
+            if (rc) { free_plan(plan); return rc; }
+            *out = plan;
+            return 0;
+        }
+    }
     // All s*s output phases go into ONE launch: the window is the largest phase window (2x2 for a 3x3
     // stride-2 kernel), phases with fewer taps get zero weights for the missing ones, and a ZSlice per
     // phase carries its padding, output origin and weight slab.
@@ -879,6 +921,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             sc.s3.K = K; sc.s3.Dy = Dy; sc.s3.Hy = Hy; sc.s3.Wy = Wy;
             sc.s3.Dx = Dx; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
             sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dx + 1) / 2;
+            sc.s3.xp = Wy; sc.s3.yp = Wx;
             RT_REQUIRE((int64_t)Dx * C * Hx * Wx < (1ll << 29), "conv3d_transpose: output sample exceeds 2 GB (32-bit buffer offsets)");
             rc = upload_weights(sc, packed);
             plan->subs.push_back(sc);
@@ -984,6 +1027,7 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
     const int old_op = plan->out_pitch ? plan->out_pitch : Wout;
     auto repitch = [&](int64_t off) { return (off / old_op) * op + off % old_op; };
     for (SubConv& sc : plan->subs) {
+        if (sc.small3d) { sc.s3.xp = ip; sc.s3.yp = op; continue; }
         sc.x_pitch = ip;
         std::vector<int> table(sc.CinPad, -1);
         for (int c = 0; c < plan->cin; c++) table[c] = c * plan->hin * ip;
@@ -1023,8 +1067,13 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             const int64_t gz = (int64_t)batch * a.Mz;
             RT_REQUIRE(gz <= 65535 && (a.Hx + 1) / 2 <= 65535, "rt_conv_enqueue: grid limit exceeded");
             dim3 grid((unsigned)rt::cdiv((a.Wx + 1) / 2, 256), (unsigned)((a.Hx + 1) / 2), (unsigned)gz);
-            if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1>), grid, dim3(256), 0, S(s), a);
-            else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2>), grid, dim3(256), 0, S(s), a);
+            if (sc.small3d == 2) {
+                if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false>), grid, dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false>), grid, dim3(256), 0, S(s), a);
+            } else {
+                if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, true>), grid, dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, true>), grid, dim3(256), 0, S(s), a);
+            }
             RT_LAUNCH_CHECK("deconv3d_s2_small_kernel");
             continue;
         }
