@@ -161,9 +161,12 @@ typedef struct rtConv3dDesc {
     int pad_start[3];       /* (d,h,w) -- what the reference hands to cuDNN                         */
     int pad_end[3];         /* validated like lib/conv3d_plugin.cpp:43-49, otherwise unused          */
     int act;                /* RT_ACT_* (0 at the plugin boundary; used by the fusing executor)     */
-    int out_dchw;           /* conv only: write (Do,K,Ho,Wo) instead of (K,Do,Ho,Wo)                */
-    int has_residual;
+    int out_dchw;           /* conv: write (Do,K,Ho,Wo) instead of (K,Do,Ho,Wo); transposed: write (C,D,H,W)  */
+                            /* instead of (D,C,H,W) -- the Transform plugin that follows, in the same pass  */
+    int has_residual;       /* residual tensor: shaped like the output; for the transposed op always (D,C,H,W) */
     int dtype;
+    int out_depth;          /* transposed only: keep output depth slices [0, out_depth) (0 = all) -- the      */
+                            /* Slice plugin that follows an even-depth conv3d_transpose, in the same pass      */
 } rtConv3dDesc;
 
 /* TensorFlow-compatible 3-D convolution.  x (N, D,C,H,W) , w (K,V,C,R,S) 3x3x3 -> y (N, K,Do,Ho,Wo).

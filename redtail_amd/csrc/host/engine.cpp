@@ -619,6 +619,14 @@ bool EngineImpl::lower() {
                             nx = soleConsumer(cur->id);
                         }
                     }
+                    // Conv3DTranspose [+ Slice [0,d)] [+ skip add] [+ ELU] [+ Transform {1,0,2,3}]: the decoder pattern
+                    // of the 3-D models (nvsmall_1025x321_net.cpp:331-398) in one launch
+                    if (sp->kind() == Kind::kConv3DTranspose && nx && isKind(nx, Kind::kSlice) && stereo(nx)->sliceStart() == 0) {
+                        f.out_depth = stereo(nx)->sliceEnd();
+                        absorbed.push_back(index_of(nx));
+                        cur = nx->out[0];
+                        nx = soleConsumer(cur->id);
+                    }
                     int resid = -1;
                     if (nx && nx->type == LayerType::kELEMENTWISE && nx->ew == ElementWiseOperation::kSUM &&
                         volume(nx->out[0]->dims) == volume(cur->dims)) {
@@ -635,8 +643,17 @@ bool EngineImpl::lower() {
                         f.act = RT_ACT_ELU;
                         absorbed.push_back(index_of(nx));
                         cur = nx->out[0];
+                        nx = soleConsumer(cur->id);
                     }
-                    if ((f.act || f.out_dchw || f.residual) && sp->setFusion(f)) {
+                    if (sp->kind() == Kind::kConv3DTranspose && nx && isKind(nx, Kind::kTransform)) {
+                        Permutation p = stereo(nx)->permutation();
+                        if (p.order[0] == 1 && p.order[1] == 0 && p.order[2] == 2 && p.order[3] == 3) {
+                            f.out_dchw = true;
+                            absorbed.push_back(index_of(nx));
+                            cur = nx->out[0];
+                        }
+                    }
+                    if ((f.act || f.out_dchw || f.residual || f.out_depth) && sp->setFusion(f)) {
                         for (int a : absorbed) done[a] = true;
                         op.kind = OpKind::kConv3D;
                         op.plugin = l->plugin;

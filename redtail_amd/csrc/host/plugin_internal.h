@@ -13,8 +13,10 @@ enum class Kind { kElu, kCostVolume, kSoftargmax, kConv3D, kConv3DTranspose, kTr
 
 struct ConvFusion {            // what the executor asks a Conv3D / Conv3DTranspose plugin to absorb
     int act = 0;               // RT_ACT_*
-    bool out_dchw = false;     // Conv3D only: write (D,K,H,W) directly (elides the Transform plugin)
-    bool residual = false;     // add a residual tensor shaped like the output before the activation
+    bool out_dchw = false;     // write the transposed layout directly (elides the Transform {1,0,2,3} plugin):
+                               // Conv3D (K,D,H,W) -> (D,K,H,W); Conv3DTranspose (D,C,H,W) -> (C,D,H,W)
+    bool residual = false;     // add a residual tensor before the activation (Conv3DTranspose: always (D,C,H,W))
+    int out_depth = 0;         // Conv3DTranspose only: keep output slices [0, out_depth) (elides the Slice plugin)
 };
 
 class IStereoPlugin {

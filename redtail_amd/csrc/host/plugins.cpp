@@ -329,7 +329,7 @@ public:
         return rc == 0 ? 0 : -1;
     }
     bool setFusion(const internal::ConvFusion& f) override {
-        if (f.out_dchw && transposed_) return false;
+        if (f.out_depth && !transposed_) return false;
         fusion_ = f;
         return rebuildPlan();
     }
@@ -344,6 +344,7 @@ protected:
         d.act = fusion_.act;
         d.out_dchw = fusion_.out_dchw ? 1 : 0;
         d.has_residual = fusion_.residual ? 1 : 0;
+        d.out_depth = fusion_.out_depth;
         d.dtype = kernel_.type == DataType::kHALF ? RT_F16 : RT_F32;   // storage type of the weight blob
         int rc = createPlan(d);
         RT_CHECKL(rc, log_);

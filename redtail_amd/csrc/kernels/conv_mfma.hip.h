@@ -42,6 +42,7 @@ struct ZSlice {
     int reserved;
     int64_t y_off;         // replaces ConvArgs::y_off + zi * y_zstride
     int64_t w_off;         // element offset of this slice's packed weights
+    int64_t r_off;         // like y_off, for the residual tensor (differs when the output layout is transposed)
 };
 
 struct ConvArgs {
@@ -70,6 +71,8 @@ struct ConvArgs {
     int64_t y_zstride;     // output z-slice stride
     int64_t y_off;         // constant output offset (deconv phase origin)
     int y_ystride, y_xstride;
+    int64_t r_cstride;     // residual: channel stride and per-sample stride (== y_cstride / y_bstride unless the
+    int64_t r_bstride;     // launch writes a transposed layout, e.g. Conv3DTranspose + Transform in one pass)
 };
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with
@@ -167,10 +170,11 @@ conv_mfma_f32_kernel(ConvArgs p) {
     const int nchunks = p.CinPad / CC;
     // per-slice parameters (wave-uniform): uniform launch, or one entry of the ZSlice table
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
-    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
     if (p.zs) {
         const ZSlice z = p.zs[zi];
         pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
+        r_off = z.r_off;
     }
 
     const int act = p.act;
@@ -200,7 +204,8 @@ conv_mfma_f32_kernel(ConvArgs p) {
     // SGPR, and ONE per-lane byte offset per wave-tile (pixel + the 4-channel shift of the upper half-wave).
     // Accumulator register r of 32-block b holds channel cb + (r&3) + 8*(r>>2) + 4*half.
     const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
-    const int cs32 = (int)p.y_cstride;
+    const int64_t rbase = (int64_t)n * p.r_bstride + r_off;
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
     const bool tail8 = (p.Cout & 7) != 0;          // only then is channel validity lane dependent
     unsigned yvoff[WT];
 #pragma unroll
@@ -223,11 +228,13 @@ conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
-                const buf_rsrc rs = make_buf(resid + ybase, (resid != nullptr) & (cs < p.Cout));
-                const unsigned so = (unsigned)(cs * cs32) * 4u;
+                const buf_rsrc rs = make_buf(resid + rbase, (resid != nullptr) & (cs < p.Cout));
+                const unsigned so = (unsigned)(cs * rs32) * 4u;
 #pragma unroll
                 for (int i = 0; i < WT; i++) {
-                    const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
+                    // same pixel, the residual's own channel stride for the upper half-wave's 4-channel shift
+                    const unsigned rvo = yvoff[i] == kBufOOB ? kBufOOB : yvoff[i] + (unsigned)(4 * half * (rs32 - cs32)) * 4u;
+                    const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : rvo;
                     rv[i][b][r] = kAblResid ? (float)cs : buf_load(rs, vo, so);
                 }
             }

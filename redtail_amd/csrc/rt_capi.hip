@@ -367,6 +367,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int x_pitch = 0;                    // 0 = dense (Wi)
     std::vector<rt::ZSlice> zs_host;    // host copy of the ZSlice table (re-pitching)
     int64_t y_cstride = 0, y_zstride = 0, y_off = 0;
+    int64_t r_cstride = 0;              // residual channel stride, 0 = y_cstride
     int y_ystride = 0, y_xstride = 1;
     float* w_dev = nullptr;
     int* choff_dev = nullptr;
@@ -386,6 +387,7 @@ struct rtConvPlan {
     int act = 0, has_resid = 0, dtype = RT_F32;
     int out_dims[4] = {0, 0, 0, 1};
     int64_t x_bstride = 0, y_bstride = 0;
+    int64_t r_bstride = 0;                        // residual per-sample stride, 0 = y_bstride
     int is2d = 0, cin = 0, hin = 0, win = 0;      // 2-D plans can be re-pitched (rt_conv_plan_set_pitch)
     int in_pitch = 0, out_pitch = 0;
 };
@@ -767,6 +769,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             z.Ho = (Ho - py + s - 1) / s; z.Wo = (Wo - px + s - 1) / s;
             z.ch_row = 0;
             z.y_off = (int64_t)py * Wo + px;
+            z.r_off = z.y_off;
             z.w_off = pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) {
                 if (u >= ay.K || v >= ax.K) return 0.f;                               // padded tap / empty phase
                 return w[(((size_t)ci * Cout + co) * KH + ay.tap[u]) * KW + ax.tap[v]];   // (Cin,Cout,R,S)
@@ -866,7 +869,11 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
                                                const void* weights, const void* bias) {
     RT_REQUIRE(out && d && in_dims && weights, "rt_conv3d_transpose_plan_create: null pointer");
     if (int rc = check_conv3d_desc(d, "rt_conv3d_transpose_plan_create")) return rc;
-    RT_REQUIRE(!d->out_dchw, "conv3d_transpose: output is always (D,C,H,W)");
+    // fused epilogue layouts (executor only, see rt_stereo.h): keep the first out_depth output slices (Slice plugin)
+    // and/or write (C,D,H,W) instead of (D,C,H,W) (Transform plugin); the residual always is (D,C,H,W)
+    const int Dlim = d->out_depth > 0 ? d->out_depth : d->D;
+    RT_REQUIRE(Dlim <= d->D, "conv3d_transpose: out_depth %d exceeds the output depth %d", Dlim, d->D);
+    const bool cdhw = d->out_dchw != 0;
     const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
     const int sd = d->stride[0], sh = d->stride[1];
     const int pd = d->pad_start[0], ph_ = d->pad_start[1], pw = d->pad_start[2];
@@ -880,14 +887,14 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
 
     auto plan = new rtConvPlan();
     plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
-    plan->out_dims[0] = Dx; plan->out_dims[1] = C; plan->out_dims[2] = Hx; plan->out_dims[3] = Wx;
+    plan->out_dims[0] = cdhw ? C : Dlim; plan->out_dims[1] = cdhw ? Dlim : C; plan->out_dims[2] = Hx; plan->out_dims[3] = Wx;
     plan->x_bstride = (int64_t)K * Dy * Hy * Wy;
-    plan->y_bstride = (int64_t)Dx * C * Hx * Wx;
+    plan->y_bstride = (int64_t)Dlim * C * Hx * Wx;
     const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
     const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
     int rc = 0;
     // Last layer of the 3-D models: one or two output channels, 3x3x3, stride 2 -> 2x2x2-block kernel
-    if (C <= 2 && V == 3 && R == 3 && Sk == 3 && sd == 2 && sh == 2 && env_int("RT_NO_DECONV3D_SMALL", 0) == 0) {
+    if (C <= 2 && !cdhw && V == 3 && R == 3 && Sk == 3 && sd == 2 && sh == 2 && env_int("RT_NO_DECONV3D_SMALL", 0) == 0) {
         const Phase1D pz[2] = {phase1d(2, pd, 3, 0), phase1d(2, pd, 3, 1)};
         const Phase1D py[2] = {phase1d(2, ph_, 3, 0), phase1d(2, ph_, 3, 1)};
         const Phase1D px[2] = {phase1d(2, pw, 3, 0), phase1d(2, pw, 3, 1)};
@@ -919,8 +926,8 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             SubConv sc;
             sc.small3d = 1; sc.Cout = C; sc.nz = 1;
             sc.s3.K = K; sc.s3.Dy = Dy; sc.s3.Hy = Hy; sc.s3.Wy = Wy;
-            sc.s3.Dx = Dx; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
-            sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dx + 1) / 2;
+            sc.s3.Dx = Dlim; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
+            sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dlim + 1) / 2;
             sc.s3.xp = Wy; sc.s3.yp = Wx;
             RT_REQUIRE((int64_t)Dx * C * Hx * Wx < (1ll << 29), "conv3d_transpose: output sample exceeds 2 GB (32-bit buffer offsets)");
             rc = upload_weights(sc, packed);
@@ -945,14 +952,15 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
         wx = std::max(wx, px_ph.back().K);
     }
     for (int cls = 0; cls < sd && !rc; cls++) {          // output depths dx = cls, cls + sd, ...
-        if (cls >= Dx) continue;
+        if (cls >= Dlim) continue;
         const Phase1D az = phase1d(sd, pd, V, cls);
-        const int nzd = (Dx - cls + sd - 1) / sd;
+        const int nzd = (Dlim - cls + sd - 1) / sd;
         const int nv = std::max(az.K, 1);
         SubConv sc;
         sc.KH = wy; sc.KW = wx; sc.S = 1; sc.Cout = C; sc.Hi = Hy; sc.Wi = Wy;
         sc.Ho = (Hx + sh - 1) / sh; sc.Wo = (Wx + sh - 1) / sh;
-        sc.y_cstride = out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
+        sc.y_cstride = cdhw ? (int64_t)Dlim * out_plane : out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
+        sc.r_cstride = out_plane;
         int nph = 0;
         for (int py = 0; py < sh; py++)
             for (int px = 0; px < sh; px++)
@@ -987,7 +995,8 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
                     z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
                     z.Ho = (Hx - py + sh - 1) / sh; z.Wo = (Wx - px + sh - 1) / sh;
                     z.ch_row = m;
-                    z.y_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
+                    z.r_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
+                    z.y_off = cdhw ? (int64_t)(cls + m * sd) * out_plane + (int64_t)py * Wx + px : z.r_off;
                     z.w_off = w_offs[iph++];
                     zs.push_back(z);
                 }
@@ -1036,7 +1045,7 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
         sc.y_cstride = (int64_t)Hout * op;
         sc.y_off = repitch(sc.y_off);
         if (!sc.zs_host.empty()) {
-            for (auto& z : sc.zs_host) z.y_off = repitch(z.y_off);
+            for (auto& z : sc.zs_host) { z.y_off = repitch(z.y_off); z.r_off = z.y_off; }
             RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
         }
     }
@@ -1100,6 +1109,8 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
         a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
+        a.r_cstride = sc.r_cstride ? sc.r_cstride : sc.y_cstride;
+        a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);

@@ -244,6 +244,30 @@ def test_conv3d_tran_small_output(backend, monkeypatch, k, c, ydims, xdims, ps, 
     near(gen, ref, 2e-5)
 
 
+@pytest.mark.parametrize("cdhw", [False, True])
+@pytest.mark.parametrize("c", [1, 5, 32])
+def test_conv3d_tran_fused_epilogue(backend, c, cdhw):
+    """Conv3DTranspose + Slice[0,d) + skip add + ELU (+ Transform {1,0,2,3}) in one launch: the decoder pattern of
+    the 3-D models (nvsmall_1025x321_net.cpp:331-398).  The skip tensor stays (D,C,H,W) whatever the output layout."""
+    n, k, ydims, dfull = 2, 8, (3, 4, 19), 7
+    dkeep = dfull - 1
+    y, w, b = rnd(n, k, *ydims), rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * k / 8)), rnd(c)
+    od = (dfull, c, 7, 37)
+    skip = rnd(n, dkeep, c, 7, 37)
+    ref = O.conv3d_transpose_tf(T(y), T(w), T(b), od, (2, 2, 2), (0, 1, 1), (0, 1, 1))[:, :dkeep]
+    ref = O.elu(ref + T(skip))
+    if cdhw:
+        ref = O.transform(ref)
+    plan = backend.klib.conv3d_plan(w, b, c, k, (dfull, 7, 37), (3, 3, 3), (2, 2, 2), (0, 1, 1), (0, 1, 1),
+                                    act=capi.RT_ACT_ELU, out_dchw=cdhw, has_residual=True, transposed_in_dims=ydims,
+                                    out_depth=dkeep)
+    assert plan.out_dims == ((c, dkeep, 7, 37) if cdhw else (dkeep, c, 7, 37))
+    out = backend.empty(ref.shape)
+    plan.enqueue(backend.dev(y), out, backend.dev(skip), n)
+    near(backend.host(out), ref.numpy(), 2e-5)
+    plan.destroy()
+
+
 def test_conv_rejects_bad_descriptors(backend):
     w = rnd(4, 4, 7, 7)
     with pytest.raises(capi.RtError):

@@ -107,6 +107,17 @@ def test_nvtiny_tiny(rt):
     assert np.abs(out - ref).max() <= 1e-3, np.abs(out - ref).max()
 
 
+def test_nvtiny_unfused_equals_fused(rt, monkeypatch):
+    """3-D decoder fusion (Conv3DTranspose + Slice + add + ELU + Transform in one launch) vs every plugin on its own"""
+    w = O.synth_weights_3d(O.NVTINY_3D)
+    l, r = pairs(1, 33, 65)
+    fused, (_, n1) = run_net(rt, "nvtiny", w, l, r, max_disp=8)
+    monkeypatch.setenv("RT_NO_FUSION", "1")
+    unfused, (_, n2) = run_net(rt, "nvtiny", w, l, r, max_disp=8)
+    assert n1 <= 26 < n2, (n1, n2)
+    assert np.abs(fused - unfused).max() <= 1e-4
+
+
 def test_bad_inputs_fail_loudly(rt):
     w = O.synth_weights_resnet18_2d()
     with pytest.raises(capi.RtError):
