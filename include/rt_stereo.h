@@ -167,6 +167,9 @@ typedef struct rtConv3dDesc {
     int dtype;
     int out_depth;          /* transposed only: keep output depth slices [0, out_depth) (0 = all) -- the      */
                             /* Slice plugin that follows an even-depth conv3d_transpose, in the same pass      */
+    int in_pad_end;         /* conv only: the last in_pad_end of the D input slices are zeros that do not exist  */
+                            /* in memory (x is (D - in_pad_end, C, H, W)) -- the Pad plugin emitted before every  */
+                            /* stride-2 Conv3D (scripts/tensorrt_model_builder.py:331-345), in the same pass     */
 } rtConv3dDesc;
 
 /* TensorFlow-compatible 3-D convolution.  x (N, D,C,H,W) , w (K,V,C,R,S) 3x3x3 -> y (N, K,Do,Ho,Wo).

@@ -619,6 +619,15 @@ bool EngineImpl::lower() {
                             nx = soleConsumer(cur->id);
                         }
                     }
+                    // Pad (zero slices appended in D) feeding only this Conv3D: read the unpadded tensor, the gather
+                    // table turns the missing slices into zeros
+                    int folded_pad_op = -1;
+                    if (sp->kind() == Kind::kConv3D && l->in[0]->producer && isKind(l->in[0]->producer, Kind::kPadding) &&
+                        consumers(l->in[0]->id) == 1) {
+                        for (size_t oi = 0; oi < ops_.size(); oi++)
+                            if (ops_[oi].kind == OpKind::kPlugin && ops_[oi].out == l->in[0]->id) folded_pad_op = (int)oi;
+                        if (folded_pad_op >= 0) f.in_pad_end = stereo(l->in[0]->producer)->padEnd();
+                    }
                     // Conv3DTranspose [+ Slice [0,d)] [+ skip add] [+ ELU] [+ Transform {1,0,2,3}]: the decoder pattern
                     // of the 3-D models (nvsmall_1025x321_net.cpp:331-398) in one launch
                     if (sp->kind() == Kind::kConv3DTranspose && nx && isKind(nx, Kind::kSlice) && stereo(nx)->sliceStart() == 0) {
@@ -653,8 +662,12 @@ bool EngineImpl::lower() {
                             cur = nx->out[0];
                         }
                     }
-                    if ((f.act || f.out_dchw || f.residual || f.out_depth) && sp->setFusion(f)) {
+                    if ((f.act || f.out_dchw || f.residual || f.out_depth || f.in_pad_end) && sp->setFusion(f)) {
                         for (int a : absorbed) done[a] = true;
+                        if (f.in_pad_end) {                       // drop the Pad launch, consume its input
+                            op.in[0] = ops_[folded_pad_op].in[0];
+                            ops_.erase(ops_.begin() + folded_pad_op);
+                        }
                         op.kind = OpKind::kConv3D;
                         op.plugin = l->plugin;
                         op.splugin = sp;

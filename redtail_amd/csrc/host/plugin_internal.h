@@ -17,6 +17,7 @@ struct ConvFusion {            // what the executor asks a Conv3D / Conv3DTransp
                                // Conv3D (K,D,H,W) -> (D,K,H,W); Conv3DTranspose (D,C,H,W) -> (C,D,H,W)
     bool residual = false;     // add a residual tensor before the activation (Conv3DTranspose: always (D,C,H,W))
     int out_depth = 0;         // Conv3DTranspose only: keep output slices [0, out_depth) (elides the Slice plugin)
+    int in_pad_end = 0;        // Conv3D only: the last input slices are implicit zeros (elides the Pad plugin)
 };
 
 class IStereoPlugin {

@@ -330,6 +330,7 @@ public:
     }
     bool setFusion(const internal::ConvFusion& f) override {
         if (f.out_depth && !transposed_) return false;
+        if (f.in_pad_end && transposed_) return false;
         fusion_ = f;
         return rebuildPlan();
     }
@@ -345,6 +346,7 @@ protected:
         d.out_dchw = fusion_.out_dchw ? 1 : 0;
         d.has_residual = fusion_.residual ? 1 : 0;
         d.out_depth = fusion_.out_depth;
+        d.in_pad_end = fusion_.in_pad_end;
         d.dtype = kernel_.type == DataType::kHALF ? RT_F16 : RT_F32;   // storage type of the weight blob
         int rc = createPlan(d);
         RT_CHECKL(rc, log_);

@@ -825,7 +825,9 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     if (d->out_dchw) { plan->out_dims[0] = Do; plan->out_dims[1] = K; }
     else { plan->out_dims[0] = K; plan->out_dims[1] = Do; }
     plan->out_dims[2] = Ho; plan->out_dims[3] = Wo;
-    plan->x_bstride = (int64_t)d->D * C * d->H * d->W;
+    const int Dreal = d->D - d->in_pad_end;               // slices that exist in memory (folded Pad plugin)
+    RT_REQUIRE(d->in_pad_end >= 0 && Dreal > 0, "conv3d: in_pad_end %d out of range", d->in_pad_end);
+    plan->x_bstride = (int64_t)Dreal * C * d->H * d->W;
     plan->y_bstride = (int64_t)K * Do * Ho * Wo;
 
     SubConv sc;
@@ -851,7 +853,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     for (int dz = 0; dz < Do; dz++)
         for (int v = 0; v < V; v++) {
             const int din = dz * sd + v - pd;
-            if (din < 0 || din >= d->D) continue;
+            if (din < 0 || din >= Dreal) continue;
             for (int c = 0; c < C; c++) table[(size_t)dz * sc.CinPad + v * C + c] = (int)(((int64_t)din * C + c) * plane);
         }
     if (!rc) rc = upload_table(sc, table);

@@ -35,7 +35,7 @@ def main():
         tot = sum(t for _, t in prof)
         print("%-9s %dx%d: %8.2f ms/pair  (%d launches, sum of launch times %.2f ms)  finite=%s" % (
             model, w, h, ms, len(prof), tot, bool(torch.isfinite(out).all())))
-        for name, t in sorted(prof, key=lambda p: -p[1])[:14]:
+        for name, t in sorted(prof, key=lambda p: -p[1])[:64]:
             print("      %-28s %8.3f ms" % (name, t))
         net.destroy()
 
