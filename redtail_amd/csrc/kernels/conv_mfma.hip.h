@@ -39,7 +39,7 @@ struct ZSlice {
     int pad_y, pad_x;
     int Ho, Wo;
     int ch_row;            // row of the ch_off table
-    int reserved;
+    unsigned tap_mask;     // bit (u*KW + v): tap (u, v) of the launch window exists in this slice (others have zero weights)
     int64_t y_off;         // replaces ConvArgs::y_off + zi * y_zstride
     int64_t w_off;         // element offset of this slice's packed weights
     int64_t r_off;         // like y_off, for the residual tensor (differs when the output layout is transposed)
@@ -171,10 +171,12 @@ conv_mfma_f32_kernel(ConvArgs p) {
     // per-slice parameters (wave-uniform): uniform launch, or one entry of the ZSlice table
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
     int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
+    unsigned tap_mask = ~0u;       // transposed-conv phases narrower than the launch window skip the padded taps
     if (p.zs) {
         const ZSlice z = p.zs[zi];
         pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
         r_off = z.r_off;
+        tap_mask = z.tap_mask;
     }
 
     const int act = p.act;
@@ -354,13 +356,15 @@ conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
                 for (int i = 0; i < WT; i++) b_nxt[i] = lds_b(b_base[i] + r * 2 * PC + s);
             }
+            if ((tap_mask >> t) & 1u) {            // wave-uniform
 #pragma unroll
-            for (int j = 0; j < CPG; j++)
+                for (int j = 0; j < CPG; j++)
 #pragma unroll
-                for (int i = 0; i < WT; i++)
+                    for (int i = 0; i < WT; i++)
 #pragma unroll
-                    for (int b = 0; b < NBW; b++)
-                        acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[b][j], b_cur[i][j], acc[i][b], 0, 0, 0);
+                        for (int b = 0; b < NBW; b++)
+                            acc[i][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[b][j], b_cur[i][j], acc[i][b], 0, 0, 0);
+            }
             if (t + 1 < TAPS) {
 #pragma unroll
                 for (int b = 0; b < NBW; b++) a_cur[b] = a_nxt[b];

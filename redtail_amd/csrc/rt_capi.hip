@@ -770,6 +770,9 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             z.ch_row = 0;
             z.y_off = (int64_t)py * Wo + px;
             z.r_off = z.y_off;
+            z.tap_mask = 0;
+            for (int u = 0; u < ay.K; u++)
+                for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
             z.w_off = pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) {
                 if (u >= ay.K || v >= ax.K) return 0.f;                               // padded tap / empty phase
                 return w[(((size_t)ci * Cout + co) * KH + ay.tap[u]) * KW + ax.tap[v]];   // (Cin,Cout,R,S)
@@ -997,6 +1000,9 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
                     z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
                     z.Ho = (Hx - py + sh - 1) / sh; z.Wo = (Wx - px + sh - 1) / sh;
                     z.ch_row = m;
+                    z.tap_mask = 0;
+                    for (int u = 0; u < ay.K; u++)
+                        for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
                     z.r_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
                     z.y_off = cdhw ? (int64_t)(cls + m * sd) * out_plane + (int64_t)py * Wx + px : z.r_off;
                     z.w_off = w_offs[iph++];
