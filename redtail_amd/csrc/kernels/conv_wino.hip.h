@@ -135,15 +135,19 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     // each lane owns output pixel pairs (2t, 2t+1) of rows 2*tg + a: one 8-byte access per pair; the pair that
     // straddles the right image edge (odd widths) falls back to a 4-byte access behind a scalar branch
     const bool edge_tile = tx0 + TX > Wo;                 // wave-uniform
+    // (recomputed in the epilogue instead of being kept live across the main loop: 4 registers at the 128-VGPR limit)
     unsigned yv2[2], yv1[2];
+    auto out_offsets = [&]() {
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-        const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t;
-        const bool row_ok = oy < Ho && cbase < p.Cout;
-        const unsigned off = (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u;
-        yv2[a] = (row_ok && ox + 1 < Wo) ? off : kBufOOB;
-        yv1[a] = (row_ok && ox + 1 == Wo) ? off : kBufOOB;
-    }
+        for (int a = 0; a < 2; a++) {
+            const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t;
+            const bool row_ok = oy < Ho && cbase < p.Cout;
+            const unsigned off = (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u;
+            yv2[a] = (row_ok && ox + 1 < Wo) ? off : kBufOOB;
+            yv1[a] = (row_ok && ox + 1 == Wo) ? off : kBufOOB;
+        }
+    };
+    out_offsets();
     // residual values are requested first (HBM latency overlaps the first gather) and consumed after prefetch(0)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
     float rr[4][2][2];
@@ -235,6 +239,8 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
     const buf_rsrc rs_y = make_buf(p.y + ybase);
+    asm volatile("" ::: "memory");     // keep the recomputation below the loop
+    out_offsets();
     auto epilogue = [&](auto ACT) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
