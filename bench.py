@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "4")),
                     help="IExecutionContexts per GPU, each with its own stream; steps are issued round-robin "
                          "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop")
+    ap.add_argument("--from-host", action="store_true", help="also measure the PCIe-inclusive rate (extra JSON object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,6 +174,49 @@ def main():
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
         single = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3, "steps": n1}
+    # PCIe-inclusive rate (never `value`): the same K steps with each pair's two images copied host -> device and its
+    # disparity device -> host, pinned buffers, copies on a per-context copy stream ordered by events so that they
+    # overlap the convolutions of the other contexts (double-buffered H2D)
+    pcie = None
+    if args.from_host and rank == 0:
+        h_l, h_r = left.cpu().pin_memory(), right.cpu().pin_memory()
+        h_out = [torch.empty(b, 1, H, W).pin_memory() for _ in nets]
+        NBUF = 2                                                      # input buffers per context: copy i+1 under compute i
+        d_l = [[torch.empty_like(left) for _ in range(NBUF)] for _ in nets]
+        d_r = [[torch.empty_like(right) for _ in range(NBUF)] for _ in nets]
+        copy_streams = [torch.cuda.Stream(device=dev) for _ in nets]
+        copied = [[torch.cuda.Event() for _ in range(NBUF)] for _ in nets]
+        consumed = [[torch.cuda.Event() for _ in range(NBUF)] for _ in nets]
+
+        def host_step(i):
+            c, k = i % nctx, (i // nctx) % NBUF
+            with torch.cuda.stream(copy_streams[c]):
+                copy_streams[c].wait_event(consumed[c][k])        # the pair that used this buffer has read its inputs
+                d_l[c][k].copy_(h_l, non_blocking=True)
+                d_r[c][k].copy_(h_r, non_blocking=True)
+                copied[c][k].record()
+            streams[c].wait_event(copied[c][k])
+            nets[c].execute(d_l[c][k], d_r[c][k], disps[c], b, stream=streams[c].cuda_stream)
+            with torch.cuda.stream(streams[c]):
+                consumed[c][k].record()
+                h_out[c].copy_(disps[c], non_blocking=True)
+
+        for c in range(nctx):
+            for k in range(NBUF):
+                consumed[c][k].record(streams[c])
+        for i in range(args.warmup):
+            host_step(i)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            host_step(i)
+        torch.cuda.synchronize(dev)
+        dt1 = time.perf_counter() - t1
+        mb = (left.numel() + right.numel() + disps[0].numel()) * 4 / 1e6
+        pcie = {"value": args.steps * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / args.steps / b * 1e3,
+                "mb_per_pair": mb / b, "gb_per_s": mb * args.steps / dt1 / 1e3,
+                "note": "H2D of both images + D2H of the disparity per pair, pinned host memory, overlapped"}
+        assert torch.equal(h_out[0], disps[0].cpu()), "host copy of the disparity differs"
     for d in disps:
         assert torch.isfinite(d).all(), "non-finite disparity"
         assert torch.equal(d, disps[0]), "contexts disagree"
@@ -206,6 +250,8 @@ def main():
         }
         if single is not None:
             out["single_context"] = single
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth.synth_weights_resnet18_2d(seed=7))
         print(json.dumps(out), flush=True)
