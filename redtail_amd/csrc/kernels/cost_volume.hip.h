@@ -257,19 +257,21 @@ cost_volume_f32_kernel(const float* __restrict__ left, const float* __restrict__
 // Soft-argmax / soft-argmin over D: one pass, online softmax in registers, coalesced along W.
 // grid = (ceil(H*W/256), N)
 // ------------------------------------------------------------------------------------------------
-template <bool ISMIN>
+// T = float or _Float16 storage (the reference's plugin takes kHALF volumes in NCHW, softargmax_plugin.cpp:51-54,
+// and widens them to fp32 around its cuDNN passes, :116-160); arithmetic is fp32 either way.
+template <bool ISMIN, typename T = float>
 __global__ void __launch_bounds__(256)
-softargmax_f32_kernel(const float* __restrict__ vol, float* __restrict__ out, int D, int64_t HW) {
+softargmax_f32_kernel(const T* __restrict__ vol, T* __restrict__ out, int D, int64_t HW) {
     const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y;
     if (px >= HW) return;
-    const float* v = vol + (int64_t)n * D * HW + px;
+    const T* v = vol + (int64_t)n * D * HW + px;
     float m = -INFINITY, s = 0.f, ws = 0.f;
     for (int d0 = 0; d0 < D; d0 += 8) {
         float xv[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float t = d0 + j < D ? v[(int64_t)(d0 + j) * HW] : 0.f;
+            const float t = d0 + j < D ? (float)v[(int64_t)(d0 + j) * HW] : 0.f;
             xv[j] = d0 + j < D ? (ISMIN ? -t : t) : -INFINITY;
         }
         float cm = xv[0];
@@ -287,7 +289,7 @@ softargmax_f32_kernel(const float* __restrict__ vol, float* __restrict__ out, in
         }
         m = mn;
     }
-    out[(int64_t)n * HW + px] = ws / s;
+    out[(int64_t)n * HW + px] = (T)(ws / s);
 }
 
 }  // namespace rt

@@ -286,9 +286,17 @@ extern "C" int rt_softargmax(const void* vol, void* out, int batch, int D, int H
                              rtStream s) {
     RT_REQUIRE(vol && out, "rt_softargmax: null pointer");
     RT_REQUIRE(batch > 0 && D > 0 && H > 0 && W > 0 && batch <= 65535, "rt_softargmax: bad dims");
-    if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_softargmax: only fp32 in this build");
+    if (dtype != RT_F32 && dtype != RT_F16) return fail(RT_E_UNSUPPORTED, "rt_softargmax: dtype %d", dtype);
     const int64_t hw = (int64_t)H * W;
     dim3 grid((unsigned)rt::cdiv(hw, 256), (unsigned)batch);
+    if (dtype == RT_F16) {          // kHALF volumes, NCHW (softargmax_plugin.cpp:51-54)
+        auto v = static_cast<const _Float16*>(vol);
+        auto o = static_cast<_Float16*>(out);
+        if (is_min) hipLaunchKernelGGL((rt::softargmax_f32_kernel<true, _Float16>), grid, dim3(256), 0, S(s), v, o, D, hw);
+        else hipLaunchKernelGGL((rt::softargmax_f32_kernel<false, _Float16>), grid, dim3(256), 0, S(s), v, o, D, hw);
+        RT_LAUNCH_CHECK("softargmax kernel (fp16)");
+        return 0;
+    }
     if (is_min)
         hipLaunchKernelGGL((rt::softargmax_f32_kernel<true>), grid, dim3(256), 0, S(s), static_cast<const float*>(vol),
                            static_cast<float*>(out), D, hw);

@@ -126,6 +126,25 @@ def test_corr_random_fp16_nc2hw2(backend, shape, D):
     near(got, O.corr_cost_volume(T(l), T(r), D).numpy(), 1e-2 * scale)
 
 
+@pytest.mark.parametrize("is_min", [False, True])
+def test_softargmax_fp16(backend, is_min):
+    """kHALF volumes in NCHW (softargmax_plugin.cpp:51-54): fp16 in and out, fp32 arithmetic in between"""
+    n, d, h, w = 2, 12, 9, 33
+    vol = (rnd(n, d, h, w) * np.float32(3)).astype(np.float16)
+    ref = O.softargmax(T(vol.astype(np.float32)), is_min).numpy()
+    if backend.name == "gpu":
+        src, dst = torch.from_numpy(vol).cuda(), torch.full((n, 1, h, w), float("nan"), dtype=torch.float16, device="cuda")
+        backend.klib.softargmax(src, dst, n, d, h, w, is_min, dtype=capi.RT_F16)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy().astype(np.float32)
+    else:
+        src, dst = np.ascontiguousarray(vol), np.full((n, 1, h, w), np.nan, np.float16)
+        backend.klib.softargmax(src, dst, n, d, h, w, is_min, dtype=capi.RT_F16)
+        got = dst.astype(np.float32)
+    near(got, ref, 1e-2)                                     # the reference's fp16 tolerance (tests_main.cpp:320)
+    near(got, ref.astype(np.float16).astype(np.float32), 8e-3)   # at most one half ulp below 16
+
+
 def test_corr_softargmax_into_concat_buffer(backend):
     """out_batch_stride places the result in channel 32 of a 33-channel buffer (resnet18_2D net :601-615)"""
     n, c, h, w, D = 2, 8, 6, 40, 12
