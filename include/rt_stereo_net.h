@@ -44,6 +44,12 @@ int rt_net_execute(rtStereoNet* net, const void* left, const void* right, void* 
 int rt_net_profile(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, char* buf,
                    size_t buf_bytes);
 
+/* Engine plan: ICudaEngine::serialize() (sample_app/main.cpp:269-275).  buf == NULL queries the size.  Fails for
+ * networks with non-serialisable plugins (the 3-D models), as the reference does. */
+int rt_net_serialize(rtStereoNet* net, void* buf, size_t buf_bytes, size_t* plan_bytes);
+/* IRuntime::deserializeCudaEngine(plan, size, &StereoDnnPluginFactory) + createExecutionContext
+ * (sample_app/main.cpp:198-220; lib/internal_utils.cpp:289-313). */
+int rt_net_create_from_plan(rtStereoNet** net, const void* plan, size_t plan_bytes);
 int rt_net_num_layers(const rtStereoNet* net);     /* layers of the network definition  */
 int rt_net_num_launches(const rtStereoNet* net);   /* kernel launches after fusion       */
 int rt_net_destroy(rtStereoNet* net);

@@ -224,6 +224,8 @@ NET_SYMBOLS = {
     "rt_net_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_char_p]),
     "rt_net_create_from_memory": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           c_size_t]),
+    "rt_net_serialize": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]),
+    "rt_net_create_from_plan": (c_int, [POINTER(c_void_p), c_void_p, c_size_t]),
     "rt_net_execute": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_net_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_char_p, c_size_t]),
     "rt_net_num_layers": (c_int, [c_void_p]),
@@ -278,6 +280,12 @@ class NetLib:
         self.check(rc, "rt_net_create")
         return StereoNet(self, h, width, height)
 
+    def create_from_plan(self, plan, width, height):
+        """IRuntime::deserializeCudaEngine on bytes returned by StereoNet.serialize()"""
+        h = c_void_p()
+        self.check(self.lib.rt_net_create_from_plan(ctypes.byref(h), plan, len(plan)), "rt_net_create_from_plan")
+        return StereoNet(self, h, width, height)
+
 
 class StereoNet:
     def __init__(self, netlib, handle, width, height):
@@ -304,6 +312,14 @@ class StereoNet:
             name, ms = line.rsplit("\t", 1)
             rows.append((name, float(ms)))
         return rows
+
+    def serialize(self):
+        """engine plan bytes (ICudaEngine::serialize)"""
+        n = ctypes.c_size_t()
+        self.netlib.check(self.netlib.lib.rt_net_serialize(self.handle, None, 0, ctypes.byref(n)), "rt_net_serialize")
+        buf = ctypes.create_string_buffer(n.value)
+        self.netlib.check(self.netlib.lib.rt_net_serialize(self.handle, buf, n.value, ctypes.byref(n)), "rt_net_serialize")
+        return buf.raw
 
     def destroy(self):
         if self.handle:

@@ -418,6 +418,8 @@ private:
     void assignPitch();
     bool ok_ = false;
     bool half2_ = false;
+public:
+    std::vector<std::unique_ptr<char[]>> weight_store_;   // weight bytes of a deserialised plan (Weights.values point here)
 };
 
 // ---- building ------------------------------------------------------------------------------------------------
@@ -795,23 +797,99 @@ void EngineImpl::assignStreams() {
             for (int w : o2.wait_on) op.publish |= (w == root(op.out));
 }
 
-IHostMemory* EngineImpl::serialize() const {
-    // Plan = the serialisable plugins' blobs in layer order (same blobs StereoDnnPluginFactory reads);
-    // the graph itself is rebuilt from the network builder, so this is a plugin manifest rather than
-    // a TensorRT plan.  See INTEGRATION.md.
-    auto* m = new HostMemory();
-    for (auto& l : layers_) {
-        if (!l->plugin) continue;
-        const size_t n = l->plugin->getSerializationSize();
-        if (!n) continue;
-        std::string b(n, '\0');
-        l->plugin->serialize(&b[0]);
-        uint32_t len = (uint32_t)n;
-        m->blob.append(reinterpret_cast<const char*>(&len), 4);
-        m->blob.append(l->name);
-        m->blob.push_back('\0');
-        m->blob.append(b);
+// ---- plan (de)serialisation ------------------------------------------------------------------------------------
+// A plan is the recorded sequence of network-building calls (inputs, layers with their parameters and weights,
+// plugin blobs exactly as IPlugin::serialize() wrote them, outputs) plus the builder settings.  Deserialising replays
+// the calls into a fresh INetworkDefinition -- plugins come back through IPluginFactory::createPlugin(layerName,
+// blob, size), as TensorRT does it (sample_app/main.cpp:198-220, lib/internal_utils.cpp:289-313) -- and builds the
+// engine again, which takes milliseconds here because there is no kernel autotuning step.  Like in the reference only
+// networks whose plugins are all serialisable have a plan (ELU / cost volume / soft-argmax: ResNet-18 2D); the 3-D
+// convolution plugins are not serialisable there either (lib/conv3d_plugin.cpp: getSerializationSize() == 0).
+namespace plan {
+constexpr char kMagic[8] = {'R', 'T', 'S', 'D', 'P', 'L', 'N', '1'};
+struct Writer {
+    std::string out;
+    void raw(const void* p, size_t n) { out.append(static_cast<const char*>(p), n); }
+    template <typename T> void pod(T v) { raw(&v, sizeof(T)); }
+    void str(const std::string& s) { pod<uint32_t>((uint32_t)s.size()); raw(s.data(), s.size()); }
+    void dims(const Dims& d) { pod<int32_t>(d.nbDims); for (int i = 0; i < 8; i++) pod<int32_t>(d.d[i]); }
+    void hw(const DimsHW& d) { pod<int32_t>(d.h()); pod<int32_t>(d.w()); }
+    void weights(const Weights& w) {
+        pod<int32_t>((int32_t)w.type);
+        pod<int64_t>(w.count);
+        raw(w.values, (size_t)w.count * (w.type == DataType::kHALF ? 2 : 4));
     }
+};
+struct Reader {
+    const char* p; const char* end; bool ok = true;
+    bool need(size_t n) { if ((size_t)(end - p) < n) ok = false; return ok; }
+    template <typename T> T pod() { T v{}; if (need(sizeof(T))) { std::memcpy(&v, p, sizeof(T)); p += sizeof(T); } return v; }
+    std::string str() { uint32_t n = pod<uint32_t>(); std::string s; if (need(n)) { s.assign(p, n); p += n; } return s; }
+    Dims dims() { Dims d{}; d.nbDims = pod<int32_t>(); for (int i = 0; i < 8; i++) d.d[i] = pod<int32_t>(); return d; }
+    DimsHW hw() { int h = pod<int32_t>(), w = pod<int32_t>(); return DimsHW{h, w}; }
+};
+}  // namespace plan
+
+IHostMemory* EngineImpl::serialize() const {
+    plan::Writer w;
+    w.raw(plan::kMagic, 8);
+    w.pod<int32_t>(max_batch_);
+    w.pod<uint8_t>(half2_ ? 1 : 0);
+    std::vector<const TensorImpl*> inputs, outputs;
+    for (int b : bindings_) (tensors_[b]->is_input ? inputs : outputs).push_back(tensors_[b].get());
+    // tensor numbers in the plan are canonical (inputs, then layer outputs in layer order), so a plan survives a
+    // deserialise / serialise round trip byte for byte
+    std::map<int, int32_t> num;
+    for (auto* t : inputs) num.emplace(t->id, (int32_t)num.size());
+    for (auto& l : layers_)
+        for (auto* t : l->out) num.emplace(t->id, (int32_t)num.size());
+    auto id_of = [&](const TensorImpl* t) { return num.at(t->id); };
+    w.pod<uint32_t>((uint32_t)inputs.size());
+    for (auto* t : inputs) { w.pod<int32_t>(id_of(t)); w.str(t->name); w.dims(t->dims); }
+    w.pod<uint32_t>((uint32_t)layers_.size());
+    for (auto& l : layers_) {
+        w.pod<int32_t>((int32_t)l->type);
+        w.str(l->name);
+        w.pod<uint32_t>((uint32_t)l->in.size());
+        for (auto* t : l->in) w.pod<int32_t>(id_of(t));
+        w.pod<uint32_t>((uint32_t)l->out.size());
+        for (auto* t : l->out) { w.pod<int32_t>(id_of(t)); w.str(t->name); }
+        switch (l->type) {
+            case LayerType::kCONVOLUTION:
+            case LayerType::kDECONVOLUTION:
+                w.pod<int32_t>(l->nb_maps); w.hw(l->ksize); w.hw(l->stride); w.hw(l->padding);
+                w.weights(l->kernel); w.weights(l->bias);
+                break;
+            case LayerType::kSCALE:
+                w.pod<int32_t>((int32_t)l->scale_mode); w.weights(l->shift); w.weights(l->scale); w.weights(l->power);
+                break;
+            case LayerType::kACTIVATION: w.pod<int32_t>((int32_t)l->act); break;
+            case LayerType::kELEMENTWISE: w.pod<int32_t>((int32_t)l->ew); break;
+            case LayerType::kCONCATENATION: break;
+            case LayerType::kPADDING: w.hw(l->pre_pad); w.hw(l->post_pad); break;
+            case LayerType::kSHUFFLE: w.dims(l->reshape); break;
+            case LayerType::kPLUGIN: {
+                const size_t n = l->plugin->getSerializationSize();
+                if (!n) {
+                    log_.log(ILogger::Severity::kERROR, (l->name + ": plugin is not serialisable, this engine has no plan "
+                             "(same as the reference's Conv3D / Transform / Pad / Slice plugins)").c_str());
+                    return nullptr;
+                }
+                std::string blob(n, '\0');
+                l->plugin->serialize(&blob[0]);
+                w.pod<uint8_t>(l->plugin_ext ? 1 : 0);
+                w.str(blob);
+                break;
+            }
+            default:
+                log_.log(ILogger::Severity::kERROR, (l->name + ": layer type cannot be serialised").c_str());
+                return nullptr;
+        }
+    }
+    w.pod<uint32_t>((uint32_t)outputs.size());
+    for (auto* t : outputs) w.pod<int32_t>(id_of(t));
+    auto* m = new HostMemory();
+    m->blob = std::move(w.out);
     return m;
 }
 
@@ -1049,11 +1127,127 @@ private:
 class RuntimeImpl : public IRuntime {
 public:
     explicit RuntimeImpl(ILogger& log) : log_(log) {}
-    ICudaEngine* deserializeCudaEngine(const void*, std::size_t, IPluginFactory*) override {
-        log_.log(ILogger::Severity::kERROR,
-                 "deserializeCudaEngine: TensorRT plan files are not portable to this runtime; rebuild the engine from the "
-                 "network builder (takes milliseconds here, there is no kernel autotuning step)");
-        return nullptr;
+    ICudaEngine* deserializeCudaEngine(const void* blob, std::size_t size, IPluginFactory* factory) override {
+        auto fail = [&](const std::string& msg) -> ICudaEngine* {
+            log_.log(ILogger::Severity::kERROR, ("deserializeCudaEngine: " + msg).c_str());
+            return nullptr;
+        };
+        if (!blob || size < 8 || std::memcmp(blob, plan::kMagic, 8) != 0)
+            return fail("not a plan of this runtime (TensorRT plan files are not portable: rebuild the engine from the network "
+                        "builder, which takes milliseconds here)");
+        plan::Reader r{static_cast<const char*>(blob) + 8, static_cast<const char*>(blob) + size};
+        const int max_batch = r.pod<int32_t>();
+        const bool half2 = r.pod<uint8_t>() != 0;
+        std::unique_ptr<NetworkImpl> net(new NetworkImpl(log_));
+        std::vector<std::unique_ptr<char[]>> store;
+        std::map<int, ITensor*> tensor;
+        auto weights = [&]() {
+            Weights w{};
+            w.type = (DataType)r.pod<int32_t>();
+            w.count = r.pod<int64_t>();
+            const size_t bytes = (size_t)w.count * (w.type == DataType::kHALF ? 2 : 4);
+            if (w.count < 0 || !r.need(bytes)) { r.ok = false; w.count = 0; return w; }
+            store.emplace_back(new char[bytes ? bytes : 1]);
+            std::memcpy(store.back().get(), r.p, bytes);
+            r.p += bytes;
+            w.values = w.count ? store.back().get() : nullptr;
+            return w;
+        };
+        const uint32_t nin = r.pod<uint32_t>();
+        for (uint32_t i = 0; i < nin && r.ok; i++) {
+            const int id = r.pod<int32_t>();
+            const std::string name = r.str();
+            const Dims d = r.dims();
+            tensor[id] = net->addInput(name.c_str(), DataType::kFLOAT, d);
+        }
+        const uint32_t nl = r.pod<uint32_t>();
+        for (uint32_t li = 0; li < nl && r.ok; li++) {
+            const LayerType type = (LayerType)r.pod<int32_t>();
+            const std::string name = r.str();
+            std::vector<ITensor*> ins;
+            const uint32_t ni = r.pod<uint32_t>();
+            for (uint32_t i = 0; i < ni && r.ok; i++) {
+                auto it = tensor.find(r.pod<int32_t>());
+                if (it == tensor.end()) return fail(name + ": input tensor defined after use");
+                ins.push_back(it->second);
+            }
+            std::vector<std::pair<int, std::string>> outs;
+            const uint32_t no = r.pod<uint32_t>();
+            for (uint32_t i = 0; i < no && r.ok; i++) { const int id = r.pod<int32_t>(); outs.emplace_back(id, r.str()); }
+            if (!r.ok || ins.empty()) return fail("truncated plan");
+            ILayer* layer = nullptr;
+            switch (type) {
+                case LayerType::kCONVOLUTION:
+                case LayerType::kDECONVOLUTION: {
+                    const int maps = r.pod<int32_t>();
+                    const DimsHW k = r.hw(), st = r.hw(), pad = r.hw();
+                    const Weights kw = weights(), bw = weights();
+                    if (!r.ok) break;
+                    if (type == LayerType::kCONVOLUTION) {
+                        auto* c = net->addConvolution(*ins[0], maps, k, kw, bw);
+                        c->setStride(st); c->setPadding(pad);
+                        layer = c;
+                    } else {
+                        auto* c = net->addDeconvolution(*ins[0], maps, k, kw, bw);
+                        c->setStride(st); c->setPadding(pad);
+                        layer = c;
+                    }
+                    break;
+                }
+                case LayerType::kSCALE: {
+                    const ScaleMode mode = (ScaleMode)r.pod<int32_t>();
+                    const Weights a = weights(), b = weights(), c = weights();
+                    if (r.ok) layer = net->addScale(*ins[0], mode, a, b, c);
+                    break;
+                }
+                case LayerType::kACTIVATION: layer = net->addActivation(*ins[0], (ActivationType)r.pod<int32_t>()); break;
+                case LayerType::kELEMENTWISE:
+                    if (ins.size() != 2) return fail(name + ": element-wise layer needs two inputs");
+                    layer = net->addElementWise(*ins[0], *ins[1], (ElementWiseOperation)r.pod<int32_t>());
+                    break;
+                case LayerType::kCONCATENATION: layer = net->addConcatenation(ins.data(), (int)ins.size()); break;
+                case LayerType::kPADDING: { const DimsHW a = r.hw(), b = r.hw(); layer = net->addPadding(*ins[0], a, b); break; }
+                case LayerType::kSHUFFLE: {
+                    auto* sh = net->addShuffle(*ins[0]);
+                    sh->setReshapeDimensions(r.dims());
+                    layer = sh;
+                    break;
+                }
+                case LayerType::kPLUGIN: {
+                    const bool ext = r.pod<uint8_t>() != 0;
+                    const std::string pb = r.str();
+                    if (!r.ok) break;
+                    if (!factory) return fail(name + ": the plan contains plugin layers but no IPluginFactory was given");
+                    IPlugin* plugin = factory->createPlugin(name.c_str(), pb.data(), pb.size());
+                    if (!plugin) return fail(name + ": the plugin factory could not re-create the plugin");
+                    layer = ext ? net->addPluginExt(ins.data(), (int)ins.size(), *static_cast<IPluginExt*>(plugin))
+                                : net->addPlugin(ins.data(), (int)ins.size(), *plugin);
+                    break;
+                }
+                default: return fail(name + ": unknown layer type in plan");
+            }
+            if (!r.ok || !layer) return fail("truncated or inconsistent plan at layer " + name);
+            layer->setName(name.c_str());
+            if ((int)outs.size() != layer->getNbOutputs()) return fail(name + ": output count mismatch");
+            for (size_t i = 0; i < outs.size(); i++) {
+                layer->getOutput((int)i)->setName(outs[i].second.c_str());
+                tensor[outs[i].first] = layer->getOutput((int)i);
+            }
+        }
+        const uint32_t nout = r.pod<uint32_t>();
+        for (uint32_t i = 0; i < nout && r.ok; i++) {
+            auto it = tensor.find(r.pod<int32_t>());
+            if (it == tensor.end()) return fail("output tensor missing");
+            net->markOutput(*it->second);
+        }
+        if (!r.ok) return fail("truncated plan");
+        auto* e = new EngineImpl(*net, max_batch, half2, log_);
+        if (!e->ok()) {
+            delete e;
+            return fail("engine build failed");
+        }
+        e->weight_store_ = std::move(store);
+        return e;
     }
     void destroy() override { delete this; }
 private:

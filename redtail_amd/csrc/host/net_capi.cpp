@@ -162,6 +162,43 @@ extern "C" int rt_net_create_from_memory(rtStereoNet** net, int model, int width
     return build(net, model, width, height, max_batch, dtype, max_disp, std::move(copy));
 }
 
+// Engine plan = what ICudaEngine::serialize() returns (sample_app/main.cpp:269-275 caches it in a .plan file).
+// Call with buf == NULL to query the size.  Networks with non-serialisable plugins (the 3-D models) have no plan,
+// exactly as in the reference.
+extern "C" int rt_net_serialize(rtStereoNet* net, void* buf, size_t buf_bytes, size_t* plan_bytes) {
+    if (!net || !plan_bytes) return fail("rt_net_serialize: null pointer");
+    IHostMemory* m = net->engine->serialize();
+    if (!m) return fail("rt_net_serialize: " + net->log.last_error);
+    *plan_bytes = m->size();
+    int rc = 0;
+    if (buf) {
+        if (buf_bytes < m->size()) rc = fail("rt_net_serialize: buffer too small");
+        else memcpy(buf, m->data(), m->size());
+    }
+    m->destroy();
+    return rc;
+}
+
+// Counterpart of sample_app/main.cpp:198-220: IRuntime::deserializeCudaEngine(plan, size, &StereoDnnPluginFactory).
+extern "C" int rt_net_create_from_plan(rtStereoNet** out, const void* plan, size_t plan_bytes) {
+    if (!out || !plan || !plan_bytes) return fail("rt_net_create_from_plan: null pointer");
+    std::unique_ptr<rtStereoNet> n(new rtStereoNet());
+    n->plugins = IPluginContainer::create(n->log);
+    StereoDnnPluginFactory factory(*n->plugins);
+    IRuntime* runtime = createInferRuntime(n->log);
+    n->engine = runtime->deserializeCudaEngine(plan, plan_bytes, &factory);
+    runtime->destroy();
+    if (!n->engine) return fail("rt_net_create_from_plan: " + n->log.last_error);
+    if (n->engine->getNbBindings() != 3 || n->engine->getBindingIndex("left") != 0 || n->engine->getBindingIndex("right") != 1 ||
+        n->engine->getBindingIndex("disp") != 2)
+        return fail("rt_net_create_from_plan: unexpected bindings");
+    n->max_batch = n->engine->getMaxBatchSize();
+    n->context = n->engine->createExecutionContext();
+    if (!n->context) return fail("rt_net_create_from_plan: context creation failed");
+    *out = n.release();
+    return 0;
+}
+
 extern "C" int rt_net_execute(rtStereoNet* net, const void* left, const void* right, void* disp, int batch, rtStream stream) {
     if (!net || !left || !right || !disp) return fail("rt_net_execute: null pointer");
     void* bindings[3] = {const_cast<void*>(left), const_cast<void*>(right), disp};

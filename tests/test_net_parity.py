@@ -118,6 +118,35 @@ def test_nvtiny_unfused_equals_fused(rt, monkeypatch):
     assert np.abs(fused - unfused).max() <= 1e-4
 
 
+def test_plan_round_trip(rt):
+    """ICudaEngine::serialize -> IRuntime::deserializeCudaEngine with StereoDnnPluginFactory (sample_app/main.cpp:198-220,
+    269-275): the re-created engine must produce the same bits; the 3-D models have no plan, as in the reference
+    (their Conv3D / Transform / Pad / Slice plugins are not serialisable)."""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 25, 41)
+    net = rt.lib.create("resnet18_2D", 41, 25, max_batch=2, weights=w, max_disp=8)
+    ref = rt.empty(2, 1, 25, 41)
+    net.execute(rt.dev(l), rt.dev(r), ref, 2)
+    ref = rt.host(ref).copy()
+    plan = net.serialize()
+    net.destroy()
+    assert plan[:8] == b"RTSDPLN1" and len(plan) > 3_000_000          # carries the 3.6 MB of weights
+    net2 = rt.lib.create_from_plan(plan, 41, 25)
+    out = rt.empty(2, 1, 25, 41)
+    net2.execute(rt.dev(l), rt.dev(r), out, 2)
+    assert np.array_equal(rt.host(out), ref)
+    assert net2.serialize() == plan                                     # and serialises to the same bytes again
+    net2.destroy()
+    with pytest.raises(capi.RtError):
+        rt.lib.create_from_plan(plan[:len(plan) // 2], 41, 25)          # truncated
+    with pytest.raises(capi.RtError):
+        rt.lib.create_from_plan(b"not a plan" * 10, 41, 25)
+    net3 = rt.lib.create("nvtiny", 65, 33, weights=O.synth_weights_3d(O.NVTINY_3D), max_disp=8)
+    with pytest.raises(capi.RtError):
+        net3.serialize()
+    net3.destroy()
+
+
 def test_bad_inputs_fail_loudly(rt):
     w = O.synth_weights_resnet18_2d()
     with pytest.raises(capi.RtError):
