@@ -217,6 +217,46 @@ def main():
                 "mb_per_pair": mb / b, "gb_per_s": mb * args.steps / dt1 / 1e3,
                 "note": "H2D of both images + D2H of the disparity per pair, pinned host memory, overlapped"}
         assert torch.equal(h_out[0], disps[0].cpu()), "host copy of the disparity differs"
+
+        # same pipeline with camera-format I/O: u8 BGR frames in (3 bytes per pixel instead of 12), pre-processing
+        # and the 16-bit KITTI encoding of the disparity on the device (rt_preprocess_bgr8 / rt_disparity_to_u16)
+        k = lib.kernels
+        to_u8 = lambda t: (t.cpu().flip(1).permute(0, 2, 3, 1) * 255).round().clamp(0, 255).to(torch.uint8).contiguous()
+        h_l8, h_r8 = to_u8(left).pin_memory(), to_u8(right).pin_memory()
+        d_l8 = [[torch.empty_like(h_l8, device=dev) for _ in range(NBUF)] for _ in nets]
+        d_r8 = [[torch.empty_like(h_r8, device=dev) for _ in range(NBUF)] for _ in nets]
+        d_u16 = [torch.empty(b, 1, H, W, dtype=torch.int16, device=dev) for _ in nets]
+        h_u16 = [torch.empty(b, 1, H, W, dtype=torch.int16).pin_memory() for _ in nets]
+
+        def host_step_u8(i):
+            c, q = i % nctx, (i // nctx) % NBUF
+            with torch.cuda.stream(copy_streams[c]):
+                copy_streams[c].wait_event(consumed[c][q])
+                d_l8[c][q].copy_(h_l8, non_blocking=True)
+                d_r8[c][q].copy_(h_r8, non_blocking=True)
+                copied[c][q].record()
+            streams[c].wait_event(copied[c][q])
+            sh_ = streams[c].cuda_stream
+            k.preprocess_bgr8(d_l8[c][q], H, W, d_l[c][q], H, W, b, stream=sh_)
+            k.preprocess_bgr8(d_r8[c][q], H, W, d_r[c][q], H, W, b, stream=sh_)
+            nets[c].execute(d_l[c][q], d_r[c][q], disps[c], b, stream=sh_)
+            k.disparity_to_u16(disps[c], d_u16[c], b * H * W, 256.0 * W, stream=sh_)
+            with torch.cuda.stream(streams[c]):
+                consumed[c][q].record()
+                h_u16[c].copy_(d_u16[c], non_blocking=True)
+
+        for i in range(args.warmup):
+            host_step_u8(i)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            host_step_u8(i)
+        torch.cuda.synchronize(dev)
+        dt1 = time.perf_counter() - t1
+        mb8 = (h_l8.numel() + h_r8.numel() + 2 * h_u16[0].numel()) / 1e6
+        pcie["u8_frames"] = {"value": args.steps * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / args.steps / b * 1e3,
+                             "mb_per_pair": mb8 / b,
+                             "note": "u8 BGR frames in, 16-bit disparity out, pre/post-processing on the device"}
     for d in disps:
         assert torch.isfinite(d).all(), "non-finite disparity"
         assert torch.equal(d, disps[0]), "contexts disagree"

@@ -119,6 +119,16 @@ int rt_slice_d(const void* x, void* y, int batch, int D, int64_t inner, int star
 int rt_concat_channels(const void* x, void* y, int batch, int C, int Ctot, int c_off, int64_t inner, int dtype,
                        rtStream stream);
 
+/* ---- image front-end / back-end of the sample application ----------------------------------- */
+/* u8 BGR HWC image(s) (N, src_h, src_w, 3) -> float RGB CHW (N, 3, dst_h, dst_w) in [0,1]: convertTo(CV_32F),
+ * cv::resize(INTER_AREA) (down-scaling or same size), BGR -> RGB, HWC -> CHW, / 255 of readImgFile
+ * (sample_app/main.cpp:83-98; stereo_dnn_ros_node.cpp:42-103), on the device. */
+int rt_preprocess_bgr8(const void* src_u8, int src_h, int src_w, void* dst_f32, int dst_h, int dst_w, int batch,
+                       rtStream stream);
+/* disparity map -> 16-bit KITTI encoding: saturate_cast<ushort>(round(disp * scale)), scale = 256 (x width for the
+ * normalised output of ResNet-18 2D), sample_app/main.cpp:324-330. */
+int rt_disparity_to_u16(const void* disp_f32, void* out_u16, int64_t n, float scale, rtStream stream);
+
 /* ---- convolutions (MFMA implicit GEMM) ----------------------------------------------------- */
 /* A plan owns the device copy of the (re-packed) weights, bias and gather tables of one layer,
  * like Conv3DPlugin::configure owns kernel_weights_d_ (lib/conv3d_plugin.cpp:122-133). */

@@ -162,6 +162,46 @@ def deconv2d(x, w, b, stride, pad):
 # --------------------------------------------------------------------------------------
 # Weight files (scripts/tensorrt_model_builder.py:52-60; reader sample_app/main.cpp:111-134)
 # --------------------------------------------------------------------------------------
+def _area_table(ssize, dsize):
+    """per destination index: list of (source index, weight) -- OpenCV's computeResizeAreaTab for scale >= 1
+    (the INTER_AREA path cv::resize takes when shrinking; modules/imgproc/src/resize.cpp)"""
+    scale = ssize / dsize
+    tab = []
+    for dx in range(dsize):
+        f1 = dx * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1, s2 = int(np.ceil(f1)), min(int(np.floor(f2)), ssize)
+        s1 = min(s1, s2)
+        taps = []
+        if s1 - f1 > 1e-3:
+            taps.append((s1 - 1, (s1 - f1) / cell))
+        for sx in range(s1, s2):
+            taps.append((sx, 1.0 / cell))
+        if f2 - s2 > 1e-3 and s2 < ssize:
+            taps.append((s2, min(min(f2 - s2, 1.0), cell) / cell))
+        tab.append(taps)
+    return tab
+
+
+def preprocess_bgr8(img_u8, dst_h, dst_w):
+    """readImgFile (sample_app/main.cpp:83-98): u8 BGR HWC -> float32, cv::resize(INTER_AREA), BGR -> RGB, HWC -> CHW,
+    / 255.  PARITY UNPINNED: OpenCV is not available in this environment, the area filter restates its published
+    table construction; only shrinking / same size (what the apps do with KITTI frames)."""
+    sh, sw, _ = img_u8.shape
+    x = img_u8.astype(np.float64)
+    if (sh, sw) != (dst_h, dst_w):
+        ty, tx = _area_table(sh, dst_h), _area_table(sw, dst_w)
+        rows = np.stack([sum(wgt * x[sy] for sy, wgt in taps) for taps in ty])                 # (dst_h, sw, 3)
+        x = np.stack([sum(wgt * rows[:, sx] for sx, wgt in taps) for taps in tx], axis=1)      # (dst_h, dst_w, 3)
+    return (x[:, :, ::-1].transpose(2, 0, 1) / 255.0).astype(np.float32)
+
+
+def disparity_to_u16(disp, scale):
+    """main.cpp:324-330: img_f *= 256 (* w); convertTo(CV_16U) = saturate_cast<ushort>(cvRound(x)), round half to even"""
+    return np.clip(np.rint(disp.astype(np.float32) * np.float32(scale)), 0, 65535).astype(np.uint16)
+
+
 def read_weights(path, fp16=False):
     raw = open(path, "rb").read()
     off, out = 0, {}

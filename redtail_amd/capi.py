@@ -70,6 +70,8 @@ KERNEL_SYMBOLS = {
     "rt_conv3d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), c_void_p, c_void_p]),
     "rt_conv3d_transpose_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), POINTER(c_int), c_void_p,
                                                 c_void_p]),
+    "rt_preprocess_bgr8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -128,6 +130,13 @@ class KernelLib:
     def corr_cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, fmt=RT_NCHW, stream=None):
         self.check(self.lib.rt_corr_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, stream),
                    "rt_corr_cost_volume")
+
+    def preprocess_bgr8(self, src, src_h, src_w, dst, dst_h, dst_w, batch=1, stream=None):
+        self.check(self.lib.rt_preprocess_bgr8(_ptr(src), src_h, src_w, _ptr(dst), dst_h, dst_w, batch, stream),
+                   "rt_preprocess_bgr8")
+
+    def disparity_to_u16(self, disp, out, n, scale, stream=None):
+        self.check(self.lib.rt_disparity_to_u16(_ptr(disp), _ptr(out), n, scale, stream), "rt_disparity_to_u16")
 
     def corr_softargmax_pitched(self, l, r, out, batch, C, H, W, D, is_min, in_pitch, out_pitch, out_bstride=0,
                                 dtype=RT_F32, stream=None):

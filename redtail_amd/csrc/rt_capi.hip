@@ -16,6 +16,7 @@
 #include "kernels/conv_mfma.hip.h"
 #include "kernels/conv_wino.hip.h"
 #include "kernels/deconv3d_small.hip.h"
+#include "kernels/imgproc.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -359,6 +360,33 @@ extern "C" int rt_concat_channels(const void* x, void* y, int batch, int C, int 
     RT_REQUIRE(c_off >= 0 && c_off + C <= Ctot, "rt_concat_channels: channel range out of bounds");
     char* dst = static_cast<char*>(y) + (size_t)c_off * inner * dsize(dtype);
     return copy_rows(x, dst, batch, C * inner, C * inner, Ctot * inner, 0, dtype, S(s));
+}
+
+// =================================================================================================
+// image front-end / back-end (sample_app/main.cpp:83-98, 324-330)
+// =================================================================================================
+extern "C" int rt_preprocess_bgr8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int batch,
+                                  rtStream s) {
+    RT_REQUIRE(src && dst, "rt_preprocess_bgr8: null pointer");
+    RT_REQUIRE(src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && batch > 0 && batch <= 65535 && dst_h <= 65535,
+               "rt_preprocess_bgr8: bad dims");
+    if (dst_h > src_h || dst_w > src_w)
+        return fail(RT_E_UNSUPPORTED, "rt_preprocess_bgr8: INTER_AREA up-scaling (%dx%d -> %dx%d) is not implemented", src_w, src_h, dst_w, dst_h);
+    if ((float)src_w / dst_w > 6.f || (float)src_h / dst_h > 6.f)
+        return fail(RT_E_UNSUPPORTED, "rt_preprocess_bgr8: scale factors above 6 are not implemented");
+    dim3 grid((unsigned)rt::cdiv(dst_w, 256), (unsigned)dst_h, (unsigned)batch);
+    hipLaunchKernelGGL(rt::preprocess_bgr8_kernel, grid, dim3(256), 0, S(s), static_cast<const unsigned char*>(src), src_h,
+                       src_w, static_cast<float*>(dst), dst_h, dst_w);
+    RT_LAUNCH_CHECK("preprocess_bgr8_kernel");
+    return 0;
+}
+
+extern "C" int rt_disparity_to_u16(const void* disp, void* out, int64_t n, float scale, rtStream s) {
+    RT_REQUIRE(disp && out && n > 0, "rt_disparity_to_u16: bad arguments");
+    hipLaunchKernelGGL(rt::disparity_u16_kernel, dim3((unsigned)rt::cdiv(n, 256)), dim3(256), 0, S(s),
+                       static_cast<const float*>(disp), static_cast<unsigned short*>(out), n, scale);
+    RT_LAUNCH_CHECK("disparity_u16_kernel");
+    return 0;
 }
 
 // =================================================================================================
