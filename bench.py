@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "4")),
                     help="IExecutionContexts per GPU, each with its own stream; steps are issued round-robin "
                          "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop")
+    ap.add_argument("--half2", action="store_true",
+                    help="TensorRT half2 mode (BASELINE config C3): fp16 weight file, activations stored as fp16 between "
+                         "launches, fp32 arithmetic; the JSON line then says dtype f16-storage")
     ap.add_argument("--from-host", action="store_true", help="also measure the PCIe-inclusive rate (extra JSON object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -121,14 +124,15 @@ def main():
     # ---- weights: rank 0 owns the file image, everyone else receives it over RCCL/xGMI ------------------
     if rank == 0:
         weights = synth.synth_weights_resnet18_2d(seed=7)
-        blob = capi.pack_weights(weights)
+        blob = capi.pack_weights(weights, fp16=args.half2)
     if distributed:
         import torch.distributed as dist
         blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
 
     lib = capi.NetLib()
     lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
-    nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob) for _ in range(args.contexts)]
+    nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob, fp16_weights=args.half2)
+            for _ in range(args.contexts)]
     net = nets[0]
 
     b = args.batch
@@ -276,8 +280,10 @@ def main():
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ResNet-18 2D Stereo DNN fp32, 1257x369, batch=%d per step, one MI355X per rank" % b,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 storage, f32 arithmetic" if args.half2 else "f32", "data": "synthetic",
+            "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
+                           "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,
                        "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3)",

@@ -162,6 +162,12 @@ int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const v
  * 128-byte aligned per row.  Tensors are then (N, C, H, pitch) in memory with W valid columns. */
 int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
 
+/* Storage type (RT_F32 / RT_F16) of the input and of the output + residual tensors of a 2-D plan: TensorRT's half2
+ * mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262) keeps activations in fp16 between layers; arithmetic
+ * stays fp32 here.  Supported: fp16 -> fp16 everywhere, fp32 -> fp16 (first layers) on the direct-form kernels,
+ * fp16 -> fp32 (last layer) on the small-output transposed kernel. */
+int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
+
 typedef struct rtConv3dDesc {
     int C, K;               /* conv: input channels C, output channels K.  Transposed op: K = INPUT   */
                             /* channels (tensor KDHW), C = OUTPUT channels (tensor DCHW)             */

@@ -74,6 +74,7 @@ KERNEL_SYMBOLS = {
     "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
+    "rt_conv_plan_set_io_types": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_plan_destroy": (c_int, [c_void_p]),
 }
@@ -205,6 +206,9 @@ class ConvPlan:
 
     def set_pitch(self, in_pitch, out_pitch):
         self.klib.check(self.klib.lib.rt_conv_plan_set_pitch(self.handle, in_pitch, out_pitch), "rt_conv_plan_set_pitch")
+
+    def set_io_types(self, x_dtype, y_dtype):
+        self.klib.check(self.klib.lib.rt_conv_plan_set_io_types(self.handle, x_dtype, y_dtype), "rt_conv_plan_set_io_types")
 
     def enqueue(self, x, y, residual=None, batch=1, stream=None):
         self.klib.check(self.klib.lib.rt_conv_enqueue(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream),

@@ -58,6 +58,7 @@ struct TensorImpl : public ITensor {
     void* dev = nullptr;
     int stream = 0;             // which of the two execution streams produces it
     int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
+    bool f16 = false;           // stored as fp16 (half2 mode); only tensors that only layout-aware launches touch
 
     void setName(const char* n) override { name = n ? n : ""; }
     const char* getName() const override { return name.c_str(); }
@@ -724,8 +725,8 @@ void EngineImpl::assignPitch() {
             if (op.kind == OpKind::kConv && op.resid >= 0 && P(op.resid) != P(op.out)) {
                 clear(op.resid); clear(op.out); changed = true;
             }
-            if (op.kind == OpKind::kCorrSoftargmax && P(op.in[0]) != P(op.in[1])) {
-                clear(op.in[0]); clear(op.in[1]); changed = true;
+            if (op.kind == OpKind::kCorrSoftargmax && (P(op.in[0]) != P(op.in[1]) || P(op.in[0]) != P(op.out))) {
+                clear(op.in[0]); clear(op.in[1]); clear(op.out); changed = true;   // one storage type for the fused kernel
             }
             if (op.kind == OpKind::kConcat) {
                 bool all = P(op.out), any = P(op.out);
@@ -738,20 +739,38 @@ void EngineImpl::assignPitch() {
             }
         }
     }
+    // half2 mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262): the same tensors are also stored as fp16 --
+    // TensorRT keeps activations in fp16 between its own layers and hands plugins what they asked for; arithmetic
+    // stays fp32 in the kernels.  Rows are then padded to 64 elements (128 bytes, and the even pitch the 2-pixel
+    // stores need).
+    const bool f16 = half2_ && !getenv("RT_NO_F16");
     for (auto& t : tensors_) {
         if (!ok[t->id]) continue;
         const char* ex = getenv("RT_PITCH_EXTRA");          // A/B knob: extra 128-byte lines per row
-        const int w = t->dims.d[2], pitch = (w + 31) / 32 * 32 + 32 * (ex ? atoi(ex) : 0);
+        const int q = f16 ? 64 : 32;
+        const int w = t->dims.d[2], pitch = (w + q - 1) / q * q + q * (ex ? atoi(ex) : 0);
         t->pitch = pitch == w ? 0 : pitch;
+        t->f16 = f16;
     }
-    for (auto& op : ops_) {
-        if (op.kind != OpKind::kConv) continue;
-        const int ip = tensors_[root(op.in[0])]->pitch, opi = tensors_[root(op.out)]->pitch;
-        if ((ip || opi) && rt_conv_plan_set_pitch(op.plan, ip, opi) != 0) {
-            log_.log(ILogger::Severity::kERROR, (op.name + ": " + rt_last_error_string()).c_str());
-            ok_ = false;
-            return;
+    auto apply = [&](bool with_f16) {
+        for (auto& op : ops_) {
+            if (op.kind != OpKind::kConv) continue;
+            const TensorImpl& x = *tensors_[root(op.in[0])];
+            const TensorImpl& y = *tensors_[root(op.out)];
+            if ((x.pitch || y.pitch) && rt_conv_plan_set_pitch(op.plan, x.pitch, y.pitch) != 0) return false;
+            if (rt_conv_plan_set_io_types(op.plan, with_f16 && x.f16 ? RT_F16 : RT_F32, with_f16 && y.f16 ? RT_F16 : RT_F32) != 0)
+                return false;
         }
+        return true;
+    };
+    if (!apply(f16)) {
+        if (f16) {       // a layer has no fp16 form (e.g. Winograd reading an fp32 binding): keep the whole engine fp32
+            log_.log(ILogger::Severity::kWARNING, (std::string("half2 mode: ") + rt_last_error_string() + " -- activations stay fp32").c_str());
+            for (auto& t : tensors_) t->f16 = false;
+            if (apply(false)) return;
+        }
+        log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+        ok_ = false;
     }
 }
 
@@ -932,7 +951,7 @@ bool ContextImpl::ensureBuffers(int batch) {
         }
         if (!used) continue;
         const size_t elems = t->pitch ? (size_t)t->dims.d[0] * t->dims.d[1] * t->pitch : (size_t)volume(t->dims);
-        if (rt_malloc(&buffers_[t->id], elems * sizeof(float) * (size_t)batch) != 0) {
+        if (rt_malloc(&buffers_[t->id], elems * (t->f16 ? 2 : 4) * (size_t)batch) != 0) {
             eng_.log_.log(ILogger::Severity::kERROR, (std::string("engine: device allocation failed: ") + rt_last_error_string()).c_str());
             return false;
         }
@@ -1036,7 +1055,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 for (int i : op.in) {
                     const Dims& d = eng_.tensors_[i]->dims;
                     if (rc == 0)
-                        rc = rt_concat_channels(addr(i, batch, bindings), y, batch, d.d[0], ctot, coff, inner, RT_F32, st);
+                        rc = rt_concat_channels(addr(i, batch, bindings), y, batch, d.d[0], ctot, coff, inner, out.f16 ? RT_F16 : RT_F32, st);
                     coff += d.d[0];
                 }
                 break;
@@ -1045,7 +1064,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
                 rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
                                                 f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
-                                                0, RT_F32, st);
+                                                0, out.f16 ? RT_F16 : RT_F32, st);
                 break;
             }
             case OpKind::kCopy:

@@ -126,6 +126,7 @@ int build(rtStereoNet** out, int model, int width, int height, int max_batch, in
     }
     n->layers = net->getNbLayers();
     builder->setMaxBatchSize(max_batch);
+    builder->setHalf2Mode(dtype == RT_F16);        // fp16 weight file = fp16 inference, as in sample_app/main.cpp:256-262
     builder->setMaxWorkspaceSize((size_t)1 << 30);
     n->engine = builder->buildCudaEngine(*net);
     net->destroy();

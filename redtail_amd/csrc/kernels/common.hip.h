@@ -72,4 +72,41 @@ __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned v
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
 
+// ---- storage-type generic element access ---------------------------------------------------------------------
+// Activations are stored as fp32 or (TensorRT "half2 mode": setHalf2Mode + fp16 weights, sample_app/main.cpp:256-262)
+// as fp16; arithmetic is fp32 either way (what the reference's fp16 correlation kernel does too,
+// lib/kernels.cu:219-221).  Offsets are BYTES, ES = element size; the 2-element forms need 2*ES alignment, which
+// the executor guarantees through even row pitches.
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static constexpr unsigned ES = 4;
+    __device__ static __forceinline__ float load(buf_rsrc r, unsigned vo, unsigned so) { return buf_load(r, vo, so); }
+    __device__ static __forceinline__ f32x2_t load2(buf_rsrc r, unsigned vo, unsigned so) { return buf_load2(r, vo, so); }
+    __device__ static __forceinline__ void store(float v, buf_rsrc r, unsigned vo, unsigned so) { buf_store(v, r, vo, so); }
+    __device__ static __forceinline__ void store2(f32x2_t v, buf_rsrc r, unsigned vo, unsigned so) { buf_store2(v, r, vo, so); }
+};
+template <> struct Io<_Float16> {
+    static constexpr unsigned ES = 2;
+    __device__ static __forceinline__ float load(buf_rsrc r, unsigned vo, unsigned so) {
+        const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0);
+        return (float)__builtin_bit_cast(_Float16, u);
+    }
+    __device__ static __forceinline__ f32x2_t load2(buf_rsrc r, unsigned vo, unsigned so) {
+        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0);
+        return f32x2_t{(float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)),
+                       (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))};
+    }
+    __device__ static __forceinline__ void store(float v, buf_rsrc r, unsigned vo, unsigned so) {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, vo, so, 0);
+    }
+    __device__ static __forceinline__ void store2(f32x2_t v, buf_rsrc r, unsigned vo, unsigned so) {
+        const unsigned a = __builtin_bit_cast(unsigned short, (_Float16)v[0]), b = __builtin_bit_cast(unsigned short, (_Float16)v[1]);
+        __builtin_amdgcn_raw_buffer_store_b32(a | (b << 16), r, vo, so, 0);
+    }
+};
+// base + n elements of size ES (tensor pointers travel as float* whatever the storage type)
+__device__ static __forceinline__ const char* elem_ptr(const void* base, int64_t elems, unsigned es) {
+    return static_cast<const char*>(base) + elems * (int64_t)es;
+}
+
 }  // namespace rt

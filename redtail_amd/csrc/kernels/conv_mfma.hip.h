@@ -133,9 +133,11 @@ struct ConvCfg {
     static_assert(W_ELEMS % 4 == 0, "weight slab is copied as float4");
 };
 
-template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS>
+// TIN / TOUT: storage type of the input and of the output + residual (float, or _Float16 in half2 mode)
+template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(64 * NW, (ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>::MINW))
 conv_mfma_f32_kernel(ConvArgs p) {
+    constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     using Cfg = ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>;
     constexpr int TX = Cfg::TX, NB = Cfg::NB, PC = Cfg::PC, WT = Cfg::WT, CPG = Cfg::CPG;
     constexpr int NPIX = Cfg::NPIX, NKP = Cfg::NKP, TAPS = Cfg::TAPS, NPAR = Cfg::NPAR, NTHR = Cfg::NTHR;
@@ -166,7 +168,7 @@ conv_mfma_f32_kernel(ConvArgs p) {
     const int zi = blockIdx.z % p.nz;
     const int n = blockIdx.z / p.nz;
 
-    const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX);
     const int nchunks = p.CinPad / CC;
     // per-slice parameters (wave-uniform): uniform launch, or one entry of the ZSlice table
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
@@ -193,7 +195,7 @@ conv_mfma_f32_kernel(ConvArgs p) {
         const int iy = ty0 * S - pad_y + pr;
         const int ix = tx0 * S - pad_x + pc;
         const bool own = pidx < NPIX;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ESX : kBufOOB;
         lidx[k] = own ? (pr * 2 + sh) * PC + pc : -1;
     }
 
@@ -215,7 +217,7 @@ conv_mfma_f32_kernel(ConvArgs p) {
         const int t = wv + NW * i;
         const int oy = ty0 + t / TXW;
         const int ox = tx0 + (t % TXW) * 32 + l31;
-        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * 4u : kBufOOB;
+        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ESY : kBufOOB;
     }
     // residual (skip connection) values of this lane's outputs: requested first thing, so their (HBM) latency
     // overlaps the first gather, and added to the accumulators before the first MFMA -- no registers are held
@@ -230,14 +232,14 @@ conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
-                const buf_rsrc rs = make_buf(resid + rbase, (resid != nullptr) & (cs < p.Cout));
-                const unsigned so = (unsigned)(cs * rs32) * 4u;
+                const buf_rsrc rs = make_buf(elem_ptr(resid, rbase, ESY), (resid != nullptr) & (cs < p.Cout));
+                const unsigned so = (unsigned)(cs * rs32) * ESY;
 #pragma unroll
                 for (int i = 0; i < WT; i++) {
                     // same pixel, the residual's own channel stride for the upper half-wave's 4-channel shift
-                    const unsigned rvo = yvoff[i] == kBufOOB ? kBufOOB : yvoff[i] + (unsigned)(4 * half * (rs32 - cs32)) * 4u;
+                    const unsigned rvo = yvoff[i] == kBufOOB ? kBufOOB : yvoff[i] + (unsigned)(4 * half * (rs32 - cs32)) * ESY;
                     const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : rvo;
-                    rv[i][b][r] = kAblResid ? (float)cs : buf_load(rs, vo, so);
+                    rv[i][b][r] = kAblResid ? (float)cs : Io<TOUT>::load(rs, vo, so);
                 }
             }
     };
@@ -279,10 +281,10 @@ conv_mfma_f32_kernel(ConvArgs p) {
             for (int j = 0; j < CPG; j++) {
                 const int off = tab[ch * CC + 2 * j + h];          // wave-uniform scalar load
                 const buf_rsrc rs = make_buf(xb, off >= 0);
-                const unsigned so = (unsigned)off * 4u;
+                const unsigned so = (unsigned)off * ESX;
 #pragma unroll
                 for (int k = 0; k < NKP; k++)
-                    rin[h][k][j] = kAblGather ? (float)(off + (int)voff[k]) : buf_load(rs, voff[k], so);
+                    rin[h][k][j] = kAblGather ? (float)(off + (int)voff[k]) : Io<TIN>::load(rs, voff[k], so);
             }
         if (WLDS) {
             const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_ELEMS * 4);
@@ -410,13 +412,13 @@ conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int cs = nblk * NB + b * 32 + (r & 3) + 8 * (r >> 2);
-                const buf_rsrc rs = make_buf(p.y + ybase, cs < p.Cout);
-                const unsigned so = (unsigned)(cs * cs32) * 4u;
+                const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ESY), cs < p.Cout);
+                const unsigned so = (unsigned)(cs * cs32) * ESY;
 #pragma unroll
                 for (int i = 0; i < WT; i++) {
                     const float v = apply_act_fast(acc[i][b][r], decltype(ACT)::value);
                     const unsigned vo = (decltype(TAIL)::value && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];
-                    if (!kAblStore || v == 12345.678f) buf_store(v, rs, vo, so);
+                    if (!kAblStore || v == 12345.678f) Io<TOUT>::store(v, rs, vo, so);
                 }
             }
     };

@@ -54,9 +54,11 @@ struct WinoCfg {
     static_assert(U_ELEMS / 4 % NTHR == 0, "weight slab is copied as whole float4 rounds");
 };
 
-template <int NW>
+// TIN / TOUT: storage type of the input and of the output + residual (float, or _Float16 in half2 mode)
+template <int NW, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(ConvArgs p) {
     using Cfg = WinoCfg<NW>;
+    constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     constexpr int CC = Cfg::CC, TY = Cfg::TY, TX = Cfg::TX, PC = Cfg::PC, PCP = Cfg::PCP, CHS = Cfg::CHS;
     constexpr int NPIX = Cfg::NPIX, CPW = Cfg::CPW, NKP = Cfg::NKP, NTHR = Cfg::NTHR, NK_W = Cfg::NK_W;
 
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const int nblk = blockIdx.y;
     const int zi = blockIdx.z % p.nz;
     const int n = blockIdx.z / p.nz;
-    const float* __restrict__ xb = p.x + (int64_t)n * p.x_bstride;
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX);
     const int nchunks = p.CinPad / CC;
     const int Ho = p.Ho, Wo = p.Wo;
     const int64_t ybase = (int64_t)n * p.y_bstride + p.y_off + (int64_t)zi * p.y_zstride;
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 - p.pad_y + pr, ix = tx0 - p.pad_x + pc;
         const bool own = pidx < NPIX;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ESX : kBufOOB;
         loff[k] = own ? ((wv % CC) * CPW) * CHS + pr * PCP + pc : -1;
     }
     const float* __restrict__ wsrc = p.w + ((int64_t)nblk * nchunks) * Cfg::U_ELEMS;
@@ -109,9 +111,9 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         for (int q = 0; q < CPW; q++) {
             const int off = tab[ch * CC + q];             // wave-uniform scalar load
             const buf_rsrc rs = make_buf(xb, off >= 0);
-            const unsigned so = (unsigned)off * 4u;
+            const unsigned so = (unsigned)off * ESX;
 #pragma unroll
-            for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : buf_load(rs, voff[k], so);
+            for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : Io<TIN>::load(rs, voff[k], so);
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
 #pragma unroll
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         for (int a = 0; a < 2; a++) {
             const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t;
             const bool row_ok = oy < Ho && cbase < p.Cout;
-            const unsigned off = (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * 4u;
+            const unsigned off = (unsigned)(oy * p.y_ystride + ox * p.y_xstride + (cb * 16 + 4 * k4) * cs32) * ESY;
             yv2[a] = (row_ok && ox + 1 < Wo) ? off : kBufOOB;
             yv1[a] = (row_ok && ox + 1 == Wo) ? off : kBufOOB;
         }
@@ -152,14 +154,14 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
     float rr[4][2][2];
     {
-        const buf_rsrc rs_r = make_buf(p.resid + ybase, p.resid != nullptr);
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, ybase, ESY), p.resid != nullptr);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;
             const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const f32x2 v = kAblResid ? f32x2{(float)i, (float)a} : buf_load2(rs_r, dead ? kBufOOB : yv2[a], so);
+                const f32x2 v = kAblResid ? f32x2{(float)i, (float)a} : Io<TOUT>::load2(rs_r, dead ? kBufOOB : yv2[a], so);
                 rr[i][a][0] = v[0];
                 rr[i][a][1] = v[1];
             }
@@ -167,10 +169,10 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         if (edge_tile) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+                const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;
                 const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
-                for (int a = 0; a < 2; a++) rr[i][a][0] += buf_load(rs_r, dead ? kBufOOB : yv1[a], so);
+                for (int a = 0; a < 2; a++) rr[i][a][0] += Io<TOUT>::load(rs_r, dead ? kBufOOB : yv1[a], so);
             }
         }
     }
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     }
 
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
-    const buf_rsrc rs_y = make_buf(p.y + ybase);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, ybase, ESY));
     asm volatile("" ::: "memory");     // keep the recomputation below the loop
     out_offsets();
     auto epilogue = [&](auto ACT) {
@@ -255,13 +257,13 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             y[0][1] = t0[1] - t0[2] - t0[3];
             y[1][0] = t1[0] + t1[1] + t1[2];
             y[1][1] = t1[1] - t1[2] - t1[3];
-            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * 4u;
+            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;
             const bool dead = tail4 && cbase + i >= p.Cout;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const f32x2 o = {apply_act_fast(y[a][0], decltype(ACT)::value), apply_act_fast(y[a][1], decltype(ACT)::value)};
-                if (!kAblStore || o[0] == 12345.678f) buf_store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
-                if (edge_tile) buf_store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
+                if (!kAblStore || o[0] == 12345.678f) Io<TOUT>::store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
+                if (edge_tile) Io<TOUT>::store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
             }
         }
     };

@@ -40,7 +40,9 @@ __device__ static __forceinline__ float pack_half2(float lo, float hi) {
     return __builtin_bit_cast(float, a | (b << 16));
 }
 
-template <int DT, bool FUSED, bool ISMIN, bool H2 = false>
+// T = storage type of the NCHW feature maps and of the fused soft-argmax output (float, or _Float16 when the
+// executor runs in half2 mode); the NC2HW2 form (H2) always travels as 4-byte slots, T = float.
+template <int DT, bool FUSED, bool ISMIN, bool H2 = false, typename T = float>
 __global__ void __launch_bounds__(256)
 corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out, int C,
                 int H, int W, int D, int d_base, int64_t out_bstride, int in_pitch, int out_pitch) {
@@ -60,8 +62,8 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z;
     const int64_t plane = (int64_t)H * in_pitch;         // row pitch >= W (dense: == W)
     const int cslots = H2 ? (C + 1) / 2 : C;              // planes per sample
-    const float* __restrict__ lb = left + (int64_t)n * cslots * plane;
-    const float* __restrict__ rb = right + (int64_t)n * cslots * plane;
+    const T* __restrict__ lb = reinterpret_cast<const T*>(left) + (int64_t)n * cslots * plane;
+    const T* __restrict__ rb = reinterpret_cast<const T*>(right) + (int64_t)n * cslots * plane;
 
     float acc[8][DT];
 #pragma unroll
@@ -101,19 +103,19 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
             const int c = c0 + wv * CPW + j;
             const bool cok = c < C;
             const int cp = cok ? (H2 ? c >> 1 : c) : 0;
-            const float* rp = rb + (int64_t)cp * plane;
-            const float* lp = lb + (int64_t)cp * plane;
+            const T* rp = rb + (int64_t)cp * plane;
+            const T* lp = lb + (int64_t)cp * plane;
 #pragma unroll
             for (int k = 0; k < NKR; k++) {
                 const bool ok = cok & (roff[k] >= 0);
-                float v = rp[ok ? roff[k] : 0];
+                float v = (float)rp[ok ? roff[k] : 0];
                 if (H2) v = half_of_slot(v, c & 1);
                 pr_[j][k] = ok ? v : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < NKL; k++) {
                 const bool ok = cok & (loff[k] >= 0);
-                float v = lp[ok ? loff[k] : 0];
+                float v = (float)lp[ok ? loff[k] : 0];
                 if (H2) v = half_of_slot(v, c & 1);
                 pl_[j][k] = ok ? v : 0.f;
             }
@@ -223,7 +225,7 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
                 ws += red[(2 * 4 + w4) * NPX + px] * sc;
             }
             const int yy = y0 + px / TX, xx = x0 + px % TX;
-            if (yy < H && xx < W) out[(int64_t)n * out_bstride + (int64_t)yy * out_pitch + xx] = ws / s;
+            if (yy < H && xx < W) reinterpret_cast<T*>(out)[(int64_t)n * out_bstride + (int64_t)yy * out_pitch + xx] = (T)(ws / s);
         }
     }
 }

@@ -31,9 +31,10 @@ struct Deconv3dSmallArgs {
 
 // Z = false: the 2-D form (TensorRT addDeconvolution 3x3 stride 2, resnet18_2D_513x257_net.cpp:758-763): Dy = Dx = 1,
 // 2x2 output blocks, weights packed [K][COUT][phase 4][neighbour 4].
-template <int COUT, bool Z = true>
+template <int COUT, bool Z = true, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArgs p) {
     constexpr int NJ = Z ? 8 : 4;          // neighbours = phases per block
+    constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     const int mx = blockIdx.x * 256 + threadIdx.x;
     const int my = blockIdx.y;
     const int mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
@@ -44,10 +45,10 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
     for (int j = 0; j < NJ; j++) {
         const int iz = Z ? mz + p.bz + (j >> 2) : 0, iy = my + p.by + ((j >> 1) & 1), ix = mx + p.bx + (j & 1);
         const bool ok = iz >= 0 && iz < p.Dy && iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy;
-        voff[j] = ok ? (unsigned)((iz * p.Hy + iy) * p.xp + ix) * 4u : kBufOOB;
+        voff[j] = ok ? (unsigned)((iz * p.Hy + iy) * p.xp + ix) * ESX : kBufOOB;
     }
-    const buf_rsrc rs_x = make_buf(p.x + (int64_t)n * p.x_bstride);
-    const unsigned cstride = (unsigned)(p.Dy * p.Hy * p.xp) * 4u;
+    const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX));
+    const unsigned cstride = (unsigned)(p.Dy * p.Hy * p.xp) * ESX;
 
     float acc[COUT][NJ];
 #pragma unroll
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
     for (int k = 0; k < p.K; k++, wk += COUT * NJ * NJ) {
         float xv[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) xv[j] = buf_load(rs_x, voff[j], (unsigned)k * cstride);
+        for (int j = 0; j < NJ; j++) xv[j] = Io<TIN>::load(rs_x, voff[j], (unsigned)k * cstride);
 #pragma unroll
         for (int co = 0; co < COUT; co++)
 #pragma unroll
@@ -69,8 +70,8 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
     }
 
     // outputs (2mz + pz, co, 2my + py, 2mx + {0,1})
-    const buf_rsrc rs_y = make_buf(p.y + (int64_t)n * p.y_bstride);
-    const buf_rsrc rs_r = make_buf(p.resid + (int64_t)n * p.y_bstride, p.resid != nullptr);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride, ESY));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.y_bstride, ESY), p.resid != nullptr);
     const int ox = 2 * mx;
 #pragma unroll
     for (int co = 0; co < COUT; co++) {
@@ -81,16 +82,16 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
             for (int py = 0; py < 2; py++) {
                 const int oz = Z ? 2 * mz + pz : 0, oy = 2 * my + py;
                 const bool row_ok = oz < p.Dx && oy < p.Hx;
-                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * ESY;
                 const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
                 const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
                 f32x2_t o = {acc[co][4 * pz + 2 * py], acc[co][4 * pz + 2 * py + 1]};
-                const f32x2_t r2 = buf_load2(rs_r, v2, 0);
-                const float r1 = buf_load(rs_r, v1, 0);
+                const f32x2_t r2 = Io<TOUT>::load2(rs_r, v2, 0);
+                const float r1 = Io<TOUT>::load(rs_r, v1, 0);
                 o[0] = apply_act_rt(o[0] + r2[0] + r1, p.act);
                 o[1] = apply_act_rt(o[1] + r2[1], p.act);
-                buf_store2(o, rs_y, v2, 0);
-                buf_store(o[0], rs_y, v1, 0);
+                Io<TOUT>::store2(o, rs_y, v2, 0);
+                Io<TOUT>::store(o[0], rs_y, v1, 0);
             }
     }
 }

@@ -208,7 +208,7 @@ extern "C" int rt_activation(const void* x, void* y, int64_t n, int act, int dty
 // cost volumes / soft-argmax
 // =================================================================================================
 namespace {
-template <bool FUSED, bool ISMIN, bool H2 = false>
+template <bool FUSED, bool ISMIN, bool H2 = false, typename T = float>
 int launch_corr(const float* l, const float* r, float* out, int batch, int C, int H, int W, int D, int64_t obs,
                 hipStream_t st, int in_pitch = 0, int out_pitch = 0) {
     const int ip = in_pitch ? in_pitch : W, op = out_pitch ? out_pitch : W;
@@ -217,10 +217,10 @@ int launch_corr(const float* l, const float* r, float* out, int batch, int C, in
     dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)batch);
     for (int d_base = 0; d_base < D; d_base += 4 * dt) {
         switch (dt) {
-            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
         }
         RT_LAUNCH_CHECK("corr cost volume kernel");
     }
@@ -248,11 +248,14 @@ extern "C" int rt_corr_softargmax_pitched(const void* left, const void* right, v
     RT_REQUIRE(left && right && out, "rt_corr_softargmax_pitched: null pointer");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax_pitched: bad dims");
     RT_REQUIRE((in_pitch == 0 || in_pitch >= W) && (out_pitch == 0 || out_pitch >= W), "rt_corr_softargmax_pitched: pitch smaller than the row");
-    if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_pitched: only fp32 in this build");
+    if (dtype != RT_F32 && dtype != RT_F16) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_pitched: bad dtype");
     if (out_bstride == 0) out_bstride = (int64_t)H * (out_pitch ? out_pitch : W);
     auto l = static_cast<const float*>(left);
     auto r = static_cast<const float*>(right);
     auto o = static_cast<float*>(out);
+    if (dtype == RT_F16)        // fp16 NCHW feature maps and output (half2 mode of the executor)
+        return is_min ? launch_corr<true, true, false, _Float16>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch)
+                      : launch_corr<true, false, false, _Float16>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch);
     return is_min ? launch_corr<true, true>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch)
                   : launch_corr<true, false>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch);
 }
@@ -410,6 +413,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
+    int x_f16 = 0, y_f16 = 0;           // storage type of input / output + residual (half2 mode), set by rt_conv_plan_set_io_types
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
@@ -622,6 +626,15 @@ int launch_window(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream
         hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, ty, txw, NBW, CC, nw, wlds>), grid,       \
                            dim3(64 * nw), 0, st, a);                                                      \
         return 0;                                                                                         \
+    }
+    // fp16 storage (half2 mode): the default tile only; fp32 in -> fp16 out (first layer) or fp16 -> fp16
+    if (sc.x_f16 || sc.y_f16) {
+        if (!(sc.TY == 4 && sc.TXW == 1 && sc.NW == 4 && sc.WLDS) || !sc.y_f16) return 1;
+        if (sc.x_f16)
+            hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, 4, 1, NBW, CC, 4, true, _Float16, _Float16>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, 4, 1, NBW, CC, 4, true, float, _Float16>), grid, dim3(256), 0, st, a);
+        return 0;
     }
     RT_TILE(4, 2, 4, true) RT_TILE(4, 1, 4, true) RT_TILE(2, 2, 4, true) RT_TILE(2, 1, 2, true) RT_TILE(8, 1, 8, true) RT_TILE(8, 1, 4, true)
 #undef RT_TILE
@@ -1100,6 +1113,27 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
     return 0;
 }
 
+// Storage type (RT_F32 / RT_F16) of the input and of the output + residual of a 2-D plan: TensorRT's half2 mode keeps
+// activations in fp16 between layers; the arithmetic stays fp32.  fp16 outputs need an even row pitch (pixel pairs
+// are written as one 4-byte word).
+extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype) {
+    RT_REQUIRE(plan && plan->is2d, "rt_conv_plan_set_io_types: 2-D convolution plans only");
+    RT_REQUIRE((x_dtype == RT_F32 || x_dtype == RT_F16) && (y_dtype == RT_F32 || y_dtype == RT_F16), "rt_conv_plan_set_io_types: bad dtype");
+    const int xf = x_dtype == RT_F16, yf = y_dtype == RT_F16;
+    const int op = plan->out_pitch ? plan->out_pitch : plan->out_dims[2];
+    RT_REQUIRE(!yf || (op & 1) == 0, "rt_conv_plan_set_io_types: fp16 output rows need an even pitch (got %d)", op);
+    for (SubConv& sc : plan->subs) {
+        if (!xf && !yf) { sc.x_f16 = sc.y_f16 = 0; continue; }
+        if (sc.direct) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the direct (Cout <= 2) kernel is fp32 only");
+        if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
+        else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
+        else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
+        else set_tile(sc, 6);                  // the fp16 instantiations exist for the default tile
+        sc.x_f16 = xf; sc.y_f16 = yf;
+    }
+    return 0;
+}
+
 extern "C" int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]) {
     RT_REQUIRE(plan && dims, "rt_conv_plan_out_dims: null pointer");
     for (int i = 0; i < 4; i++) dims[i] = plan->out_dims[i];
@@ -1120,7 +1154,15 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             const int64_t gz = (int64_t)batch * a.Mz;
             RT_REQUIRE(gz <= 65535 && (a.Hx + 1) / 2 <= 65535, "rt_conv_enqueue: grid limit exceeded");
             dim3 grid((unsigned)rt::cdiv((a.Wx + 1) / 2, 256), (unsigned)((a.Hx + 1) / 2), (unsigned)gz);
-            if (sc.small3d == 2) {
+            if (sc.small3d == 2 && sc.x_f16) {          // half2 mode: fp16 activations in, fp32 (binding) or fp16 out
+                if (sc.y_f16) {
+                    if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
+                    else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
+                } else {
+                    if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
+                    else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
+                }
+            } else if (sc.small3d == 2) {
                 if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false>), grid, dim3(256), 0, S(s), a);
                 else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false>), grid, dim3(256), 0, S(s), a);
             } else {
@@ -1178,7 +1220,10 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (sc.wino) {
             RT_REQUIRE(!sc.zs_dev && sc.y_xstride == 1, "rt_conv_enqueue: Winograd kernel takes uniform, x-contiguous slices only");
-            if (sc.NW == 8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
+            if (sc.x_f16 || sc.y_f16) {
+                RT_REQUIRE(sc.x_f16 && sc.y_f16, "rt_conv_enqueue: the Winograd kernel takes fp16 on both sides or on neither");
+                hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
+            } else if (sc.NW == 8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
             else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("conv_wino_f32_kernel");
             continue;

@@ -1,0 +1,89 @@
+"""fp16 storage of activations (TensorRT half2 mode): the convolution kernels, the fused correlation and the whole
+ResNet-18 2D network with fp16 tensors between layers and fp32 arithmetic.  Tolerances follow the reference's own
+fp16 tests (1e-2, tests_main.cpp:320,1025); the conv-level checks are tighter (one rounding of the output)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import capi
+from test_ops_parity import T, rnd
+from test_pitch_parity import pitched
+
+
+def h16(a):
+    return np.ascontiguousarray(a.astype(np.float16))
+
+
+def dev16(backend, a):
+    return torch.from_numpy(h16(a)).cuda() if backend.name == "gpu" else h16(a)
+
+
+def empty16(backend, shape):
+    if backend.name == "gpu":
+        return torch.full(tuple(shape), float("nan"), dtype=torch.float16, device="cuda")
+    return np.full(shape, np.nan, np.float16)
+
+
+def host(backend, t):
+    if backend.name == "gpu":
+        torch.cuda.synchronize()
+        return t.cpu().numpy().astype(np.float32)
+    return np.asarray(t).astype(np.float32)
+
+
+CASES = [
+    # cin, cout, h, w, k, stride, transposed, act, resid, x16, y16
+    (32, 32, 9, 37, 3, 1, False, capi.RT_ACT_ELU, True, True, True),       # Winograd
+    (3, 32, 11, 29, 5, 2, False, capi.RT_ACT_ELU, False, False, True),     # first layer: fp32 image in, fp16 out
+    (32, 64, 9, 35, 3, 2, False, capi.RT_ACT_ELU, False, True, True),      # stride 2
+    (64, 32, 5, 9, 3, 2, True, capi.RT_ACT_ELU, True, True, True),         # transposed, merged phases
+    (32, 1, 6, 13, 3, 2, True, capi.RT_ACT_SIGMOID, False, True, False),   # last layer: fp16 in, fp32 out
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k,stride,tr,act,resid,x16,y16", CASES)
+def test_conv2d_f16_storage(backend, cin, cout, h, w, k, stride, tr, act, resid, x16, y16):
+    batch, pad = 2, (k // 2 if not tr else 1)
+    x, b = rnd(batch, cin, h, w), rnd(cout)
+    xq = x.astype(np.float16).astype(np.float32) if x16 else x
+    if tr:
+        wt = rnd(cin, cout, k, k) * np.float32(1 / np.sqrt(cin * k * k))
+        ref = O.deconv2d(T(xq), T(wt), T(b), stride, pad)
+    else:
+        wt = rnd(cout, cin, k, k) * np.float32(1 / np.sqrt(cin * k * k))
+        ref = O.conv2d(T(xq), T(wt), T(b), stride, pad)
+    res = rnd(*ref.shape) if resid else None
+    if resid:
+        ref = ref + T(res.astype(np.float16).astype(np.float32) if y16 else res)
+    ref = O.elu(ref) if act == capi.RT_ACT_ELU else (torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref)
+    ref = ref.numpy()
+    wo = ref.shape[-1]
+    ip, op = (w + 63) // 64 * 64, (wo + 63) // 64 * 64
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, pad, act=act, has_residual=resid, transposed=tr)
+    plan.set_pitch(ip, op)
+    plan.set_io_types(capi.RT_F16 if x16 else capi.RT_F32, capi.RT_F16 if y16 else capi.RT_F32)
+    xin = dev16(backend, pitched(x, ip, 0.0)) if x16 else backend.dev(pitched(x, ip))
+    rin = None
+    if resid:
+        rin = dev16(backend, pitched(res, op, 0.0)) if y16 else backend.dev(pitched(res, op))
+    y = empty16(backend, ref.shape[:-1] + (op,)) if y16 else backend.empty(ref.shape[:-1] + (op,))
+    plan.enqueue(xin, y, rin, batch)
+    out = host(backend, y) if y16 else backend.host(y)
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max())) if y16 else 3e-5
+    assert np.abs(out[..., :wo] - ref).max() <= tol
+    assert np.isnan(out[..., wo:]).all(), "padding columns were written"
+    plan.destroy()
+
+
+def test_corr_softargmax_f16_storage(backend):
+    n, c, h, w, d = 2, 16, 7, 45, 12
+    l, r = rnd(n, c, h, w) * np.float32(0.5), rnd(n, c, h, w) * np.float32(0.5)
+    lq, rq = (a.astype(np.float16).astype(np.float32) for a in (l, r))
+    ref = O.softargmax(O.corr_cost_volume(T(lq), T(rq), d), False).numpy()
+    out = empty16(backend, (n, 1, h, 64))
+    backend.klib.corr_softargmax_pitched(dev16(backend, pitched(l, 64, 0.0)), dev16(backend, pitched(r, 64, 0.0)), out, n, c,
+                                         h, w, d, False, 64, 64, dtype=capi.RT_F16)
+    res = host(backend, out)
+    assert np.abs(res[..., :w] - ref).max() <= 8e-3          # half ulp of values below 16
+    assert np.isnan(res[..., w:]).all()

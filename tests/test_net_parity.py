@@ -118,6 +118,26 @@ def test_nvtiny_unfused_equals_fused(rt, monkeypatch):
     assert np.abs(fused - unfused).max() <= 1e-4
 
 
+def test_resnet18_2d_half2_mode(rt, monkeypatch):
+    """fp16 weight file = half2 mode (sample_app/main.cpp:256-262): activations between the fused launches are stored
+    as fp16, arithmetic stays fp32.  Error against the fp32 oracle with the same (fp16-rounded) weights must stay inside
+    the reference's fp16 tolerance of 1e-2 (tests_main.cpp:320, 1025) -- measured ~1e-3 on the normalised disparity."""
+    w = O.synth_weights_resnet18_2d()
+    wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in w.items()}
+    l, r = pairs(2, 25, 41)
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), wq, max_disp=8).numpy()
+    half, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    assert not np.isnan(half).any()
+    err_half = np.abs(half - ref).max()
+    assert err_half <= 1e-2, err_half
+    monkeypatch.setenv("RT_NO_F16", "1")                       # same fp16 weights, fp32 activations
+    full, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    err_full = np.abs(full - ref).max()
+    assert err_full <= 2e-4, err_full
+    assert err_half > err_full                                 # i.e. the fp16 storage path really ran
+
+
 def test_plan_round_trip(rt):
     """ICudaEngine::serialize -> IRuntime::deserializeCudaEngine with StereoDnnPluginFactory (sample_app/main.cpp:198-220,
     269-275): the re-created engine must produce the same bits; the 3-D models have no plan, as in the reference
