@@ -226,6 +226,30 @@ def test_resnet18_2d_interleaved_contexts():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,cfg,w,h,disp,tol", [("nvsmall", "NVSMALL_3D", 257, 129, 16, 1e-3), ("resnet18", "RESNET18_3D", 257, 129, 12, 1e-3),
+                                                    ("nvsmall", "NVSMALL_3D", 1025, 321, 48, 1e-3),
+                                                    # 30 layers deep, disparities up to 136 px: the fp32 oracle itself is 2.2e-3 px away from an fp64
+                                                    # evaluation of the same graph, the GPU 2.4e-3 (direct form 3.5e-3) -- tools/precision_probe.py
+                                                    ("resnet18", "RESNET18_3D", 1025, 321, 68, 5e-3)])
+def test_3d_models(model, cfg, w, h, disp, tol):
+    """NVSmall / ResNet-18 3D (BASELINE configs C5 / C4 in fp32) at a quarter of their resolution and at full size
+    (1025x321, D = 48 / 68 at half resolution): Winograd Conv3D, folded Pad, fused Conv3DTranspose decoder and the
+    small-output last layer against the oracle graph; budget 1e-3 px on the soft-argmin disparity."""
+    lib = netlib("gpu")
+    weights = O.synth_weights_3d(getattr(O, cfg))
+    l, r = pairs(1, h, w)
+    net = lib.create(model, w, h, weights=weights, max_disp=disp)
+    out = torch.full((1, 1, h, w), float("nan"), device="cuda")
+    net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out, 1)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), weights, getattr(O, cfg), disp)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= tol, err
+    net.destroy()
+
+
+@pytest.mark.gpu
 def test_nvtiny_full_size():
     lib = netlib("gpu")
     path = os.path.join(REF_W, "NVTiny/TensorRT/trt_weights.bin")
