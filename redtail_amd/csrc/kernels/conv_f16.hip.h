@@ -1,0 +1,196 @@
+// Implicit-GEMM convolution with fp16 operands on the gfx950 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate):
+// the half2-mode form of conv_mfma_f32_kernel / conv_wino_f32_kernel for layers whose input and output tensors are
+// both stored as fp16 (TensorRT half2 mode, IBuilder::setHalf2Mode, reference sample_app/main.cpp:256-262; weight
+// file trt_weights_fp16.bin).  Operands are exactly the stored values -- fp16 activations, fp16 weights -- and the
+// products are accumulated in fp32, so nothing is rounded that the fp32-arithmetic path of half2 mode does not round
+// too; the matrix cores just run 16x faster (2.5 PFLOP/s dense) and the layer becomes bound by data movement.
+//
+// Same contraction description as conv_mfma.hip.h (tap window, gather table, ZSlice phases, tap masks, residual and
+// bias in the accumulator init, buffer addressing).  Per chunk of 16 input channels:
+//   LDS patch  [row][h][col][8 halfs]   channel = 8*h + e   -> one ds_read_b128 = the B operand of a lane (pixel, h)
+//   LDS weights [tap][h][co][8 halfs]                        -> one ds_read_b128 = the A operand of a lane (co, h)
+// and ONE MFMA (K = 16) per tap.  Staging: wave w gathers channel group h = w&1 for half of the patch pixels, 8 two-
+// byte loads per pixel packed to one 16-byte LDS write.  Tile: 4 rows x 32 pixels x 32 channels, 4 waves.
+#pragma once
+#include <type_traits>
+#include "common.hip.h"
+#include "conv_mfma.hip.h"
+
+namespace rt {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int KH, int KW, int S>
+struct ConvF16Cfg {
+    static constexpr int TY = 4, TX = 32, CC = 16, TAPS = KH * KW;
+    static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW, NPIX = PR * PC;
+    static constexpr int NKP = ((NPIX + 1) / 2 + 63) / 64;        // patch pixels per lane (two pixel partitions)
+    static constexpr int W_SLOTS = TAPS * 2 * 32;                 // 16-byte slots of the weight slab of one chunk
+    static constexpr int NK_W = (W_SLOTS + 255) / 256;
+};
+
+template <int KH, int KW, int S>
+__global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
+    using Cfg = ConvF16Cfg<KH, KW, S>;
+    constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, NPIX = Cfg::NPIX;
+    constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W;
+    constexpr unsigned ES = 2;
+
+    __shared__ __attribute__((aligned(16))) f32x4 sIn[Cfg::PR * 2 * PC];
+    __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile = blockIdx.x;
+    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (tile % p.tiles_x) * TX;
+    const int ty0 = (tile / p.tiles_x) * TY;
+    const int nblk = blockIdx.y;
+    const int zi = blockIdx.z % p.nz;
+    const int n = blockIdx.z / p.nz;
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
+    const int nchunks = p.CinPad / CC;
+    int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
+    unsigned tap_mask = ~0u;
+    if (p.zs) {
+        const ZSlice z = p.zs[zi];
+        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
+        r_off = z.r_off;
+        tap_mask = z.tap_mask;
+    }
+    const int act = p.act;
+
+    // ---- staging roles: wave w -> channel group g = w & 1 (channels 8g .. 8g+7 of the chunk), pixel half w >> 1 -----
+    const int g = wv & 1, spart = wv >> 1;
+    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 8 * g;
+    unsigned voff[NKP];
+    int lidx[NKP];
+#pragma unroll
+    for (int k = 0; k < NKP; k++) {
+        const int pidx = spart * (NKP * 64) + lane + 64 * k;
+        const int pr = pidx / PC, pc = pidx - pr * PC;
+        const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
+        const bool own = pidx < NPIX;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ES : kBufOOB;
+        lidx[k] = own ? (pr * 2 + g) * PC + pc : -1;
+    }
+    // w_off and the slab size count 16-byte slots here (8 halfs)
+    const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + (w_off + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS) * 16;
+    const buf_rsrc rs_w = make_buf(wsrc);
+    unsigned wvoff[NK_W];
+#pragma unroll
+    for (int k = 0; k < NK_W; k++) {
+        const int idx = tid + 256 * k;
+        wvoff[k] = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
+    }
+
+    f32x4 rin[NKP];          // 8 halfs per patch pixel
+    f32x4 rw[NK_W];
+    auto prefetch = [&](int ch) {
+        unsigned short u[NKP][8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int off = tab[ch * CC + e];                      // wave-uniform scalar load
+            const buf_rsrc rs = make_buf(xb, off >= 0);
+            const unsigned so = (unsigned)off * ES;
+#pragma unroll
+            for (int k = 0; k < NKP; k++) u[k][e] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff[k], so, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NKP; k++) {
+            u32x4_t w4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) w4[q] = (unsigned)u[k][2 * q] | ((unsigned)u[k][2 * q + 1] << 16);
+            rin[k] = __builtin_bit_cast(f32x4, w4);
+        }
+        const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) rw[k] = buf_load4(rs_w, wvoff[k], so);
+    };
+    auto stage_to_lds = [&]() {
+#pragma unroll
+        for (int k = 0; k < NKP; k++)
+            if (lidx[k] >= 0) sIn[lidx[k]] = rin[k];
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + 256 * k;
+            if (idx < Cfg::W_SLOTS) sW[idx] = rw[k];
+        }
+    };
+
+    // ---- output addressing, accumulator init = bias + residual (as in conv_mfma.hip.h) ---------------------------
+    const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
+    const int64_t rbase = (int64_t)n * p.r_bstride + r_off;
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
+    const bool tail8 = (p.Cout & 7) != 0;
+    const int oy = ty0 + wv, ox = tx0 + l31;
+    const unsigned yvoff = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ES : kBufOOB;
+    const unsigned rvoff = yvoff == kBufOOB ? kBufOOB : yvoff + (unsigned)(4 * half * (rs32 - cs32)) * ES;
+
+    f32x16 acc;
+    {
+        const float* bsrc = p.bias + nblk * 32 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bsrc + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[4 * q + e] = bv[e];
+        }
+    }
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
+        const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), (p.resid != nullptr) & (cs < p.Cout));
+        const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : rvoff;
+        rv[r] = Io<_Float16>::load(rs, vo, (unsigned)(cs * rs32) * ES);
+    }
+
+    const int a_base = half * 32 + l31;
+    const int b_base = (wv * S * 2 + half) * PC + l31 * S;
+    auto compute = [&]() {
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            if (!((tap_mask >> t) & 1u)) continue;                  // wave-uniform
+            const int r = t / KW, s = t % KW;
+            const f16x8_t a = __builtin_bit_cast(f16x8_t, sW[a_base + t * 64]);
+            const f16x8_t b = __builtin_bit_cast(f16x8_t, sIn[b_base + r * 2 * PC + s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+    };
+
+    prefetch(0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] += rv[r];
+    for (int ch = 0; ch < nchunks; ch++) {
+        if (ch) __syncthreads();
+        stage_to_lds();
+        __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+        compute();
+    }
+
+    auto epilogue = [&](auto ACT) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
+            const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
+            const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff;
+            Io<_Float16>::store(apply_act_fast(acc[r], decltype(ACT)::value), rs, vo, (unsigned)(cs * cs32) * ES);
+        }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+}  // namespace rt

@@ -17,6 +17,7 @@
 #include "kernels/conv_wino.hip.h"
 #include "kernels/deconv3d_small.hip.h"
 #include "kernels/imgproc.hip.h"
+#include "kernels/conv_f16.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -414,6 +415,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
     int x_f16 = 0, y_f16 = 0;           // storage type of input / output + residual (half2 mode), set by rt_conv_plan_set_io_types
+    int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
@@ -429,6 +431,9 @@ struct rtConvPlan {
     int64_t x_bstride = 0, y_bstride = 0;
     int64_t r_bstride = 0;                        // residual per-sample stride, 0 = y_bstride
     int is2d = 0, cin = 0, hin = 0, win = 0;      // 2-D plans can be re-pitched (rt_conv_plan_set_pitch)
+    std::vector<float> w_canon;                   // 2-D plans: weights as given (KCRS / (Cin,Cout,R,S)), for re-packing
+    rtConv2dDesc desc2d{};                        // ... and the descriptor they came with
+    int is_deconv = 0;
     int in_pitch = 0, out_pitch = 0;
 };
 
@@ -690,6 +695,7 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
     plan->is2d = 1; plan->cin = d->Cin; plan->hin = d->Hin; plan->win = d->Win;
+    plan->desc2d = *d; plan->is_deconv = 0;
 
     SubConv sc;
     sc.KH = d->KH; sc.KW = d->KW; sc.S = d->stride;
@@ -702,6 +708,7 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     sc.CinPad = sc.direct ? d->Cin : rt::round_up(d->Cin, sc.CC);
     if (sc.CinPad > 512) { free_plan(plan); return fail(RT_E_UNSUPPORTED, "conv2d: Cin > 512"); }
     const std::vector<float> w = to_f32(weights, (size_t)d->Cout * d->Cin * d->KH * d->KW, d->dtype);
+    plan->w_canon = w;
     const int Cin = d->Cin, KH = d->KH, KW = d->KW;
     int rc = upload_packed(sc, Cin, [&](int co, int ci, int u, int v) {
         return w[(((size_t)co * Cin + ci) * KH + u) * KW + v];          // KCRS
@@ -737,7 +744,9 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
     plan->is2d = 1; plan->cin = d->Cin; plan->hin = d->Hin; plan->win = d->Win;
+    plan->desc2d = *d; plan->is_deconv = 1;
     const std::vector<float> w = to_f32(weights, (size_t)d->Cin * d->Cout * d->KH * d->KW, d->dtype);
+    plan->w_canon = w;
     const int Cin = d->Cin, Cout = d->Cout, KH = d->KH, KW = d->KW;
 
     // Last layer of ResNet-18 2D (32 -> 1, 3x3, stride 2): 2x2-output-block kernel, see deconv3d_small.hip.h
@@ -1113,6 +1122,74 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
     return 0;
 }
 
+namespace {
+// fp16 operand slabs of conv_f16mma_kernel: [nblk][chunk of 16 ci][tap][h][co % 32][8 halfs], ci = chunk*16 + 8*h + e.
+// Appends one slab set (all nblk x chunks) and returns its offset in 16-byte slots.
+template <typename F>
+int64_t pack_f16_into(std::vector<uint16_t>& packed, const SubConv& sc, int cin_real, F wfun) {
+    const int64_t base = (int64_t)packed.size() / 8;
+    const int taps = sc.KH * sc.KW, nblk = (int)rt::cdiv(sc.Cout, 32), nch = sc.CinPad / 16;
+    packed.resize(packed.size() + (size_t)nblk * nch * taps * 2 * 32 * 8, 0);
+    for (int co = 0; co < sc.Cout; co++)
+        for (int ci = 0; ci < cin_real; ci++)
+            for (int u = 0; u < sc.KH; u++)
+                for (int v = 0; v < sc.KW; v++) {
+                    const _Float16 hv = (_Float16)wfun(co, ci, u, v);
+                    uint16_t bits;
+                    std::memcpy(&bits, &hv, 2);
+                    const int nb = co / 32, cc = co % 32, ch = ci / 16, h = (ci % 16) / 8, e = ci % 8;
+                    packed[(size_t)base * 8 + ((((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * 32 + cc) * 8) + e] = bits;
+                }
+    return base;
+}
+
+// Switches a 2-D plan to the fp16-arithmetic kernel: re-packs the weights it was created with.
+int repack_f16mma(rtConvPlan* plan) {
+    SubConv& sc = plan->subs[0];
+    const rtConv2dDesc& d = plan->desc2d;
+    const std::vector<float>& w = plan->w_canon;
+    const int Cin = d.Cin, Cout = d.Cout;
+    sc.CC = 16;
+    sc.CinPad = rt::round_up(Cin, 16);
+    sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4;
+    std::vector<uint16_t> packed;
+    if (!plan->is_deconv) {
+        pack_f16_into(packed, sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; });
+    } else {
+        const int s = d.stride;
+        size_t iz = 0;
+        for (int py = 0; py < s; py++)
+            for (int px = 0; px < s; px++) {
+                if (py >= plan->out_dims[1] || px >= plan->out_dims[2]) continue;
+                const Phase1D ay = phase1d(s, d.pad_h, d.KH, py), ax = phase1d(s, d.pad_w, d.KW, px);
+                const int64_t off = pack_f16_into(packed, sc, Cin, [&](int co, int ci, int u, int v) {
+                    if (u >= ay.K || v >= ax.K) return 0.f;
+                    return w[(((size_t)ci * Cout + co) * d.KH + ay.tap[u]) * d.KW + ax.tap[v]];
+                });
+                if (!sc.zs_host.empty()) sc.zs_host[iz++].w_off = off;
+            }
+        if (!sc.zs_host.empty())
+            RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
+    }
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
+    RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    if (sc.choff_dev) (void)hipFree(sc.choff_dev);
+    sc.choff_dev = nullptr;
+    const int ip = sc.x_pitch ? sc.x_pitch : plan->win;
+    std::vector<int> table(sc.CinPad, -1);
+    for (int c = 0; c < Cin; c++) table[c] = c * plan->hin * ip;
+    if (int rc = upload_table(sc, table)) return rc;
+    sc.wino = 0; sc.f16mma = 1;
+    return 0;
+}
+
+bool f16mma_window(const SubConv& sc) {
+    return (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
+}
+}  // namespace
+
 // Storage type (RT_F32 / RT_F16) of the input and of the output + residual of a 2-D plan: TensorRT's half2 mode keeps
 // activations in fp16 between layers; the arithmetic stays fp32.  fp16 outputs need an even row pitch (pixel pairs
 // are written as one 4-byte word).
@@ -1125,6 +1202,15 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
     for (SubConv& sc : plan->subs) {
         if (!xf && !yf) { sc.x_f16 = sc.y_f16 = 0; continue; }
         if (sc.direct) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the direct (Cout <= 2) kernel is fp32 only");
+        // both tensors fp16: fp16 operands on the matrix cores (the stored values are the operands, fp32 accumulate)
+        if (xf && yf && !sc.small3d && !sc.f16mma && plan->subs.size() == 1 && f16mma_window(sc) && env_int("RT_NO_F16MMA", 0) == 0) {
+            if (int rc = repack_f16mma(plan)) return rc;
+        }
+        if (sc.f16mma) {
+            if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: plan was switched to fp16 arithmetic, both tensors must stay fp16");
+            sc.x_f16 = sc.y_f16 = 1;
+            continue;
+        }
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1218,6 +1304,17 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.f16mma) {
+#define RT_F16CASE(kh, kw, st)                                                                              \
+    if (sc.KH == kh && sc.KW == kw && sc.S == st) {                                                         \
+        hipLaunchKernelGGL((rt::conv_f16mma_kernel<kh, kw, st>), grid, dim3(256), 0, S(s), a);              \
+        RT_LAUNCH_CHECK("conv_f16mma_kernel<" #kh "," #kw "," #st ">");                                     \
+        continue;                                                                                           \
+    }
+            RT_F16CASE(3, 3, 1) RT_F16CASE(3, 3, 2) RT_F16CASE(1, 1, 1) RT_F16CASE(1, 2, 1) RT_F16CASE(2, 1, 1) RT_F16CASE(2, 2, 1)
+#undef RT_F16CASE
+            return fail(RT_E_UNSUPPORTED, "conv (fp16 arithmetic): window %dx%d stride %d not instantiated", sc.KH, sc.KW, sc.S);
+        }
         if (sc.wino) {
             RT_REQUIRE(!sc.zs_dev && sc.y_xstride == 1, "rt_conv_enqueue: Winograd kernel takes uniform, x-contiguous slices only");
             if (sc.x_f16 || sc.y_f16) {
