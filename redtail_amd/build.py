@@ -72,7 +72,9 @@ def build_hip_ablation(mask, force=False, timing=False):
     out = os.path.join(outdir, "librt_stereo_hip_abl%d%s.so" % (mask, "_timing" if timing else ""))
     deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
     if force or _newer(out, deps):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRT_ABLATE=%d" % mask, "-w"] +
+        # mask >= 10000: no ablation, conv_f16mma_kernel compiled for (mask - 10000) waves per SIMD
+        defs = ["-DRT_ABLATE=0", "-DRT_F16_WAVES=%d" % (mask - 10000)] if mask >= 10000 else ["-DRT_ABLATE=%d" % mask]
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + defs +
              (["-DRT_KERNEL_TIMING"] if timing else []) + [
               os.path.join(CSRC, "rt_capi.hip"), "-o", out])
     return out

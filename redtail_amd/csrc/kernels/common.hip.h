@@ -13,6 +13,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;   // CDNA wavefront
 
+// register budget of a kernel as waves per SIMD (the test emulator defines this away)
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 __host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -11,6 +11,17 @@
 //   LDS weights [tap][h][co][8 halfs]                        -> one ds_read_b128 = the A operand of a lane (co, h)
 // and ONE MFMA (K = 16) per tap.  Staging: wave w gathers channel group h = w&1 for half of the patch pixels, 8 two-
 // byte loads per pixel packed to one 16-byte LDS write.  Tile: 4 rows x 32 pixels x 32 channels, 4 waves.
+//
+// Where the time goes (tools/ablate_conv.py run16, MI355X, 32->32 @185x629 + residual + ELU, batch 8: 53 us, the HBM
+// floor is ~18): with every global access compiled out the kernel still takes 30 us, without the MFMAs 50 -- a tile is
+// only ~600 MFMA cycles, so workgroup turnaround (launch, kernel arguments, gather table, bias, two exposed memory
+// latencies) bounds it and throughput follows occupancy (6 workgroups per CU here).  Measured and rejected, both
+// slower than this form: (a) 8-byte pixel-quad gathers transposed in registers + pixel-pair stores through a DPP
+// lane swap (fewer, wider memory instructions, but 112 VGPRs -> 4 workgroups per CU): -17 %; (b) a persistent
+// grid with LDS-resident weights and next-tile prefetch one chunk ahead (125 VGPRs, 4 per CU): 2x slower, the
+// tiles of one workgroup serialise on the gather latency that independent workgroups overlap.  What would be next:
+// a persistent form with the whole next tile (both chunks + residual) in flight, or an NC/8HW8 tensor layout
+// (one 16-byte access per pixel and channel group on both sides).
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
@@ -30,8 +41,12 @@ struct ConvF16Cfg {
     static constexpr int NK_W = (W_SLOTS + 255) / 256;
 };
 
+// throughput follows occupancy here (tools/ablate_conv.py runocc16: 80 / 67 / 61 / 58 / 51 us at 4 .. 8 waves per SIMD)
+#ifndef RT_F16_WAVES
+#define RT_F16_WAVES 8
+#endif
 template <int KH, int KW, int S>
-__global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma_kernel(ConvArgs p) {
     using Cfg = ConvF16Cfg<KH, KW, S>;
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, NPIX = Cfg::NPIX;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W;
@@ -103,7 +118,7 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
             const buf_rsrc rs = make_buf(xb, off >= 0);
             const unsigned so = (unsigned)off * ES;
 #pragma unroll
-            for (int k = 0; k < NKP; k++) u[k][e] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff[k], so, 0);
+            for (int k = 0; k < NKP; k++) u[k][e] = kAblGather ? (unsigned short)(off + (int)voff[k]) : __builtin_amdgcn_raw_buffer_load_b16(rs, voff[k], so, 0);
         }
 #pragma unroll
         for (int k = 0; k < NKP; k++) {
@@ -114,16 +129,16 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
 #pragma unroll
-        for (int k = 0; k < NK_W; k++) rw[k] = buf_load4(rs_w, wvoff[k], so);
+        for (int k = 0; k < NK_W; k++) rw[k] = kAblWLoad ? f32x4{(float)wvoff[k], 1.f, 2.f, (float)ch} : buf_load4(rs_w, wvoff[k], so);
     };
     auto stage_to_lds = [&]() {
 #pragma unroll
         for (int k = 0; k < NKP; k++)
-            if (lidx[k] >= 0) sIn[lidx[k]] = rin[k];
+            if (lidx[k] >= 0 && (!kAblLdsWr || rin[k][0] == 12345.678f)) sIn[lidx[k]] = rin[k];
 #pragma unroll
         for (int k = 0; k < NK_W; k++) {
             const int idx = tid + 256 * k;
-            if (idx < Cfg::W_SLOTS) sW[idx] = rw[k];
+            if (idx < Cfg::W_SLOTS && (!kAblLdsWr || rw[k][0] == 12345.678f)) sW[idx] = rw[k];
         }
     };
 
@@ -152,7 +167,7 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
         const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
         const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), (p.resid != nullptr) & (cs < p.Cout));
         const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : rvoff;
-        rv[r] = Io<_Float16>::load(rs, vo, (unsigned)(cs * rs32) * ES);
+        rv[r] = kAblResid ? (float)cs : Io<_Float16>::load(rs, vo, (unsigned)(cs * rs32) * ES);
     }
 
     const int a_base = half * 32 + l31;
@@ -162,9 +177,12 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
         for (int t = 0; t < TAPS; t++) {
             if (!((tap_mask >> t) & 1u)) continue;                  // wave-uniform
             const int r = t / KW, s = t % KW;
-            const f16x8_t a = __builtin_bit_cast(f16x8_t, sW[a_base + t * 64]);
-            const f16x8_t b = __builtin_bit_cast(f16x8_t, sIn[b_base + r * 2 * PC + s]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            const f32x4 av = kAblLdsRd ? f32x4{(float)(a_base + t), 1.f, 2.f, 3.f} : sW[a_base + t * 64];
+            const f32x4 bv = kAblLdsRd ? f32x4{(float)(b_base - t), 3.f, 2.f, 1.f} : sIn[b_base + r * 2 * PC + s];
+            const f16x8_t a = __builtin_bit_cast(f16x8_t, av);
+            const f16x8_t b = __builtin_bit_cast(f16x8_t, bv);
+            if (kAblMfma) acc[t & 15] += av[0] * bv[1];
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
         }
     };
 
@@ -172,9 +190,9 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] += rv[r];
     for (int ch = 0; ch < nchunks; ch++) {
-        if (ch) __syncthreads();
+        if (ch) wg_barrier();
         stage_to_lds();
-        __syncthreads();
+        wg_barrier();
         if (ch + 1 < nchunks) prefetch(ch + 1);
         compute();
     }
@@ -185,7 +203,8 @@ __global__ void __launch_bounds__(256) conv_f16mma_kernel(ConvArgs p) {
             const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
             const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
             const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff;
-            Io<_Float16>::store(apply_act_fast(acc[r], decltype(ACT)::value), rs, vo, (unsigned)(cs * cs32) * ES);
+            const float v = apply_act_fast(acc[r], decltype(ACT)::value);
+            if (!kAblStore || v == 12345.678f) Io<_Float16>::store(v, rs, vo, (unsigned)(cs * cs32) * ES);
         }
     };
     if (act == 1) epilogue(std::integral_constant<int, 1>{});

@@ -96,6 +96,7 @@ constexpr bool kAblResid = (RT_ABLATE & 16) != 0;    // no residual loads
 constexpr bool kAblStore = (RT_ABLATE & 32) != 0;    // no output stores
 constexpr bool kAblLdsRd = (RT_ABLATE & 64) != 0;    // MFMA operands from registers instead of LDS
 constexpr bool kAblXform = (RT_ABLATE & 128) != 0;   // Winograd kernel: no input transform
+constexpr bool kAblMfma = (RT_ABLATE & 256) != 0;    // conv_f16mma_kernel: no matrix instructions
 __device__ __forceinline__ void wg_barrier() { if (!kAblBarrier) __syncthreads(); }
 
 template <int N> struct VecOf;

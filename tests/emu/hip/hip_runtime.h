@@ -161,6 +161,7 @@ static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned v
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, aux) hipemu::buffer_load_b16(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b16(d, r, v, s, aux) hipemu::buffer_store_b16(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b64(d, r, v, s, aux) hipemu::buffer_store_b64(d, r, v, s)
+#define RT_WAVES_PER_EU(n)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

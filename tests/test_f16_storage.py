@@ -42,6 +42,8 @@ CASES = [
     (40, 20, 9, 37, 3, 1, False, capi.RT_ACT_ELU, True, True, True),       # ragged channel counts (chunks of 16, tail of 4)
     (16, 72, 8, 70, 3, 1, False, capi.RT_ACT_NONE, False, True, True),     # three column blocks, three tiles across
     (24, 32, 7, 33, 3, 2, True, capi.RT_ACT_NONE, False, True, True),      # transposed, odd sizes
+    (32, 33, 6, 41, 3, 1, False, capi.RT_ACT_ELU, True, True, True),       # odd channel count: 2-byte output accesses
+    (16, 32, 10, 66, 3, 2, False, capi.RT_ACT_ELU, True, True, True),      # stride 2 with residual, odd output width (33)
 ]
 
 

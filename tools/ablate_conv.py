@@ -13,10 +13,27 @@ VARIANTS = [(0, "full kernel"), (1, "no input gathers"), (2, "no weight loads"),
             (51, "no global memory traffic"), (128, "no input transform (Winograd)"), (179, "no memory, no transform")]
 
 
+# conv_f16mma_kernel (half2 mode): `build16` / `run16 [batch]`
+VARIANTS16 = [(0, "full kernel"), (1, "no input gathers"), (16, "no residual loads"), (32, "no stores"), (51, "no global memory traffic"),
+              (64, "no LDS reads"), (256, "no MFMA"), (4 + 8 + 64, "no LDS, no barriers"), (51 + 4 + 8 + 64, "MFMA only")]
+
+
+# occupancy of conv_f16mma_kernel: `buildocc16` / `runocc16 [batch]`
+VARIANTSOCC = [(10000 + w, "%d waves per SIMD" % w) for w in (4, 5, 6, 7, 8)]
+
+
 def main():
-    if sys.argv[1] == "build":
-        for m, _ in VARIANTS:
-            build.build_hip_ablation(m)
+    f16 = sys.argv[1].endswith("16")
+    if sys.argv[1].endswith("occ16"):
+        global VARIANTS16
+        VARIANTS16 = VARIANTSOCC
+    global VARIANTS
+    if f16:
+        VARIANTS = VARIANTS16
+    if sys.argv[1].startswith("build"):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(4) as ex:
+            list(ex.map(build.build_hip_ablation, [m for m, _ in VARIANTS]))
         return
     import numpy as np
     import torch
@@ -25,7 +42,8 @@ def main():
     h, w = 185, 629
     wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
     bias = np.random.randn(cout).astype(np.float32)
-    x = torch.randn(b, cin, h, w, device="cuda")
+    pitch = 640 if f16 else w
+    x = torch.randn(b, cin, h, pitch, device="cuda", dtype=torch.float16 if f16 else torch.float32)
     y = torch.empty_like(x)
     r = torch.randn_like(x)
     for m, name in VARIANTS:
@@ -36,6 +54,9 @@ def main():
             fn = getattr(k.lib, sym)
             fn.restype, fn.argtypes = res, args
         plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+        if f16:
+            plan.set_pitch(pitch, pitch)
+            plan.set_io_types(capi.RT_F16, capi.RT_F16)
         e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
         k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
         for _ in range(3):
