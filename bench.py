@@ -22,6 +22,9 @@ Extra objects on the JSON line:
                 after the timed region.  The kernel is the Winograd F(2x2,3x3) form: it issues 16/36 of those
                 multiplies on the matrix cores ("mfma_flops_executed"), which is why `achieved` can approach
                 the direct-form MFMA peak.
+                With --half2 (TensorRT half2 mode, BASELINE config C3) the same layers run conv_f16mma_kernel with
+                fp16 operands; at 2.5 PFLOP/s they are HBM-bound, so the object is priced in algorithmic bytes
+                against 8 TB/s.
   cpu_baseline  the oracle (torch CPU restatement of the reference graph, oracle/stereo_oracle.py) timed
                 on this host's cores on a bounded sample of the same workload.
 """
@@ -40,6 +43,7 @@ from redtail_amd import capi, parallel, synth  # noqa: E402
 
 W, H = 1257, 369
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0                 # same table: HBM3E, 8 TB/s
 HALF_W, HALF_H = 629, 185
 DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
 DOMINANT_BYTES = 4.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9 + 32)     # x, residual, y, weights, bias
@@ -103,7 +107,7 @@ def main():
                          "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop")
     ap.add_argument("--half2", action="store_true",
                     help="TensorRT half2 mode (BASELINE config C3): fp16 weight file, activations stored as fp16 between "
-                         "launches, fp32 arithmetic; the JSON line then says dtype f16-storage")
+                         "launches, fp16 operands on the matrix cores with fp32 accumulation; the JSON line then says dtype f16")
     ap.add_argument("--from-host", action="store_true", help="also measure the PCIe-inclusive rate (extra JSON object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -275,24 +279,35 @@ def main():
                     cnt += 1
         avg_s = tot / cnt * 1e-3
         achieved = DOMINANT_FLOPS * b / avg_s / 1e12
-        traffic, traffic_src = measured_traffic() if b == 1 else (None, None)
+        traffic, traffic_src = measured_traffic() if (b == 1 and not args.half2) else (None, None)
+        if args.half2:
+            # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the same layer HBM-bound, so it is
+            # priced in bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
+            h2_bytes = 2.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9) + 4.0 * 32
+            roofline = {"bound": "hbm", "kernel": "conv_f16mma_kernel<3,3,1> 3x3 32->32 @629x185 (+bias,+residual,+ELU), fp16 operands, fp32 accumulate",
+                        "achieved": h2_bytes * b / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": h2_bytes * b / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes": h2_bytes * b, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
+                        "flops_per_launch": DOMINANT_FLOPS * b}
+        else:
+            roofline = {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3)",
+                        "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
+                        "algorithmic_bytes": DOMINANT_BYTES * b,
+                        "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
+                        "flops_per_launch": DOMINANT_FLOPS * b, "mfma_flops_executed": DOMINANT_FLOPS * b * 16.0 / 36.0}
         out = {
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 storage, f32 arithmetic" if args.half2 else "f32", "data": "synthetic",
+            "dtype": "f16 (f32 accumulate)" if args.half2 else "f32", "data": "synthetic",
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,
                        "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3)",
-                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
-                         "algorithmic_bytes": DOMINANT_BYTES * b,
-                         "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
-                         "flops_per_launch": DOMINANT_FLOPS * b, "mfma_flops_executed": DOMINANT_FLOPS * b * 16.0 / 36.0},
+            "roofline": roofline,
         }
         if single is not None:
             out["single_context"] = single

@@ -163,9 +163,11 @@ int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const v
 int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
 
 /* Storage type (RT_F32 / RT_F16) of the input and of the output + residual tensors of a 2-D plan: TensorRT's half2
- * mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262) keeps activations in fp16 between layers; arithmetic
- * stays fp32 here.  Supported: fp16 -> fp16 everywhere, fp32 -> fp16 (first layers) on the direct-form kernels,
- * fp16 -> fp32 (last layer) on the small-output transposed kernel. */
+ * mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262) keeps activations in fp16 between layers.
+ * fp16 -> fp16 (3x3 stride 1/2, transposed 3x3 stride 2): the plan's weights are re-packed as fp16 and the stored
+ * values become the operands of the fp16 matrix instructions, accumulation stays fp32 (RT_NO_F16MMA=1 in the
+ * environment keeps fp32 arithmetic).  fp32 -> fp16 (first layers, direct-form kernels) and fp16 -> fp32 (last layer,
+ * small-output transposed kernel) compute in fp32.  Other combinations return RT_E_UNSUPPORTED. */
 int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
 
 typedef struct rtConv3dDesc {
