@@ -9,8 +9,9 @@
 // bias in the accumulator init, buffer addressing).  Per chunk of 16 input channels:
 //   LDS patch  [row][h][col][8 halfs]   channel = 8*h + e   -> one ds_read_b128 = the B operand of a lane (pixel, h)
 //   LDS weights [tap][h][co][8 halfs]                        -> one ds_read_b128 = the A operand of a lane (co, h)
-// and ONE MFMA (K = 16) per tap.  Staging: wave w gathers channel group h = w&1 for half of the patch pixels, 8 two-
-// byte loads per pixel packed to one 16-byte LDS write.  Tile: 4 rows x 32 pixels x 32 channels, 4 waves.
+// and ONE MFMA (K = 16) per tap.  Staging: wave w gathers channel group h = w&1 for half of the patch, one 4-byte
+// load per channel and PIXEL PAIR, transposed in registers to two 16-byte LDS writes.  Tile: 4 rows x 32 pixels x
+// 32 channels, 4 waves.
 //
 // Where the time goes (tools/ablate_conv.py run16, MI355X, 32->32 @185x629 + residual + ELU, batch 8: 53 us, the HBM
 // floor is ~18): with every global access compiled out the kernel still takes 30 us, without the MFMAs 50 -- a tile is
@@ -35,8 +36,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int KH, int KW, int S>
 struct ConvF16Cfg {
     static constexpr int TY = 4, TX = 32, CC = 16, TAPS = KH * KW;
-    static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW, NPIX = PR * PC;
-    static constexpr int NKP = ((NPIX + 1) / 2 + 63) / 64;        // patch pixels per lane (two pixel partitions)
+    static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW;
+    static constexpr int PCA = (PC + 1 + 1) / 2 * 2;              // LDS columns: alignment offset (0 / 1) + patch, whole pairs
+    static constexpr int NQ = PCA / 2, TG = PR * NQ;              // pixel pairs per row / per channel group
+    static constexpr int NKT = (TG + 127) / 128;                  // pairs per lane (two waves per channel group)
     static constexpr int W_SLOTS = TAPS * 2 * 32;                 // 16-byte slots of the weight slab of one chunk
     static constexpr int NK_W = (W_SLOTS + 255) / 256;
 };
@@ -48,11 +51,11 @@ struct ConvF16Cfg {
 template <int KH, int KW, int S>
 __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma_kernel(ConvArgs p) {
     using Cfg = ConvF16Cfg<KH, KW, S>;
-    constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, NPIX = Cfg::NPIX;
-    constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W;
+    constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PCA = Cfg::PCA, NQ = Cfg::NQ;
+    constexpr int NKT = Cfg::NKT, NK_W = Cfg::NK_W;
     constexpr unsigned ES = 2;
 
-    __shared__ __attribute__((aligned(16))) f32x4 sIn[Cfg::PR * 2 * PC];
+    __shared__ __attribute__((aligned(16))) f32x4 sIn[Cfg::PR * 2 * PCA];
     __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
 
     const int tid = threadIdx.x;
@@ -84,19 +87,25 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     }
     const int act = p.act;
 
-    // ---- staging roles: wave w -> channel group g = w & 1 (channels 8g .. 8g+7 of the chunk), pixel half w >> 1 -----
+    // ---- staging roles: wave w -> channel group g = w & 1 (channels 8g .. 8g+7 of the chunk), pair range w >> 1 ------
+    // A lane gathers PIXEL PAIRS (one 4-byte load per channel: half the loads of a per-pixel gather and no register
+    // holds a lone half).  Pairs start at even columns -- the row pitch is even -- so the LDS patch starts at the
+    // even column at or below the first patch column.
     const int g = wv & 1, spart = wv >> 1;
     const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 8 * g;
-    unsigned voff[NKP];
-    int lidx[NKP];
+    const int ix0 = tx0 * S - pad_x, ax0 = ix0 & ~1, dcol = ix0 - ax0;
+    unsigned voff[NKT];
+    bool odd_ok[NKT];        // the pair's second pixel is inside the row (columns >= Wi of a pitched row hold anything)
+    int lidx[NKT];
 #pragma unroll
-    for (int k = 0; k < NKP; k++) {
-        const int pidx = spart * (NKP * 64) + lane + 64 * k;
-        const int pr = pidx / PC, pc = pidx - pr * PC;
-        const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
-        const bool own = pidx < NPIX;
+    for (int k = 0; k < NKT; k++) {
+        const int q = spart * (NKT * 64) + lane + 64 * k;
+        const int pr = q / NQ, qc = q - pr * NQ;
+        const int iy = ty0 * S - pad_y + pr, ix = ax0 + 2 * qc;
+        const bool own = q < Cfg::TG;
         voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ES : kBufOOB;
-        lidx[k] = own ? (pr * 2 + g) * PC + pc : -1;
+        odd_ok[k] = ix + 1 < p.Wi;
+        lidx[k] = own ? (pr * 2 + g) * PCA + 2 * qc : -1;
     }
     // w_off and the slab size count 16-byte slots here (8 halfs)
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + (w_off + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS) * 16;
@@ -108,24 +117,29 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
         wvoff[k] = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
     }
 
-    f32x4 rin[NKP];          // 8 halfs per patch pixel
+    f32x4 rin[NKT][2];       // [pair][pixel]: 8 halfs (channels) per patch pixel
     f32x4 rw[NK_W];
     auto prefetch = [&](int ch) {
-        unsigned short u[NKP][8];
+        unsigned u[NKT][8];      // channel e of the chunk's group: pixel 0 in the low half, pixel 1 in the high half
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int off = tab[ch * CC + e];                      // wave-uniform scalar load
             const buf_rsrc rs = make_buf(xb, off >= 0);
             const unsigned so = (unsigned)off * ES;
 #pragma unroll
-            for (int k = 0; k < NKP; k++) u[k][e] = kAblGather ? (unsigned short)(off + (int)voff[k]) : __builtin_amdgcn_raw_buffer_load_b16(rs, voff[k], so, 0);
+            for (int k = 0; k < NKT; k++) u[k][e] = kAblGather ? (unsigned)(off + (int)voff[k]) : __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], so, 0);
         }
 #pragma unroll
-        for (int k = 0; k < NKP; k++) {
-            u32x4_t w4;
+        for (int k = 0; k < NKT; k++) {                            // 8 x (2 pixels) -> 2 x (8 channels)
+            u32x4_t p0, p1;
 #pragma unroll
-            for (int q = 0; q < 4; q++) w4[q] = (unsigned)u[k][2 * q] | ((unsigned)u[k][2 * q + 1] << 16);
-            rin[k] = __builtin_bit_cast(f32x4, w4);
+            for (int q = 0; q < 4; q++) {
+                const unsigned a = u[k][2 * q], b = u[k][2 * q + 1];
+                p0[q] = (a & 0xffffu) | (b << 16);
+                p1[q] = odd_ok[k] ? ((a >> 16) | (b & 0xffff0000u)) : 0u;
+            }
+            rin[k][0] = __builtin_bit_cast(f32x4, p0);
+            rin[k][1] = __builtin_bit_cast(f32x4, p1);
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
 #pragma unroll
@@ -133,8 +147,11 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     };
     auto stage_to_lds = [&]() {
 #pragma unroll
-        for (int k = 0; k < NKP; k++)
-            if (lidx[k] >= 0 && (!kAblLdsWr || rin[k][0] == 12345.678f)) sIn[lidx[k]] = rin[k];
+        for (int k = 0; k < NKT; k++)
+            if (lidx[k] >= 0 && (!kAblLdsWr || rin[k][0][0] == 12345.678f)) {
+                sIn[lidx[k]] = rin[k][0];
+                sIn[lidx[k] + 1] = rin[k][1];
+            }
 #pragma unroll
         for (int k = 0; k < NK_W; k++) {
             const int idx = tid + 256 * k;
@@ -171,14 +188,14 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     }
 
     const int a_base = half * 32 + l31;
-    const int b_base = (wv * S * 2 + half) * PC + l31 * S;
+    const int b_base = (wv * S * 2 + half) * PCA + dcol + l31 * S;
     auto compute = [&]() {
 #pragma unroll
         for (int t = 0; t < TAPS; t++) {
             if (!((tap_mask >> t) & 1u)) continue;                  // wave-uniform
             const int r = t / KW, s = t % KW;
             const f32x4 av = kAblLdsRd ? f32x4{(float)(a_base + t), 1.f, 2.f, 3.f} : sW[a_base + t * 64];
-            const f32x4 bv = kAblLdsRd ? f32x4{(float)(b_base - t), 3.f, 2.f, 1.f} : sIn[b_base + r * 2 * PC + s];
+            const f32x4 bv = kAblLdsRd ? f32x4{(float)(b_base - t), 3.f, 2.f, 1.f} : sIn[b_base + r * 2 * PCA + s];
             const f16x8_t a = __builtin_bit_cast(f16x8_t, av);
             const f16x8_t b = __builtin_bit_cast(f16x8_t, bv);
             if (kAblMfma) acc[t & 15] += av[0] * bv[1];

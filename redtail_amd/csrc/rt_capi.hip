@@ -1099,6 +1099,8 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
     const int ip = in_pitch ? in_pitch : plan->win, op = out_pitch ? out_pitch : Wout;
     RT_REQUIRE(ip >= plan->win && op >= Wout, "rt_conv_plan_set_pitch: pitch smaller than the row");
     RT_REQUIRE((int64_t)plan->cin * plan->hin * ip < (1ll << 29), "rt_conv_plan_set_pitch: input sample exceeds 2 GB");
+    for (const SubConv& sc : plan->subs)
+        RT_REQUIRE(!sc.f16mma || ip % 2 == 0, "rt_conv_plan_set_pitch: the fp16-arithmetic kernel needs an even input pitch");
     const int old_op = plan->out_pitch ? plan->out_pitch : Wout;
     auto repitch = [&](int64_t off) { return (off / old_op) * op + off % old_op; };
     for (SubConv& sc : plan->subs) {
@@ -1203,7 +1205,10 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
         if (!xf && !yf) { sc.x_f16 = sc.y_f16 = 0; continue; }
         if (sc.direct) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the direct (Cout <= 2) kernel is fp32 only");
         // both tensors fp16: fp16 operands on the matrix cores (the stored values are the operands, fp32 accumulate)
-        if (xf && yf && !sc.small3d && !sc.f16mma && plan->subs.size() == 1 && f16mma_window(sc) && env_int("RT_NO_F16MMA", 0) == 0) {
+        // (its gathers move 4-byte pixel pairs: row pitch, plane and sample strides must be even)
+        const int xp = sc.x_pitch ? sc.x_pitch : sc.Wi;
+        if (xf && yf && !sc.small3d && !sc.f16mma && plan->subs.size() == 1 && f16mma_window(sc) && xp % 2 == 0 &&
+            plan->x_bstride % 2 == 0 && env_int("RT_NO_F16MMA", 0) == 0) {
             if (int rc = repack_f16mma(plan)) return rc;
         }
         if (sc.f16mma) {

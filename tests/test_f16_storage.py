@@ -71,7 +71,7 @@ def test_conv2d_f16_storage(backend, cin, cout, h, w, k, stride, tr, act, resid,
     plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, pad, act=act, has_residual=resid, transposed=tr)
     plan.set_pitch(ip, op)
     plan.set_io_types(capi.RT_F16 if x16 else capi.RT_F32, capi.RT_F16 if y16 else capi.RT_F32)
-    xin = dev16(backend, pitched(x, ip, 0.0)) if x16 else backend.dev(pitched(x, ip))
+    xin = dev16(backend, pitched(x, ip)) if x16 else backend.dev(pitched(x, ip))      # NaN in the padding columns
     rin = None
     if resid:
         rin = dev16(backend, pitched(res, op, 0.0)) if y16 else backend.dev(pitched(res, op))

@@ -20,6 +20,8 @@ VARIANTS16 = [(0, "full kernel"), (1, "no input gathers"), (16, "no residual loa
 
 # occupancy of conv_f16mma_kernel: `buildocc16` / `runocc16 [batch]`
 VARIANTSOCC = [(10000 + w, "%d waves per SIMD" % w) for w in (4, 5, 6, 7, 8)]
+if os.environ.get("RT_ABL_AB"):          # A/B against a library built from another revision (tools/build/..._abl20000.so)
+    VARIANTSOCC = [(20000, "reference revision"), (10008, "working tree")]
 
 
 def main():
