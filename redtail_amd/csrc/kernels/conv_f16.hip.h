@@ -13,16 +13,20 @@
 // load per channel and PIXEL PAIR, transposed in registers to two 16-byte LDS writes.  Tile: 4 rows x 32 pixels x
 // 32 channels, 4 waves.
 //
-// Where the time goes (tools/ablate_conv.py run16, MI355X, 32->32 @185x629 + residual + ELU, batch 8: 53 us, the HBM
-// floor is ~18): with every global access compiled out the kernel still takes 30 us, without the MFMAs 50 -- a tile is
-// only ~600 MFMA cycles, so workgroup turnaround (launch, kernel arguments, gather table, bias, two exposed memory
-// latencies) bounds it and throughput follows occupancy (6 workgroups per CU here).  Measured and rejected, both
-// slower than this form: (a) 8-byte pixel-quad gathers transposed in registers + pixel-pair stores through a DPP
-// lane swap (fewer, wider memory instructions, but 112 VGPRs -> 4 workgroups per CU): -17 %; (b) a persistent
-// grid with LDS-resident weights and next-tile prefetch one chunk ahead (125 VGPRs, 4 per CU): 2x slower, the
-// tiles of one workgroup serialise on the gather latency that independent workgroups overlap.  What would be next:
-// a persistent form with the whole next tile (both chunks + residual) in flight, or an NC/8HW8 tensor layout
-// (one 16-byte access per pixel and channel group on both sides).
+// Where the time goes (MI355X, 32->32 @185x629 + residual + ELU, batch 8: 45 us; HBM floor ~18, MFMA ~8):
+//  * tools/time_phases.py 8 f16 (s_memtime stamps): of a workgroup's 33 k cycles, 17 k pass before its first 31
+//    vector-memory instructions (16 residual, 4 bias, 8 gathers, 3 weights) are ISSUED and 8 k while the 11 of the
+//    second chunk are; data is there ~100 cycles after the issue completes.  With 32 waves per CU that is ~16 cycles
+//    of the CU's memory front end per wave-instruction -- the kernel is bound by the number of memory instructions
+//    x cache lines they touch, not by bytes: a planar fp16 row of a 32-pixel tile is 64 B, half a line.
+//  * tools/ablate_conv.py runocc16: 80 / 67 / 61 / 58 / 51 us at 4 .. 8 waves per SIMD -> registers are budgeted
+//    for 8 (RT_F16_WAVES); run16: 30 us remain with every global access compiled out, 50 without the MFMAs.
+//  * pixel-PAIR gathers (this form) halved the gather instructions: 51.5 -> 45.3 us.  Measured and rejected:
+//    (a) 8-byte pixel-quad gathers + pixel-pair stores through a DPP lane swap: 112 VGPRs -> 4 waves, -17 %, and
+//    the pair stores alone cost 13 % (same half-lines per plane, plus the swap); (b) a persistent grid with
+//    LDS-resident weights and next-chunk prefetch: 2x slower (4 waves, tiles of a workgroup serialise).
+//  What removes the bound is a channel-interleaved tensor layout (NC/8HW8: one 16-byte access per pixel and channel
+//  group, every line fully used: ~230 lines per tile instead of ~540) -- an executor-wide change, next round.
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
@@ -59,6 +63,12 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
 
     const int tid = threadIdx.x;
+#ifdef RT_KERNEL_TIMING
+    unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
+    int dbi = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    RT_TSTAMP();                                  // 0: start
     const int lane = tid & 63;
     const int half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,14 +214,18 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     };
 
     prefetch(0);
+    RT_TSTAMP();                                  // 1: residual + first gathers issued
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] += rv[r];
+    RT_TSTAMP();                                  // 2: residual arrived
     for (int ch = 0; ch < nchunks; ch++) {
         if (ch) wg_barrier();
         stage_to_lds();
         wg_barrier();
+        RT_TSTAMP();                              // 3, 5: chunk in LDS (its gathers arrived)
         if (ch + 1 < nchunks) prefetch(ch + 1);
         compute();
+        RT_TSTAMP();                              // 4, 6: MFMAs issued
     }
 
     auto epilogue = [&](auto ACT) {
@@ -224,9 +238,17 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
             if (!kAblStore || v == 12345.678f) Io<_Float16>::store(v, rs, vo, (unsigned)(cs * cs32) * ES);
         }
     };
+    RT_TSTAMP();                                  // 7: epilogue start
     if (act == 1) epilogue(std::integral_constant<int, 1>{});
     else if (act == 2) epilogue(std::integral_constant<int, 2>{});
     else epilogue(std::integral_constant<int, 0>{});
+#ifdef RT_KERNEL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RT_TSTAMP();                                  // 8: stores acknowledged
+#ifdef RT_KERNEL_TIMING
+    if (dbgp && tid == 0) dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
 }
 
 }  // namespace rt

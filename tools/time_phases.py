@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from redtail_amd import build, capi  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+F16 = len(sys.argv) > 2 and sys.argv[2] == "f16"      # conv_f16mma_kernel (half2 mode) instead of the fp32 kernel
 k = capi.KernelLib.__new__(capi.KernelLib)
 import ctypes  # noqa: E402
 k.path = os.environ.get("RT_TIMING_LIB", os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so"))
@@ -23,9 +24,12 @@ h, w = 185, 629
 wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
 bias = np.random.randn(cout).astype(np.float32)
 plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
-x = torch.randn(b, cin, h, w, device="cuda")
+x = torch.randn(b, cin, h, 640 if F16 else w, device="cuda", dtype=torch.float16 if F16 else torch.float32)
 y = torch.empty_like(x)
 r = torch.randn_like(x)
+if F16:
+    plan.set_pitch(640, 640)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
 nwg = 47 * 20 * b          # 4 x 32 pixel tiles
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
@@ -37,9 +41,13 @@ torch.cuda.synchronize()
 t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
 names = ["start", "c0 sync1", "c0 ready", "c1 sync1", "c1 ready", "c2 sync1", "c2 ready", "c3 sync1", "c3 ready",
          "epilogue start", "end"]
+if F16:
+    names = ["start", "loads issued", "residual here", "c0 in LDS", "c0 MFMAs issued", "c1 in LDS", "c1 MFMAs issued",
+             "epilogue start", "stores done"]
+    t[:, 9:11] = t[:, 8:9]
 d = np.diff(t[:, :11], axis=1)
 print("batch %d: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % (b, nwg))
-for i in range(10):
+for i in range(len(names) - 1):
     print("  %-16s -> %-16s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10),
                                                  np.percentile(d[:, i], 90)))
 print("  workgroup lifetime mean %.1f" % (t[:, 10] - t[:, 0]).mean())
