@@ -170,6 +170,15 @@ int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
  * small-output transposed kernel) compute in fp32.  Other combinations return RT_E_UNSUPPORTED. */
 int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
 
+/* Channel-interleaved fp16 tensors, (C/8, H, pitch, 8) per sample: one 16-byte slot per pixel and group of 8 channels.
+ * Not in the reference (TensorRT owns its internal layouts; its own fp16 formats are of this kind, PluginFormat
+ * kNC2HW2 / kNHWC8 in NvInfer.h).  The fp16-arithmetic kernel moves such tensors in full cache lines; the executor
+ * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic touch.  rt_conv_plan_supports_il8: 1 if
+ * the plan can take them (after rt_conv_plan_set_io_types(F16, F16)); rt_conv_plan_set_layouts: layout (0 planar,
+ * 1 interleaved) of the input, the output and the residual tensor. */
+int rt_conv_plan_supports_il8(const rtConvPlan* plan);
+int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8);
+
 typedef struct rtConv3dDesc {
     int C, K;               /* conv: input channels C, output channels K.  Transposed op: K = INPUT   */
                             /* channels (tensor KDHW), C = OUTPUT channels (tensor DCHW)             */

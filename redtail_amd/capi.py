@@ -75,6 +75,8 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_plan_set_io_types": (c_int, [c_void_p, c_int, c_int]),
+    "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
+    "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_plan_destroy": (c_int, [c_void_p]),
 }
@@ -209,6 +211,13 @@ class ConvPlan:
 
     def set_io_types(self, x_dtype, y_dtype):
         self.klib.check(self.klib.lib.rt_conv_plan_set_io_types(self.handle, x_dtype, y_dtype), "rt_conv_plan_set_io_types")
+
+    def supports_il8(self):
+        return bool(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
+
+    def set_layouts(self, x_il8, y_il8, r_il8=False):
+        """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
+        self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")
 
     def enqueue(self, x, y, residual=None, batch=1, stream=None):
         self.klib.check(self.klib.lib.rt_conv_enqueue(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream),

@@ -59,6 +59,7 @@ struct TensorImpl : public ITensor {
     int stream = 0;             // which of the two execution streams produces it
     int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
     bool f16 = false;           // stored as fp16 (half2 mode); only tensors that only layout-aware launches touch
+    bool il8 = false;           // fp16 and channel-interleaved, (C/8, H, pitch, 8): only fp16-arithmetic 3x3 plans touch it
 
     void setName(const char* n) override { name = n ? n : ""; }
     const char* getName() const override { return name.c_str(); }
@@ -771,7 +772,35 @@ void EngineImpl::assignPitch() {
         }
         log_.log(ILogger::Severity::kERROR, rt_last_error_string());
         ok_ = false;
+        return;
     }
+    if (!f16) return;
+    // Channel-interleaved storage (C/8, H, pitch, 8) for the fp16 tensors that only fp16-arithmetic 3x3 stride-1 plans
+    // read and write -- the inside of the two feature towers, 30 of the 47 internal tensors of ResNet-18 2D: the
+    // kernel then moves whole cache lines (conv_f16.hip.h).  A plan takes any mix of planar and interleaved tensors,
+    // so the layout is a per-tensor property and nothing is converted anywhere.
+    std::vector<char> il(tensors_.size(), 0);
+    for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 && t->dims.d[0] % 8 == 0;
+    for (auto& op : ops_) {
+        if (op.kind == OpKind::kConv && rt_conv_plan_supports_il8(op.plan)) continue;
+        for (int i : op.in) il[root(i)] = 0;
+        il[root(op.out)] = 0;
+        if (op.resid >= 0) il[root(op.resid)] = 0;
+    }
+    for (auto& op : ops_) {
+        if (op.kind != OpKind::kConv) continue;
+        const int xi = il[root(op.in[0])], yi = il[root(op.out)], ri = op.resid >= 0 ? il[root(op.resid)] : 0;
+        if (!(xi || yi || ri)) continue;
+        if (rt_conv_plan_set_layouts(op.plan, xi, yi, ri) != 0) {
+            log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+            ok_ = false;
+            return;
+        }
+    }
+    int n_il = 0;
+    for (auto& t : tensors_) t->il8 = il[t->id] != 0;
+    for (auto& op : ops_) n_il += il[root(op.out)] != 0;         // tensors that launches really write
+    log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n_il) + " of " + std::to_string(ops_.size()) + " launches write channel-interleaved tensors").c_str());
 }
 
 void EngineImpl::assignStreams() {

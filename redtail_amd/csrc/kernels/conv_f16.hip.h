@@ -44,6 +44,7 @@ struct ConvF16Cfg {
     static constexpr int PCA = (PC + 1 + 1) / 2 * 2;              // LDS columns: alignment offset (0 / 1) + patch, whole pairs
     static constexpr int NQ = PCA / 2, TG = PR * NQ;              // pixel pairs per row / per channel group
     static constexpr int NKT = (TG + 127) / 128;                  // pairs per lane (two waves per channel group)
+    static constexpr int NPIX = PR * PC, NKP = ((NPIX + 1) / 2 + 63) / 64;   // interleaved input: patch pixels per lane
     static constexpr int W_SLOTS = TAPS * 2 * 32;                 // 16-byte slots of the weight slab of one chunk
     static constexpr int NK_W = (W_SLOTS + 255) / 256;
 };
@@ -52,11 +53,19 @@ struct ConvF16Cfg {
 #ifndef RT_F16_WAVES
 #define RT_F16_WAVES 8
 #endif
-template <int KH, int KW, int S>
+// XIL8 / YIL8: the input / output tensor is channel-interleaved, (C/8, H, pitch, 8): one 16-byte slot per pixel and
+// group of 8 channels (the executor's layout for fp16 tensors that only this kernel touches).  A gather is then ONE
+// 16-byte load per pixel and group that goes to LDS as it is, a lane stores its 4 consecutive channels of a pixel as
+// 8 bytes, and every cache line is used in full: ~230 lines per tile instead of ~540 half-used ones.  The offset of
+// channel group c/8 equals the planar offset of channel c, so gather table and channel strides are shared.
+// The residual's layout is a run-time flag (ConvArgs::r_il8): a block's skip connection may be either.
+template <int KH, int KW, int S, bool XIL8 = false, bool YIL8 = false>
 __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma_kernel(ConvArgs p) {
     using Cfg = ConvF16Cfg<KH, KW, S>;
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PCA = Cfg::PCA, NQ = Cfg::NQ;
     constexpr int NKT = Cfg::NKT, NK_W = Cfg::NK_W;
+    constexpr int NV = XIL8 ? Cfg::NKP : NKT;     // gather positions per lane (pixels / pixel pairs)
+    constexpr int NS = XIL8 ? Cfg::NKP : 2 * NKT; // 16-byte LDS slots per lane
     constexpr unsigned ES = 2;
 
     __shared__ __attribute__((aligned(16))) f32x4 sIn[Cfg::PR * 2 * PCA];
@@ -104,18 +113,28 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     const int g = wv & 1, spart = wv >> 1;
     const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 8 * g;
     const int ix0 = tx0 * S - pad_x, ax0 = ix0 & ~1, dcol = ix0 - ax0;
-    unsigned voff[NKT];
-    bool odd_ok[NKT];        // the pair's second pixel is inside the row (columns >= Wi of a pitched row hold anything)
-    int lidx[NKT];
+    unsigned voff[NV];
+    bool odd_ok[NV];         // the pair's second pixel is inside the row (columns >= Wi of a pitched row hold anything)
+    int lidx[NV];
 #pragma unroll
-    for (int k = 0; k < NKT; k++) {
-        const int q = spart * (NKT * 64) + lane + 64 * k;
-        const int pr = q / NQ, qc = q - pr * NQ;
-        const int iy = ty0 * S - pad_y + pr, ix = ax0 + 2 * qc;
-        const bool own = q < Cfg::TG;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ES : kBufOOB;
-        odd_ok[k] = ix + 1 < p.Wi;
-        lidx[k] = own ? (pr * 2 + g) * PCA + 2 * qc : -1;
+    for (int k = 0; k < NV; k++) {
+        if constexpr (XIL8) {
+            const int pidx = spart * (Cfg::NKP * 64) + lane + 64 * k;
+            const int pr = pidx / Cfg::PC, pc = pidx - pr * Cfg::PC;
+            const int iy = ty0 * S - pad_y + pr, ix = ix0 + pc;
+            const bool own = pidx < Cfg::NPIX;
+            voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB;
+            odd_ok[k] = false;
+            lidx[k] = own ? (pr * 2 + g) * PCA + dcol + pc : -1;
+        } else {
+            const int q = spart * (NKT * 64) + lane + 64 * k;
+            const int pr = q / NQ, qc = q - pr * NQ;
+            const int iy = ty0 * S - pad_y + pr, ix = ax0 + 2 * qc;
+            const bool own = q < Cfg::TG;
+            voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ES : kBufOOB;
+            odd_ok[k] = ix + 1 < p.Wi;
+            lidx[k] = own ? (pr * 2 + g) * PCA + 2 * qc : -1;
+        }
     }
     // w_off and the slab size count 16-byte slots here (8 halfs)
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + (w_off + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS) * 16;
@@ -127,29 +146,38 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
         wvoff[k] = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
     }
 
-    f32x4 rin[NKT][2];       // [pair][pixel]: 8 halfs (channels) per patch pixel
+    f32x4 rin[NS];           // 8 halfs (channels) per patch pixel; planar input: [pair][pixel]
     f32x4 rw[NK_W];
     auto prefetch = [&](int ch) {
-        unsigned u[NKT][8];      // channel e of the chunk's group: pixel 0 in the low half, pixel 1 in the high half
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int off = tab[ch * CC + e];                      // wave-uniform scalar load
+        if constexpr (XIL8) {
+            const int off = tab[ch * CC];                          // group offset == planar offset of its first channel
             const buf_rsrc rs = make_buf(xb, off >= 0);
             const unsigned so = (unsigned)off * ES;
 #pragma unroll
-            for (int k = 0; k < NKT; k++) u[k][e] = kAblGather ? (unsigned)(off + (int)voff[k]) : __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], so, 0);
-        }
+            for (int k = 0; k < NV; k++)
+                rin[k] = kAblGather ? f32x4{(float)(off + (int)voff[k]), 0.f, 0.f, 0.f} : buf_load4(rs, voff[k], so);
+        } else {
+            unsigned u[NKT][8];  // channel e of the chunk's group: pixel 0 in the low half, pixel 1 in the high half
 #pragma unroll
-        for (int k = 0; k < NKT; k++) {                            // 8 x (2 pixels) -> 2 x (8 channels)
-            u32x4_t p0, p1;
+            for (int e = 0; e < 8; e++) {
+                const int off = tab[ch * CC + e];                  // wave-uniform scalar load
+                const buf_rsrc rs = make_buf(xb, off >= 0);
+                const unsigned so = (unsigned)off * ES;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned a = u[k][2 * q], b = u[k][2 * q + 1];
-                p0[q] = (a & 0xffffu) | (b << 16);
-                p1[q] = odd_ok[k] ? ((a >> 16) | (b & 0xffff0000u)) : 0u;
+                for (int k = 0; k < NKT; k++) u[k][e] = kAblGather ? (unsigned)(off + (int)voff[k]) : __builtin_amdgcn_raw_buffer_load_b32(rs, voff[k], so, 0);
             }
-            rin[k][0] = __builtin_bit_cast(f32x4, p0);
-            rin[k][1] = __builtin_bit_cast(f32x4, p1);
+#pragma unroll
+            for (int k = 0; k < NKT; k++) {                        // 8 x (2 pixels) -> 2 x (8 channels)
+                u32x4_t p0, p1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned a = u[k][2 * q], b = u[k][2 * q + 1];
+                    p0[q] = (a & 0xffffu) | (b << 16);
+                    p1[q] = odd_ok[k] ? ((a >> 16) | (b & 0xffff0000u)) : 0u;
+                }
+                rin[2 * k] = __builtin_bit_cast(f32x4, p0);
+                rin[2 * k + 1] = __builtin_bit_cast(f32x4, p1);
+            }
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
 #pragma unroll
@@ -157,10 +185,14 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     };
     auto stage_to_lds = [&]() {
 #pragma unroll
-        for (int k = 0; k < NKT; k++)
-            if (lidx[k] >= 0 && (!kAblLdsWr || rin[k][0][0] == 12345.678f)) {
-                sIn[lidx[k]] = rin[k][0];
-                sIn[lidx[k] + 1] = rin[k][1];
+        for (int k = 0; k < NV; k++)
+            if (lidx[k] >= 0 && (!kAblLdsWr || rin[k][0] == 12345.678f)) {
+                if constexpr (XIL8) {
+                    sIn[lidx[k]] = rin[k];
+                } else {
+                    sIn[lidx[k]] = rin[2 * k];
+                    sIn[lidx[k] + 1] = rin[2 * k + 1];
+                }
             }
 #pragma unroll
         for (int k = 0; k < NK_W; k++) {
@@ -175,8 +207,12 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
     const bool tail8 = (p.Cout & 7) != 0;
     const int oy = ty0 + wv, ox = tx0 + l31;
-    const unsigned yvoff = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ES : kBufOOB;
-    const unsigned rvoff = yvoff == kBufOOB ? kBufOOB : yvoff + (unsigned)(4 * half * (rs32 - cs32)) * ES;
+    const bool inb = oy < Ho && ox < Wo;
+    const bool r_il8 = p.r_il8 != 0;              // uniform
+    // planar: element (c, y, x) at c*cstride + y*ystride + x*xstride; interleaved: 16-byte pixel slots, lane's 4 channels
+    const unsigned il8off = (unsigned)((oy * p.y_ystride + ox) * 8 + 4 * half) * ES;
+    const unsigned yvoff = !inb ? kBufOOB : (YIL8 ? il8off : (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ES);
+    const unsigned rvoff = !inb ? kBufOOB : (r_il8 ? il8off : (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * rs32) * ES);
 
     f32x16 acc;
     {
@@ -189,12 +225,24 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
         }
     }
     float rv[16];
+    if (r_il8) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
-        const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), (p.resid != nullptr) & (cs < p.Cout));
-        const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : rvoff;
-        rv[r] = kAblResid ? (float)cs : Io<_Float16>::load(rs, vo, (unsigned)(cs * rs32) * ES);
+        for (int q = 0; q < 4; q++) {                               // 4 consecutive channels of the pixel: 8 bytes
+            const int cs = nblk * 32 + 8 * q;
+            const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), (p.resid != nullptr) & (cs < p.Cout));
+            const u32x2_t u = kAblResid ? u32x2_t{0u, 0u} : __builtin_amdgcn_raw_buffer_load_b64(rs, rvoff, (unsigned)(cs * rs32) * ES, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                rv[4 * q + e] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u[e >> 1] >> (16 * (e & 1))));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
+            const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), (p.resid != nullptr) & (cs < p.Cout));
+            const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : rvoff;
+            rv[r] = kAblResid ? (float)cs : Io<_Float16>::load(rs, vo, (unsigned)(cs * rs32) * ES);
+        }
     }
 
     const int a_base = half * 32 + l31;
@@ -229,13 +277,30 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     }
 
     auto epilogue = [&](auto ACT) {
+        if constexpr (YIL8) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
-            const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
-            const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff;
-            const float v = apply_act_fast(acc[r], decltype(ACT)::value);
-            if (!kAblStore || v == 12345.678f) Io<_Float16>::store(v, rs, vo, (unsigned)(cs * cs32) * ES);
+            for (int q = 0; q < 4; q++) {
+                const int cs = nblk * 32 + 8 * q;
+                const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
+                u32x2_t o;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = apply_act_fast(acc[4 * q + e], decltype(ACT)::value);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    o[e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * e]) |
+                           ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * e + 1]) << 16);
+                if (!kAblStore || v[0] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b64(o, rs, yvoff, (unsigned)(cs * cs32) * ES, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int cs = nblk * 32 + (r & 3) + 8 * (r >> 2);
+                const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
+                const unsigned vo = (tail8 && cs + 4 * half >= p.Cout) ? kBufOOB : yvoff;
+                const float v = apply_act_fast(acc[r], decltype(ACT)::value);
+                if (!kAblStore || v == 12345.678f) Io<_Float16>::store(v, rs, vo, (unsigned)(cs * cs32) * ES);
+            }
         }
     };
     RT_TSTAMP();                                  // 7: epilogue start

@@ -73,6 +73,7 @@ struct ConvArgs {
     int y_ystride, y_xstride;
     int64_t r_cstride;     // residual: channel stride and per-sample stride (== y_cstride / y_bstride unless the
     int64_t r_bstride;     // launch writes a transposed layout, e.g. Conv3DTranspose + Transform in one pass)
+    int r_il8;             // conv_f16mma_kernel: the residual tensor is channel-interleaved (see conv_f16.hip.h)
 };
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with

@@ -416,6 +416,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
     int x_f16 = 0, y_f16 = 0;           // storage type of input / output + residual (half2 mode), set by rt_conv_plan_set_io_types
     int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
+    int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
@@ -1225,6 +1226,28 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
     return 0;
 }
 
+// Channel-interleaved tensors for the fp16-arithmetic kernel (see conv_f16.hip.h): which plans can take them ...
+extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
+    if (!plan || !plan->is2d || plan->is_deconv || plan->subs.size() != 1) return 0;
+    const SubConv& sc = plan->subs[0];
+    return sc.f16mma && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && !sc.zs_dev && sc.y_xstride == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0 &&
+           env_int("RT_NO_IL8", 0) == 0;
+}
+// ... and the layout of each of its tensors (0 = planar NCHW with a row pitch, 1 = (C/8, H, pitch, 8))
+extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
+    RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
+    if (!x_il8 && !y_il8 && !r_il8) {
+        for (SubConv& sc : plan->subs) sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
+        return 0;
+    }
+    if (!rt_conv_plan_supports_il8(plan))
+        return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: only 3x3 stride-1 plans in fp16 arithmetic with channel counts that are multiples of 8 take interleaved tensors");
+    RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
+    SubConv& sc = plan->subs[0];
+    sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
+    return 0;
+}
+
 extern "C" int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]) {
     RT_REQUIRE(plan && dims, "rt_conv_plan_out_dims: null pointer");
     for (int i = 0; i < 4; i++) dims[i] = plan->out_dims[i];
@@ -1288,6 +1311,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
         a.r_cstride = sc.r_cstride ? sc.r_cstride : sc.y_cstride;
         a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
+        a.r_il8 = sc.r_il8;
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
@@ -1310,6 +1334,14 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (sc.f16mma) {
+            if (sc.x_il8 || sc.y_il8 || sc.r_il8) {       // 3x3 stride 1 only (rt_conv_plan_supports_il8)
+                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, true, true>), grid, dim3(256), 0, S(s), a);
+                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, true, false>), grid, dim3(256), 0, S(s), a);
+                else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, false, true>), grid, dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, false, false>), grid, dim3(256), 0, S(s), a);
+                RT_LAUNCH_CHECK("conv_f16mma_kernel<3,3,1> (interleaved tensors)");
+                continue;
+            }
 #define RT_F16CASE(kh, kw, st)                                                                              \
     if (sc.KH == kh && sc.KW == kw && sc.S == st) {                                                         \
         hipLaunchKernelGGL((rt::conv_f16mma_kernel<kh, kw, st>), grid, dim3(256), 0, S(s), a);              \

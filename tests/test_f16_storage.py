@@ -95,3 +95,58 @@ def test_corr_softargmax_f16_storage(backend):
     res = host(backend, out)
     assert np.abs(res[..., :w] - ref).max() <= 8e-3          # half ulp of values below 16
     assert np.isnan(res[..., w:]).all()
+
+
+def to_il8(a):
+    """(N, C, H, P) planar -> (N, C/8, H, P, 8) channel-interleaved"""
+    n, c, h, p = a.shape
+    return np.ascontiguousarray(a.reshape(n, c // 8, 8, h, p).transpose(0, 1, 3, 4, 2))
+
+
+def from_il8(a):
+    n, g, h, p, _ = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(n, g * 8, h, p)
+
+
+@pytest.mark.parametrize("x_il8,y_il8,r_il8", [(1, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1), (1, 0, 0)])
+@pytest.mark.parametrize("cin,cout,h,w,resid", [(32, 32, 9, 37, True), (16, 72, 6, 70, True), (40, 24, 7, 33, False)])
+def test_conv2d_f16_interleaved(backend, cin, cout, h, w, resid, x_il8, y_il8, r_il8):
+    """the fp16-arithmetic kernel on channel-interleaved tensors, every combination with planar ones"""
+    if r_il8 and not resid:
+        pytest.skip("no residual")
+    batch, act = 2, capi.RT_ACT_ELU
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x, b = q16(rnd(batch, cin, h, w)), rnd(cout)
+    wt = q16(rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)))
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1)
+    res = q16(rnd(*ref.shape)) if resid else None
+    if resid:
+        ref = ref + T(res)
+    ref = O.elu(ref).numpy()
+    pitch = (w + 63) // 64 * 64
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=resid)
+    plan.set_pitch(pitch, pitch)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    assert plan.supports_il8()
+    plan.set_layouts(x_il8, y_il8, r_il8)
+    lay = lambda a, il: to_il8(a) if il else a
+    xin = dev16(backend, lay(pitched(x, pitch), x_il8))                       # NaN in the padding columns
+    rin = dev16(backend, lay(pitched(res, pitch), r_il8)) if resid else None
+    yshape = (batch, cout // 8, h, pitch, 8) if y_il8 else (batch, cout, h, pitch)
+    y = empty16(backend, yshape)
+    plan.enqueue(xin, y, rin, batch)
+    out = host(backend, y)
+    out = from_il8(out) if y_il8 else out
+    assert np.abs(out[..., :w] - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.isnan(out[..., w:]).all(), "padding columns were written"
+    plan.destroy()
+
+
+def test_interleaved_layout_is_refused_where_it_does_not_exist(backend):
+    plan = backend.klib.conv2d_plan(rnd(32, 32, 3, 3), rnd(32), 32, 32, 9, 20, 3, 2, 1)       # stride 2
+    plan.set_pitch(64, 64)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    assert not plan.supports_il8()
+    with pytest.raises(capi.RtError):
+        plan.set_layouts(1, 1)
+    plan.destroy()

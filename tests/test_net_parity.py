@@ -136,6 +136,11 @@ def test_resnet18_2d_half2_mode(rt, monkeypatch):
     err_full = np.abs(full - ref).max()
     assert err_full <= 2e-4, err_full
     assert err_half > err_full                                 # i.e. the fp16 storage path really ran
+    monkeypatch.delenv("RT_NO_F16")
+    monkeypatch.setenv("RT_NO_IL8", "1")                       # planar fp16 tensors everywhere
+    planar, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    # the channel-interleaved tensors inside the towers change addressing only: same operands, same accumulation order
+    assert np.array_equal(planar, half)
 
 
 def test_plan_round_trip(rt):
