@@ -13,20 +13,22 @@
 // load per channel and PIXEL PAIR, transposed in registers to two 16-byte LDS writes.  Tile: 4 rows x 32 pixels x
 // 32 channels, 4 waves.
 //
-// Where the time goes (MI355X, 32->32 @185x629 + residual + ELU, batch 8: 45 us; HBM floor ~18, MFMA ~8):
-//  * tools/time_phases.py 8 f16 (s_memtime stamps): of a workgroup's 33 k cycles, 17 k pass before its first 31
-//    vector-memory instructions (16 residual, 4 bias, 8 gathers, 3 weights) are ISSUED and 8 k while the 11 of the
-//    second chunk are; data is there ~100 cycles after the issue completes.  With 32 waves per CU that is ~16 cycles
-//    of the CU's memory front end per wave-instruction -- the kernel is bound by the number of memory instructions
-//    x cache lines they touch, not by bytes: a planar fp16 row of a 32-pixel tile is 64 B, half a line.
+// Where the time goes (MI355X, 32->32 @185x629 + residual + ELU, batch 8; HBM floor ~18 us, MFMA ~8 us):
+//  * planar tensors, 45 us.  tools/time_phases.py 8 f16 (s_memtime stamps): of a workgroup's 33 k cycles, 17 k pass
+//    before its first 31 vector-memory instructions (16 residual, 4 bias, 8 gathers, 3 weights) are ISSUED and 8 k
+//    while the 11 of the second chunk are; data is there ~100 cycles after the issue completes.  With 32 waves per CU
+//    that is ~16 cycles of the CU's memory front end per wave-instruction: the kernel is bound by memory instructions
+//    x cache lines touched, not by bytes -- a planar fp16 row of a 32-pixel tile is 64 B, half a line.
 //  * tools/ablate_conv.py runocc16: 80 / 67 / 61 / 58 / 51 us at 4 .. 8 waves per SIMD -> registers are budgeted
 //    for 8 (RT_F16_WAVES); run16: 30 us remain with every global access compiled out, 50 without the MFMAs.
-//  * pixel-PAIR gathers (this form) halved the gather instructions: 51.5 -> 45.3 us.  Measured and rejected:
-//    (a) 8-byte pixel-quad gathers + pixel-pair stores through a DPP lane swap: 112 VGPRs -> 4 waves, -17 %, and
-//    the pair stores alone cost 13 % (same half-lines per plane, plus the swap); (b) a persistent grid with
+//  * pixel-PAIR gathers (the planar input path) halved the gather instructions: 51.5 -> 45.3 us.  Measured and
+//    rejected: (a) 8-byte pixel-quad gathers + pixel-pair stores through a DPP lane swap: 112 VGPRs -> 4 waves, -17 %,
+//    and the pair stores alone cost 13 % (same half-lines per plane, plus the swap); (b) a persistent grid with
 //    LDS-resident weights and next-chunk prefetch: 2x slower (4 waves, tiles of a workgroup serialise).
-//  What removes the bound is a channel-interleaved tensor layout (NC/8HW8: one 16-byte access per pixel and channel
-//  group, every line fully used: ~230 lines per tile instead of ~540) -- an executor-wide change, next round.
+//  * channel-interleaved tensors (XIL8 / YIL8 below; the executor's layout inside the towers): 22 instead of 58
+//    memory instructions per wave, whole lines: 45 -> 37 us (workgroup lifetime 33 k -> 22 k cycles), HBM roofline
+//    fraction 0.45 -> 0.55 by bench.py's events.  What is left is the prologue (8 k cycles until 13 instructions are
+//    issued) and the exposed latency of the first chunk.
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
@@ -37,16 +39,18 @@ namespace rt {
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-template <int KH, int KW, int S>
+// NW waves per workgroup = NW output rows per tile.  8 (weights staged once per 8 rows, 10 patch rows for 8 output
+// rows) was measured on the interleaved form: no difference (41.7 us per layer at batch 8 both ways); 4 is built.
+template <int KH, int KW, int S, int NW = 4>
 struct ConvF16Cfg {
-    static constexpr int TY = 4, TX = 32, CC = 16, TAPS = KH * KW;
+    static constexpr int TY = NW, TX = 32, CC = 16, TAPS = KH * KW, NT = 64 * NW, NP = NW / 2;
     static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW;
     static constexpr int PCA = (PC + 1 + 1) / 2 * 2;              // LDS columns: alignment offset (0 / 1) + patch, whole pairs
     static constexpr int NQ = PCA / 2, TG = PR * NQ;              // pixel pairs per row / per channel group
-    static constexpr int NKT = (TG + 127) / 128;                  // pairs per lane (two waves per channel group)
-    static constexpr int NPIX = PR * PC, NKP = ((NPIX + 1) / 2 + 63) / 64;   // interleaved input: patch pixels per lane
+    static constexpr int NKT = (TG + NP * 64 - 1) / (NP * 64);    // pairs per lane (NP waves per channel group)
+    static constexpr int NPIX = PR * PC, NKP = (NPIX + NP * 64 - 1) / (NP * 64);   // interleaved input: patch pixels per lane
     static constexpr int W_SLOTS = TAPS * 2 * 32;                 // 16-byte slots of the weight slab of one chunk
-    static constexpr int NK_W = (W_SLOTS + 255) / 256;
+    static constexpr int NK_W = (W_SLOTS + NT - 1) / NT;
 };
 
 // throughput follows occupancy here (tools/ablate_conv.py runocc16: 80 / 67 / 61 / 58 / 51 us at 4 .. 8 waves per SIMD)
@@ -59,9 +63,10 @@ struct ConvF16Cfg {
 // 8 bytes, and every cache line is used in full: ~230 lines per tile instead of ~540 half-used ones.  The offset of
 // channel group c/8 equals the planar offset of channel c, so gather table and channel strides are shared.
 // The residual's layout is a run-time flag (ConvArgs::r_il8): a block's skip connection may be either.
-template <int KH, int KW, int S, bool XIL8 = false, bool YIL8 = false>
-__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma_kernel(ConvArgs p) {
-    using Cfg = ConvF16Cfg<KH, KW, S>;
+template <int KH, int KW, int S, bool XIL8 = false, bool YIL8 = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma_kernel(ConvArgs p) {
+    using Cfg = ConvF16Cfg<KH, KW, S, NW>;
+    constexpr int NT = Cfg::NT;
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PCA = Cfg::PCA, NQ = Cfg::NQ;
     constexpr int NKT = Cfg::NKT, NK_W = Cfg::NK_W;
     constexpr int NV = XIL8 ? Cfg::NKP : NKT;     // gather positions per lane (pixels / pixel pairs)
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
     unsigned wvoff[NK_W];
 #pragma unroll
     for (int k = 0; k < NK_W; k++) {
-        const int idx = tid + 256 * k;
+        const int idx = tid + NT * k;
         wvoff[k] = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
     }
 
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f16mma
             }
 #pragma unroll
         for (int k = 0; k < NK_W; k++) {
-            const int idx = tid + 256 * k;
+            const int idx = tid + NT * k;
             if (idx < Cfg::W_SLOTS && (!kAblLdsWr || rw[k][0] == 12345.678f)) sW[idx] = rw[k];
         }
     };

@@ -30,6 +30,8 @@ r = torch.randn_like(x)
 if F16:
     plan.set_pitch(640, 640)
     plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    if len(sys.argv) > 3 and sys.argv[3] == "il8":      # channel-interleaved tensors (same bytes, other addressing)
+        plan.set_layouts(1, 1, 1)
 nwg = 47 * 20 * b          # 4 x 32 pixel tiles
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
