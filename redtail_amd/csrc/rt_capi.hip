@@ -18,6 +18,7 @@
 #include "kernels/deconv3d_small.hip.h"
 #include "kernels/imgproc.hip.h"
 #include "kernels/conv_f16.hip.h"
+#include "kernels/conv_f16_first.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -417,6 +418,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int x_f16 = 0, y_f16 = 0;           // storage type of input / output + residual (half2 mode), set by rt_conv_plan_set_io_types
     int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
+    int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
@@ -1189,6 +1191,32 @@ int repack_f16mma(rtConvPlan* plan) {
     return 0;
 }
 
+// First layer in half2 mode (conv_f16_first.hip.h): weights as the 5 A operands [block][r][h][co][8], k = 3*s + c.
+int repack_f16first(rtConvPlan* plan) {
+    SubConv& sc = plan->subs[0];
+    const rtConv2dDesc& d = plan->desc2d;
+    const std::vector<float>& w = plan->w_canon;
+    const int nblk = (int)rt::cdiv(d.Cout, 32);
+    std::vector<uint16_t> packed((size_t)nblk * rt::ConvF16FirstCfg::W_SLOTS * 8, 0);
+    for (int co = 0; co < d.Cout; co++)
+        for (int c = 0; c < d.Cin; c++)
+            for (int r = 0; r < 5; r++)
+                for (int sx = 0; sx < 5; sx++) {
+                    const int k = 3 * sx + c, h = k / 8, e = k % 8;
+                    const _Float16 hv = (_Float16)w[(((size_t)co * d.Cin + c) * 5 + r) * 5 + sx];
+                    uint16_t bits;
+                    std::memcpy(&bits, &hv, 2);
+                    packed[((((size_t)(co / 32) * 5 + r) * 2 + h) * 32 + co % 32) * 8 + e] = bits;
+                }
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
+    RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
+    sc.wino = 0; sc.f16first = 1;
+    return 0;
+}
+
 bool f16mma_window(const SubConv& sc) {
     return (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
 }
@@ -1218,6 +1246,16 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = sc.y_f16 = 1;
             continue;
         }
+        // the network's first layer (5x5 stride 2 on the 3-channel fp32 image): fp16 operands as well
+        if (!xf && yf && !sc.f16first && !plan->is_deconv && plan->subs.size() == 1 && sc.KH == 5 && sc.KW == 5 && sc.S == 2 &&
+            plan->cin <= 3 && !plan->has_resid && !sc.direct && !sc.zs_dev && env_int("RT_NO_F16MMA", 0) == 0) {
+            if (int rc = repack_f16first(plan)) return rc;
+        }
+        if (sc.f16first) {
+            if (xf || !yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: plan was switched to the fp16 first-layer kernel (fp32 in, fp16 out)");
+            sc.x_f16 = 0; sc.y_f16 = 1;
+            continue;
+        }
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1231,8 +1269,9 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
 extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (!plan || !plan->is2d || plan->is_deconv || plan->subs.size() != 1) return 0;
     const SubConv& sc = plan->subs[0];
-    return sc.f16mma && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && !sc.zs_dev && sc.y_xstride == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0 &&
-           env_int("RT_NO_IL8", 0) == 0;
+    if (env_int("RT_NO_IL8", 0) != 0) return 0;
+    if (sc.f16first) return sc.Cout % 8 == 0;          // output only (its input is the fp32 image)
+    return sc.f16mma && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && !sc.zs_dev && sc.y_xstride == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0;
 }
 // ... and the layout of each of its tensors (0 = planar NCHW with a row pitch, 1 = (C/8, H, pitch, 8))
 extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
@@ -1245,6 +1284,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: only 3x3 stride-1 plans in fp16 arithmetic with channel counts that are multiples of 8 take interleaved tensors");
     RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
     SubConv& sc = plan->subs[0];
+    RT_REQUIRE(!sc.f16first || (!x_il8 && !r_il8), "rt_conv_plan_set_layouts: the first-layer kernel reads the planar fp32 image");
     sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
     return 0;
 }
@@ -1334,6 +1374,13 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.f16first) {
+            if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_f16_first il8 y%d grid %u x %u x %u\n", sc.y_il8, grid.x, grid.y, grid.z);
+            if (sc.y_il8) hipLaunchKernelGGL((rt::conv_f16_first_kernel<true>), grid, dim3(256), 0, S(s), a, plan->cin);
+            else hipLaunchKernelGGL((rt::conv_f16_first_kernel<false>), grid, dim3(256), 0, S(s), a, plan->cin);
+            RT_LAUNCH_CHECK("conv_f16_first_kernel");
+            continue;
+        }
         if (sc.f16mma) {
             if (env_int("RT_CONV_TRACE", 0))
                 fprintf(stderr, "[rt] conv_f16mma %dx%d s%d rows %d il8 x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.TY, sc.x_il8,

@@ -150,3 +150,32 @@ def test_interleaved_layout_is_refused_where_it_does_not_exist(backend):
     with pytest.raises(capi.RtError):
         plan.set_layouts(1, 1)
     plan.destroy()
+
+
+@pytest.mark.parametrize("cin,cout,h,w,y_il8", [(3, 32, 11, 29, 0), (3, 32, 11, 29, 1), (3, 64, 21, 135, 1), (1, 40, 9, 66, 0), (2, 24, 8, 70, 1)])
+def test_first_layer_f16(backend, cin, cout, h, w, y_il8):
+    """5x5 stride-2 first layer in half2 mode: fp32 image in, fp16 operands (image and weights rounded to fp16), fp16
+    tensor out, planar or channel-interleaved (conv_f16_first.hip.h)"""
+    batch, act = 2, capi.RT_ACT_ELU
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x, b = rnd(batch, cin, h, w), rnd(cout)
+    wt = q16(rnd(cout, cin, 5, 5) * np.float32(1 / np.sqrt(cin * 25)))
+    ref = O.elu(O.conv2d(T(q16(x)), T(wt), T(b), 2, 2)).numpy()
+    ho, wo = ref.shape[-2:]
+    op = (wo + 63) // 64 * 64
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 5, 2, 2, act=act)
+    plan.set_pitch(0, op)
+    plan.set_io_types(capi.RT_F32, capi.RT_F16)
+    if y_il8:
+        assert plan.supports_il8()
+        plan.set_layouts(0, 1)
+        with pytest.raises(capi.RtError):
+            plan.set_layouts(1, 1)                                   # the image is planar fp32
+        plan.set_layouts(0, 1)
+    y = empty16(backend, (batch, cout // 8, ho, op, 8) if y_il8 else (batch, cout, ho, op))
+    plan.enqueue(backend.dev(x), y, None, batch)
+    out = host(backend, y)
+    out = from_il8(out) if y_il8 else out
+    assert np.abs(out[..., :wo] - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.isnan(out[..., wo:]).all(), "padding columns were written"
+    plan.destroy()

@@ -59,6 +59,8 @@ def main():
         if f16:
             plan.set_pitch(pitch, pitch)
             plan.set_io_types(capi.RT_F16, capi.RT_F16)
+            if os.environ.get("RT_ABL_IL8"):          # channel-interleaved tensors (same bytes, other addressing)
+                plan.set_layouts(1, 1, 1)
         e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
         k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
         for _ in range(3):
