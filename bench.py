@@ -53,12 +53,12 @@ def dominant(name):
     return "resblock" in name or name.endswith("encoder2D_out")
 
 
-def measured_traffic():
+def measured_traffic(half2=False):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/rNN_traffic.json,
     written by tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this
     command; counters cannot be read from inside the timed process).  None when no such file is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if ("half2" in os.path.basename(f)) == half2)
     if not files:
         return None, None
     t = json.load(open(files[-1]))
@@ -279,14 +279,15 @@ def main():
                     cnt += 1
         avg_s = tot / cnt * 1e-3
         achieved = DOMINANT_FLOPS * b / avg_s / 1e12
-        traffic, traffic_src = measured_traffic() if (b == 1 and not args.half2) else (None, None)
+        traffic, traffic_src = measured_traffic(args.half2) if b == 1 else (None, None)
         if args.half2:
             # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the same layer HBM-bound, so it is
             # priced in bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
             h2_bytes = 2.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9) + 4.0 * 32
             roofline = {"bound": "hbm", "kernel": "conv_f16mma_kernel<3,3,1> 3x3 32->32 @629x185 (+bias,+residual,+ELU), fp16 operands, fp32 accumulate",
                         "achieved": h2_bytes * b / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": h2_bytes * b / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": h2_bytes * b / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_unit": "bytes/launch, mean over launches with and without residual (PMC pass %s)" % traffic_src,
                         "algorithmic_bytes": h2_bytes * b, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
                         "flops_per_launch": DOMINANT_FLOPS * b}
         else:
