@@ -166,14 +166,17 @@ int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
  * mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262) keeps activations in fp16 between layers.
  * fp16 -> fp16 (3x3 stride 1/2, transposed 3x3 stride 2): the plan's weights are re-packed as fp16 and the stored
  * values become the operands of the fp16 matrix instructions, accumulation stays fp32 (RT_NO_F16MMA=1 in the
- * environment keeps fp32 arithmetic).  fp32 -> fp16 (first layers, direct-form kernels) and fp16 -> fp32 (last layer,
- * small-output transposed kernel) compute in fp32.  Other combinations return RT_E_UNSUPPORTED. */
+ * environment keeps fp32 arithmetic).  fp32 -> fp16: the network's first layer (5x5 stride 2, <= 3 input channels)
+ * rounds image and weights to fp16 and runs on the fp16 matrix instructions too, as TensorRT's half2 mode does; other
+ * fp32 -> fp16 layers (direct-form kernels) and fp16 -> fp32 (last layer, small-output transposed kernel) compute in
+ * fp32.  Other combinations return RT_E_UNSUPPORTED. */
 int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
 
 /* Channel-interleaved fp16 tensors, (C/8, H, pitch, 8) per sample: one 16-byte slot per pixel and group of 8 channels.
  * Not in the reference (TensorRT owns its internal layouts; its own fp16 formats are of this kind, PluginFormat
  * kNC2HW2 / kNHWC8 in NvInfer.h).  The fp16-arithmetic kernel moves such tensors in full cache lines; the executor
- * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic touch.  rt_conv_plan_supports_il8: 1 if
+ * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic (and, as output, the first layer)
+ * touch.  rt_conv_plan_supports_il8: 1 if
  * the plan can take them (after rt_conv_plan_set_io_types(F16, F16)); rt_conv_plan_set_layouts: layout (0 planar,
  * 1 interleaved) of the input, the output and the residual tensor. */
 int rt_conv_plan_supports_il8(const rtConvPlan* plan);
