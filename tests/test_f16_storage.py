@@ -179,3 +179,46 @@ def test_first_layer_f16(backend, cin, cout, h, w, y_il8):
     assert np.abs(out[..., :wo] - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
     assert np.isnan(out[..., wo:]).all(), "padding columns were written"
     plan.destroy()
+
+
+def _fuzz_cases(n=24, seed=20260924):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        cin, cout = int(rng.choice([8, 16, 24, 32, 40, 64])), int(rng.choice([8, 16, 32, 40, 64, 72]))
+        h, w = int(rng.integers(1, 14)), int(rng.integers(1, 80))
+        resid = bool(rng.integers(0, 2))
+        x_il8, y_il8 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        r_il8 = int(rng.integers(0, 2)) if resid else 0
+        act = int(rng.choice([capi.RT_ACT_NONE, capi.RT_ACT_ELU, capi.RT_ACT_SIGMOID]))
+        cases.append((cin, cout, h, w, resid, x_il8, y_il8, r_il8, act, int(rng.integers(1, 4))))
+    return cases
+
+
+@pytest.mark.parametrize("cin,cout,h,w,resid,x_il8,y_il8,r_il8,act,batch", _fuzz_cases())
+def test_conv2d_f16_fuzz(backend, cin, cout, h, w, resid, x_il8, y_il8, r_il8, act, batch):
+    """seeded random shapes / layouts / epilogues for the fp16-arithmetic 3x3 kernel (1-pixel images, single rows,
+    widths below one tile, channel counts that are not multiples of 32, every layout mix)"""
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x, b = q16(rnd(batch, cin, h, w)), rnd(cout)
+    wt = q16(rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)))
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1)
+    res = q16(rnd(*ref.shape)) if resid else None
+    if resid:
+        ref = ref + T(res)
+    ref = (O.elu(ref) if act == capi.RT_ACT_ELU else torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref).numpy()
+    pitch = (w + 63) // 64 * 64
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=resid)
+    plan.set_pitch(pitch, pitch)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    plan.set_layouts(x_il8, y_il8, r_il8)
+    lay = lambda a, il: to_il8(a) if il else a
+    xin = dev16(backend, lay(pitched(x, pitch), x_il8))
+    rin = dev16(backend, lay(pitched(res, pitch), r_il8)) if resid else None
+    y = empty16(backend, (batch, cout // 8, h, pitch, 8) if y_il8 else (batch, cout, h, pitch))
+    plan.enqueue(xin, y, rin, batch)
+    out = host(backend, y)
+    out = from_il8(out) if y_il8 else out
+    assert np.abs(out[..., :w] - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.isnan(out[..., w:]).all(), "padding columns were written"
+    plan.destroy()
