@@ -172,9 +172,11 @@ int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
  * fp32.  Other combinations return RT_E_UNSUPPORTED. */
 int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
 
-/* Channel-interleaved fp16 tensors, (C/8, H, pitch, 8) per sample: one 16-byte slot per pixel and group of 8 channels.
+/* Channel-interleaved tensors, (C/8, H, pitch, 8) per sample in fp16 and (C/4, H, pitch, 4) in fp32: one 16-byte slot
+ * per pixel and channel group.
  * Not in the reference (TensorRT owns its internal layouts; its own fp16 formats are of this kind, PluginFormat
- * kNC2HW2 / kNHWC8 in NvInfer.h).  The fp16-arithmetic kernel moves such tensors in full cache lines; the executor
+ * kNC2HW2 / kNHWC8 in NvInfer.h).  The 3x3 stride-1 kernels (fp32 Winograd, fp16 arithmetic) move such tensors in full
+ * cache lines with a quarter of the memory instructions; the executor
  * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic (and, as output, the first layer)
  * touch.  rt_conv_plan_supports_il8: 1 if
  * the plan can take them (after rt_conv_plan_set_io_types(F16, F16)); rt_conv_plan_set_layouts: layout (0 planar,

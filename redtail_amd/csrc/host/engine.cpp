@@ -774,13 +774,13 @@ void EngineImpl::assignPitch() {
         ok_ = false;
         return;
     }
-    if (!f16) return;
-    // Channel-interleaved storage (C/8, H, pitch, 8) for the fp16 tensors that only fp16-arithmetic 3x3 stride-1 plans
-    // read and write -- the inside of the two feature towers, 30 of the 47 internal tensors of ResNet-18 2D: the
-    // kernel then moves whole cache lines (conv_f16.hip.h).  A plan takes any mix of planar and interleaved tensors,
-    // so the layout is a per-tensor property and nothing is converted anywhere.
+    // Channel-interleaved storage -- (C/4, H, pitch, 4) in fp32, (C/8, H, pitch, 8) in fp16: one 16-byte slot per pixel
+    // and channel group -- for the tensors that only 3x3 stride-1 plans read and write (the inside of the two feature
+    // towers and of the bottleneck: 34 of the 49 launches of ResNet-18 2D write one).  Those kernels then move whole
+    // cache lines with a quarter of the memory instructions (conv_wino.hip.h, conv_f16.hip.h).  A plan takes any mix
+    // of planar and interleaved tensors, so the layout is a per-tensor property and nothing is converted anywhere.
     std::vector<char> il(tensors_.size(), 0);
-    for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 && t->dims.d[0] % 8 == 0;
+    for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 == f16 && t->dims.d[0] % (f16 ? 8 : 4) == 0;
     for (auto& op : ops_) {
         if (op.kind == OpKind::kConv && rt_conv_plan_supports_il8(op.plan)) continue;
         for (int i : op.in) il[root(i)] = 0;
@@ -800,7 +800,7 @@ void EngineImpl::assignPitch() {
     int n_il = 0;
     for (auto& t : tensors_) t->il8 = il[t->id] != 0;
     for (auto& op : ops_) n_il += il[root(op.out)] != 0;         // tensors that launches really write
-    log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n_il) + " of " + std::to_string(ops_.size()) + " launches write channel-interleaved tensors").c_str());
+    log_.log(ILogger::Severity::kINFO, (std::string(f16 ? "half2 mode: " : "fp32: ") + std::to_string(n_il) + " of " + std::to_string(ops_.size()) + " launches write channel-interleaved tensors").c_str());
 }
 
 void EngineImpl::assignStreams() {

@@ -66,6 +66,7 @@ __device__ static __forceinline__ f32x4 buf_load4(buf_rsrc r, unsigned voff, uns
 }
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // 8-byte forms: the address only has to be 4-byte aligned (odd image widths)
 __device__ static __forceinline__ f32x2_t buf_load2(buf_rsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));

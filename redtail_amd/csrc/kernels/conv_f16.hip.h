@@ -37,7 +37,6 @@
 namespace rt {
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // NW waves per workgroup = NW output rows per tile.  8 (weights staged once per 8 rows, 10 patch rows for 8 output
 // rows) was measured on the interleaved form: no difference (41.7 us per layer at batch 8 both ways); 4 is built.

@@ -55,9 +55,16 @@ struct WinoCfg {
 };
 
 // TIN / TOUT: storage type of the input and of the output + residual (float, or _Float16 in half2 mode)
-template <int NW, typename TIN = float, typename TOUT = float>
+// XIL / YIL (fp32 tensors, NW = 4): the input / output tensor is channel-interleaved, (C/4, H, pitch, 4) -- one 16-byte
+// slot per pixel and group of 4 channels, the fp32 form of the layout described in conv_f16.hip.h.  A lane's 4 output
+// channels of a pixel are one 16-byte store (4 instead of 8 stores and residual loads), a gather is one 16-byte load
+// per pixel and group (2 instead of 8 per lane and chunk).  The residual's layout is the run-time flag ConvArgs::r_il8
+// (RRT: compiled in; the all-planar instantiation leaves it out -- it sits at the 128-register limit).
+template <int NW, typename TIN = float, typename TOUT = float, bool XIL = false, bool YIL = false, bool RRT = (XIL || YIL)>
 __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(ConvArgs p) {
     using Cfg = WinoCfg<NW>;
+    static_assert(!(XIL || YIL) || (NW == 4 && std::is_same<TIN, float>::value && std::is_same<TOUT, float>::value),
+                  "interleaved tensors: fp32, 4-wave tile");
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     constexpr int CC = Cfg::CC, TY = Cfg::TY, TX = Cfg::TX, PC = Cfg::PC, PCP = Cfg::PCP, CHS = Cfg::CHS;
     constexpr int NPIX = Cfg::NPIX, CPW = Cfg::CPW, NKP = Cfg::NKP, NTHR = Cfg::NTHR, NK_W = Cfg::NK_W;
@@ -89,42 +96,64 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const int act = p.act;
 
     // ---- staging roles: wave w gathers channels w*CPW .. of each chunk (NW = 8: one channel per wave) ----------
-    const int* __restrict__ tab = p.ch_off + (int64_t)zi * p.CinPad + (wv % CC) * CPW;
-    unsigned voff[NKP];
-    int loff[NKP];
+    // interleaved input: wave w gathers channel group w & 1 (4 channels) for half w >> 1 of the patch pixels
+    constexpr int NKX = (NPIX + 127) / 128;
+    constexpr int NV = XIL ? NKX : NKP;
+    const int xg = wv & 1;
+    const int* __restrict__ tab = p.ch_off + (int64_t)zi * p.CinPad + (XIL ? 4 * xg : (wv % CC) * CPW);
+    unsigned voff[NV];
+    int loff[NV];
 #pragma unroll
-    for (int k = 0; k < NKP; k++) {
-        const int pidx = lane + 64 * k;
+    for (int k = 0; k < NV; k++) {
+        const int pidx = XIL ? (wv >> 1) * (NKX * 64) + lane + 64 * k : lane + 64 * k;
         const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 - p.pad_y + pr, ix = tx0 - p.pad_x + pc;
         const bool own = pidx < NPIX;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ESX : kBufOOB;
-        loff[k] = own ? ((wv % CC) * CPW) * CHS + pr * PCP + pc : -1;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : ESX) : kBufOOB;
+        loff[k] = own ? (XIL ? 4 * xg : (wv % CC) * CPW) * CHS + pr * PCP + pc : -1;
     }
     const float* __restrict__ wsrc = p.w + ((int64_t)nblk * nchunks) * Cfg::U_ELEMS;
     const buf_rsrc rs_w = make_buf(wsrc);
 
-    float rin[CPW][NKP];
+    float rin[XIL ? 1 : CPW][XIL ? 1 : NKP];
+    f32x4 rin4[XIL ? NKX : 1];
     f32x4 rw[NK_W];
     auto prefetch = [&](int ch) {
-#pragma unroll
-        for (int q = 0; q < CPW; q++) {
-            const int off = tab[ch * CC + q];             // wave-uniform scalar load
+        if constexpr (XIL) {
+            const int off = tab[ch * CC];                 // group offset == planar offset of its first channel
             const buf_rsrc rs = make_buf(xb, off >= 0);
-            const unsigned so = (unsigned)off * ESX;
 #pragma unroll
-            for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : Io<TIN>::load(rs, voff[k], so);
+            for (int k = 0; k < NKX; k++)
+                rin4[k] = kAblGather ? f32x4{(float)(off + (int)voff[k]), 0.f, 0.f, 0.f} : buf_load4(rs, voff[k], (unsigned)off * 4u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPW; q++) {
+                const int off = tab[ch * CC + q];         // wave-uniform scalar load
+                const buf_rsrc rs = make_buf(xb, off >= 0);
+                const unsigned so = (unsigned)off * ESX;
+#pragma unroll
+                for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : Io<TIN>::load(rs, voff[k], so);
+            }
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
 #pragma unroll
         for (int k = 0; k < NK_W; k++) rw[k] = kAblWLoad ? f32x4{(float)tid, 1.f, 2.f, (float)ch} : buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
     };
     auto stage_to_lds = [&]() {
+        if constexpr (XIL) {
 #pragma unroll
-        for (int q = 0; q < CPW; q++)
+            for (int k = 0; k < NKX; k++)
+                if (loff[k] >= 0) {
 #pragma unroll
-            for (int k = 0; k < NKP; k++)
-                if (loff[k] >= 0) sIn[loff[k] + q * CHS] = rin[q][k];
+                    for (int j = 0; j < 4; j++) sIn[loff[k] + j * CHS] = rin4[k][j];
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPW; q++)
+#pragma unroll
+                for (int k = 0; k < NKP; k++)
+                    if (loff[k] >= 0) sIn[loff[k] + q * CHS] = rin[q][k];
+        }
 #pragma unroll
         for (int k = 0; k < NK_W; k++) reinterpret_cast<f32x4*>(sU)[tid + NTHR * k] = rw[k];
     };
@@ -139,6 +168,12 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const bool edge_tile = tx0 + TX > Wo;                 // wave-uniform
     // (recomputed in the epilogue instead of being kept live across the main loop: 4 registers at the 128-VGPR limit)
     unsigned yv2[2], yv1[2];
+    const bool r_il = RRT && p.r_il8 != 0;                // uniform
+    // interleaved tensors: the 16-byte slot of pixel (a, b) of this lane's tile; the channel group goes into soffset
+    auto il_off = [&](int a, int b) {
+        const int oy = ty0 + 2 * tg + a, ox = tx0 + 2 * t + b;
+        return (oy < Ho && ox < Wo && cbase < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + (cb * 16 + 4 * k4) * cs32) * 4u : kBufOOB;
+    };
     auto out_offsets = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; a++) {
@@ -153,7 +188,17 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     // residual values are requested first (HBM latency overlaps the first gather) and consumed after prefetch(0)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
     float rr[4][2][2];
-    {
+    if (r_il) {
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, ybase, ESY), p.resid != nullptr);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const f32x4 v = kAblResid ? f32x4{0.f, 1.f, 2.f, 3.f} : buf_load4(rs_r, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
+#pragma unroll
+                for (int i = 0; i < 4; i++) rr[i][a][b] = v[i];
+            }
+    } else {
         const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, ybase, ESY), p.resid != nullptr);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -244,6 +289,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     asm volatile("" ::: "memory");     // keep the recomputation below the loop
     out_offsets();
     auto epilogue = [&](auto ACT) {
+        float yo[YIL ? 4 : 1][2][2];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float t0[4], t1[4];
@@ -257,14 +303,31 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             y[0][1] = t0[1] - t0[2] - t0[3];
             y[1][0] = t1[0] + t1[1] + t1[2];
             y[1][1] = t1[1] - t1[2] - t1[3];
-            const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;
-            const bool dead = tail4 && cbase + i >= p.Cout;
+            if constexpr (YIL) {
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const f32x2 o = {apply_act_fast(y[a][0], decltype(ACT)::value), apply_act_fast(y[a][1], decltype(ACT)::value)};
-                if (!kAblStore || o[0] == 12345.678f) Io<TOUT>::store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
-                if (edge_tile) Io<TOUT>::store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) yo[i][a][b] = apply_act_fast(y[a][b], decltype(ACT)::value);
+            } else {
+                const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;
+                const bool dead = tail4 && cbase + i >= p.Cout;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const f32x2 o = {apply_act_fast(y[a][0], decltype(ACT)::value), apply_act_fast(y[a][1], decltype(ACT)::value)};
+                    if (!kAblStore || o[0] == 12345.678f) Io<TOUT>::store2(o, rs_y, dead ? kBufOOB : yv2[a], so);
+                    if (edge_tile) Io<TOUT>::store(o[0], rs_y, dead ? kBufOOB : yv1[a], so);
+                }
             }
+        }
+        if constexpr (YIL) {                              // the lane's 4 channels of each of its 4 pixels: 16 bytes
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const f32x4 o = {yo[0][a][b], yo[1][a][b], yo[2][a][b], yo[3][a][b]};
+                    if (!kAblStore || o[0] == 12345.678f)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u, 0);
+                }
         }
     };
     if (act == 1) epilogue(std::integral_constant<int, 1>{});

@@ -1271,6 +1271,8 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0) return 0;
     if (sc.f16first) return sc.Cout % 8 == 0;          // output only (its input is the fp32 image)
+    // fp32 tensors: groups of 4 channels, the Winograd kernel with the 4-wave tile
+    if (sc.wino && !sc.x_f16 && !sc.y_f16) return sc.TY == 4 && sc.y_xstride == 1 && !sc.zs_dev && plan->cin % 4 == 0 && sc.Cout % 4 == 0;
     return sc.f16mma && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && !sc.zs_dev && sc.y_xstride == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0;
 }
 // ... and the layout of each of its tensors (0 = planar NCHW with a row pitch, 1 = (C/8, H, pitch, 8))
@@ -1281,7 +1283,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         return 0;
     }
     if (!rt_conv_plan_supports_il8(plan))
-        return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: only 3x3 stride-1 plans in fp16 arithmetic with channel counts that are multiples of 8 take interleaved tensors");
+        return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: only 3x3 stride-1 plans (fp32 Winograd: channel counts multiples of 4; fp16 arithmetic: multiples of 8) take interleaved tensors");
     RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
     SubConv& sc = plan->subs[0];
     RT_REQUIRE(!sc.f16first || (!x_il8 && !r_il8), "rt_conv_plan_set_layouts: the first-layer kernel reads the planar fp32 image");
@@ -1411,7 +1413,13 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             if (sc.x_f16 || sc.y_f16) {
                 RT_REQUIRE(sc.x_f16 && sc.y_f16, "rt_conv_enqueue: the Winograd kernel takes fp16 on both sides or on neither");
                 hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
-            } else if (sc.NW == 8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
+            } else if (sc.NW == 8) {
+                RT_REQUIRE(!(sc.x_il8 || sc.y_il8 || sc.r_il8), "rt_conv_enqueue: interleaved tensors need the 4-wave Winograd tile");
+                hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
+            } else if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, true>), grid, dim3(256), 0, S(s), a);
+            else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, false>), grid, dim3(256), 0, S(s), a);
+            else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, true>), grid, dim3(256), 0, S(s), a);
+            else if (sc.r_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, false, true>), grid, dim3(256), 0, S(s), a);
             else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("conv_wino_f32_kernel");
             continue;

@@ -140,6 +140,12 @@ static inline void buffer_store_b64(u32x2 v, const buffer_rsrc& r, unsigned voff
         if (buffer_ok(r, voff + 4 * i, soff, 4)) std::memcpy(r.base + (size_t)voff + 4 * i + soff, &w, 4);
     }
 }
+static inline void buffer_store_b128(u32x4 v, const buffer_rsrc& r, unsigned voff, unsigned soff) {
+    for (int i = 0; i < 4; i++) {
+        unsigned w = v[i];
+        if (buffer_ok(r, voff + 4 * i, soff, 4)) std::memcpy(r.base + (size_t)voff + 4 * i + soff, &w, 4);
+    }
+}
 static inline unsigned short buffer_load_b16(const buffer_rsrc& r, unsigned voff, unsigned soff) {
     unsigned short v = 0;
     if (buffer_ok(r, voff, soff, 2)) std::memcpy(&v, r.base + (size_t)voff + soff, 2);
@@ -161,6 +167,7 @@ static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned v
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, aux) hipemu::buffer_load_b16(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b16(d, r, v, s, aux) hipemu::buffer_store_b16(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b64(d, r, v, s, aux) hipemu::buffer_store_b64(d, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hipemu::buffer_store_b128(d, r, v, s)
 #define RT_WAVES_PER_EU(n)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -269,3 +269,15 @@ def test_nvtiny_full_size():
     err = (out.cpu() - ref).abs().max().item()
     assert err <= 1e-3, err
     net.destroy()
+
+
+def test_resnet18_2d_interleaved_equals_planar(rt, monkeypatch):
+    """the executor stores tensors between 3x3 stride-1 layers channel-interleaved (C/4, H, pitch, 4): addressing
+    only -- the disparity must not change by a bit against planar tensors (RT_NO_IL8)"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 25, 41)
+    il, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    monkeypatch.setenv("RT_NO_IL8", "1")
+    planar, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    assert n1 == n2
+    assert np.array_equal(il, planar)

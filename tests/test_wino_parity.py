@@ -80,3 +80,64 @@ def test_wino_conv3d(backend, monkeypatch, out_dchw):
         plan.destroy()
     near(outs[0], ref, 2e-5)
     near(outs[1], ref, 2e-5)
+
+
+def to_il(a, g):
+    """(N, C, H, P) planar -> (N, C/g, H, P, g) channel-interleaved"""
+    n, c, h, p = a.shape
+    return np.ascontiguousarray(a.reshape(n, c // g, g, h, p).transpose(0, 1, 3, 4, 2))
+
+
+def from_il(a):
+    n, q, h, p, g = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(n, q * g, h, p)
+
+
+IL_CASES = [
+    # cin, cout, h, w, act, resid, batch, pitch
+    (32, 32, 9, 33, capi.RT_ACT_ELU, True, 1, 64),
+    (32, 32, 5, 63, capi.RT_ACT_ELU, True, 2, 64),        # odd width
+    (8, 32, 3, 5, capi.RT_ACT_NONE, False, 1, 32),        # image smaller than one tile
+    (36, 28, 7, 64, capi.RT_ACT_ELU, True, 1, 64),        # channel counts that are multiples of 4 only; padded chunks
+    (64, 64, 10, 37, capi.RT_ACT_SIGMOID, True, 1, 0),    # dense rows
+    (128, 40, 4, 18, capi.RT_ACT_ELU, False, 2, 32),
+]
+
+
+@pytest.mark.parametrize("x_il,y_il,r_il", [(1, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1), (1, 0, 0)])
+@pytest.mark.parametrize("cin,cout,h,w,act,resid,batch,pitch", IL_CASES)
+def test_wino_interleaved(backend, cin, cout, h, w, act, resid, batch, pitch, x_il, y_il, r_il):
+    """fp32 Winograd kernel on channel-interleaved (C/4, H, pitch, 4) tensors, every mix with planar ones; results
+    must equal the planar form bit for bit (same operands, same order of operations)"""
+    if r_il and not resid:
+        pytest.skip("no residual")
+    from test_pitch_parity import pitched
+    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
+    res = rnd(batch, cout, h, w) if resid else None
+    P = pitch or w
+    outs = []
+    for il in (False, True):
+        xi, yi, ri = (x_il, y_il, r_il) if il else (0, 0, 0)
+        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=resid)
+        if pitch:
+            plan.set_pitch(pitch, pitch)
+        if il:
+            assert plan.supports_il8()
+            plan.set_layouts(xi, yi, ri)
+        lay = lambda a, f: to_il(a, 4) if f else a
+        xin = backend.dev(lay(pitched(x, P), xi))                 # NaN in the padding columns
+        rin = backend.dev(lay(pitched(res, P), ri)) if resid else None
+        y = backend.empty((batch, cout // 4, h, P, 4) if yi else (batch, cout, h, P))
+        plan.enqueue(xin, y, rin, batch)
+        out = backend.host(y).copy()
+        out = from_il(out) if yi else out
+        if P > w:
+            assert np.isnan(out[..., w:]).all(), "padding columns were written"
+        outs.append(out[..., :w])
+        plan.destroy()
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1)
+    if resid:
+        ref = ref + T(res)
+    ref = O.elu(ref) if act == capi.RT_ACT_ELU else (torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref)
+    near(outs[1], ref.numpy(), 2e-5)
+    assert np.array_equal(outs[0], outs[1])
