@@ -15,7 +15,7 @@ share nothing but the weights: rank 0 builds the weight-file image and broadcast
 processes its own K pairs).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = conv_wino_f32_kernel<4> (the 34 residual-block 3x3 32->32 convolutions at
+  roofline      dominant kernel = conv_wino_f32_kernel<4,...> (the 34 residual-block 3x3 32->32 convolutions at
                 629x185 = 79 % of the network's FLOPs; the same kernel also runs conv2D_1/2/4/5/7/8):
                 ALGORITHMIC FLOPs per launch (direct form, 2*Cin*Cout*9*H*W) / average launch
                 duration measured with HIP events on the launch stream (IProfiler path of the executor) right
@@ -291,7 +291,7 @@ def main():
                         "algorithmic_bytes": h2_bytes * b, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
                         "flops_per_launch": DOMINANT_FLOPS * b}
         else:
-            roofline = {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3)",
+            roofline = {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4,float,float,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3), channel-interleaved tensors",
                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,

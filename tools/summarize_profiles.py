@@ -17,7 +17,12 @@ import os
 import shutil
 import sys
 
-DOMINANT = "conv_wino_f32_kernel<4>"
+DOMINANT = "conv_wino_f32_kernel<4, float, float, ...>"      # every tensor-layout variant of the fp32 4-wave kernel
+
+
+def is_dom(name):
+    return name.startswith("conv_wino_f32_kernel<4, float, float") or name == "conv_wino_f32_kernel<4>"
+
 DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (the kernel also runs the low-resolution layers)
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
 # with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
@@ -46,8 +51,8 @@ def main():
         if d.startswith("pmc_") and os.path.exists(f):
             for r in csv.DictReader(open(f)):
                 name = short(r["Kernel_Name"])
-                if name == DOMINANT and int(r["Grid_Size"]) != DOMINANT_GRID:
-                    name += " (other layers)"
+                if is_dom(name):
+                    name = DOMINANT + ("" if int(r["Grid_Size"]) == DOMINANT_GRID else " (other layers)")
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for k in acc.values() for c in k})
     with open(os.path.join(out, tag + "_pmc.csv"), "w", newline="") as f:
@@ -64,7 +69,7 @@ def main():
     # ---- durations of the dominant kernel from the trace ----------------------------------------------
     rows = list(csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows
-            if short(r["Kernel_Name"]) == DOMINANT and int(r["Grid_Size_X"]) == DOMINANT_GRID]
+            if is_dom(short(r["Kernel_Name"])) and int(r["Grid_Size_X"]) == DOMINANT_GRID]
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
     t1 = max(int(r["End_Timestamp"]) for r in rows)
     traffic = dict(kernel=DOMINANT, launches_counted=len(dom["FETCH_SIZE"]),
