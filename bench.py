@@ -25,6 +25,8 @@ Extra objects on the JSON line:
                 With --half2 (TensorRT half2 mode, BASELINE config C3) the same layers run conv_f16mma_kernel with
                 fp16 operands; at 2.5 PFLOP/s they are HBM-bound, so the object is priced in algorithmic bytes
                 against 8 TB/s.
+                `frac` uses the in-situ duration (event pairs inside the running network, other streams busy);
+                `isolated_launch_us` / `frac_isolated` are the same layer launched back-to-back on an idle GPU.
   cpu_baseline  the oracle (torch CPU restatement of the reference graph, oracle/stereo_oracle.py) timed
                 on this host's cores on a bounded sample of the same workload.
 """
@@ -94,6 +96,39 @@ def cpu_baseline(weights, budget_s=12.0):
                 break
     return dict(value=n / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
+
+
+def isolated_dominant(k, b, half2, launches=50):
+    """The dominant layer (3x3 32->32 @629x185 + bias + residual + ELU, the executor's tensor layouts) launched
+    back-to-back on one idle stream: microseconds per launch between two HIP events.  Reported next to the in-situ
+    figure (`avg_launch_us`: event pairs inside the running network, other streams' kernels in flight)."""
+    import ctypes
+    rng = np.random.default_rng(1)
+    wt = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288)).astype(np.float32)
+    plan = k.conv2d_plan(wt, rng.standard_normal(32).astype(np.float32), 32, 32, HALF_H, HALF_W, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+    plan.set_pitch(640, 640)
+    if half2:
+        plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    if plan.supports_il8():
+        plan.set_layouts(1, 1, 1)
+    dt = torch.float16 if half2 else torch.float32
+    x = torch.randn(b, 32, HALF_H, 640, device="cuda").to(dt)
+    r, y = torch.randn_like(x), torch.empty_like(x)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
+    for _ in range(5):
+        plan.enqueue(x, y, r, b)
+    torch.cuda.synchronize()
+    k.lib.rt_event_record(e0, None)
+    for _ in range(launches):
+        plan.enqueue(x, y, r, b)
+    k.lib.rt_event_record(e1, None)
+    torch.cuda.synchronize()
+    ms = ctypes.c_float()
+    k.lib.rt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+    k.lib.rt_event_destroy(e0); k.lib.rt_event_destroy(e1)
+    plan.destroy()
+    return ms.value * 1e3 / launches
 
 
 def main():
@@ -298,6 +333,10 @@ def main():
                         "algorithmic_bytes": DOMINANT_BYTES * b,
                         "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
                         "flops_per_launch": DOMINANT_FLOPS * b, "mfma_flops_executed": DOMINANT_FLOPS * b * 16.0 / 36.0}
+        iso_us = isolated_dominant(lib.kernels, b, args.half2)
+        roofline["isolated_launch_us"] = iso_us
+        roofline["frac_isolated"] = (roofline["algorithmic_bytes"] / iso_us / 1e3 / HBM_PEAK_GBS if args.half2
+                                     else DOMINANT_FLOPS * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS)
         out = {
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
