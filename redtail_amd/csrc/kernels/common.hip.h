@@ -78,6 +78,11 @@ __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned v
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
 
+// LDS destination of a direct global -> LDS load (buffer_load ... lds): wave-uniform base, lane l lands at + size*l
+#ifndef RT_LDS_PTR
+#define RT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+
 // ---- storage-type generic element access ---------------------------------------------------------------------
 // Activations are stored as fp32 or (TensorRT "half2 mode": setHalf2Mode + fp16 weights, sample_app/main.cpp:256-262)
 // as fp16; arithmetic is fp32 either way (what the reference's fp16 correlation kernel does too,

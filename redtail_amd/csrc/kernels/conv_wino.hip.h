@@ -35,6 +35,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RT_WINO_MINW
 #define RT_WINO_MINW 4
 #endif
+#ifndef RT_WINO_LDS_DMA
+// 1: transformed weights go global -> LDS without passing through registers (buffer_load_dwordx4 ... lds, double-
+// buffered slabs, 40 KB of LDS per workgroup).  Measured on the 32->32 layer with interleaved tensors: 145 vs 132 us at
+// batch 8, 21.1 vs 19.9 us at batch 1 -- slower (the freed registers are re-used by the scheduler up to the 128 limit,
+// with 1-8 spills), so the register-staged form is built.
+#define RT_WINO_LDS_DMA 0
+#endif
 template <int NW>
 struct WinoCfg {
     static constexpr int CC = 8;                          // input channels per chunk (2 MFMA k-steps of 4)
@@ -70,7 +77,12 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     constexpr int NPIX = Cfg::NPIX, CPW = Cfg::CPW, NKP = Cfg::NKP, NTHR = Cfg::NTHR, NK_W = Cfg::NK_W;
 
     __shared__ __attribute__((aligned(16))) float sIn[CC * CHS];
-    __shared__ __attribute__((aligned(16))) float sU[Cfg::U_ELEMS];
+    // Transformed weights: with WDMA the 16 KB slab of a chunk goes from global memory straight into LDS
+    // (buffer_load_dwordx4 ... lds: lane l of a wave writes 16 bytes at M0 base + 16*l, i.e. a straight copy of the
+    // packed slab), double-buffered so that the slab of chunk ch+1 lands while chunk ch is being multiplied.  No
+    // VGPRs hold weights in flight (16 fewer) and no ds_write instructions stage them.
+    constexpr bool WDMA = RT_WINO_LDS_DMA != 0 && NW == 4;
+    __shared__ __attribute__((aligned(16))) float sU[(WDMA ? 2 : 1) * Cfg::U_ELEMS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -117,7 +129,16 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 
     float rin[XIL ? 1 : CPW][XIL ? 1 : NKP];
     f32x4 rin4[XIL ? NKX : 1];
-    f32x4 rw[NK_W];
+    f32x4 rw[WDMA ? 1 : NK_W];
+    auto weights_to_lds = [&](int ch) {                   // WDMA: slab of chunk ch -> buffer ch & 1
+        const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            float* dst = sU + (ch & 1) * Cfg::U_ELEMS + (wv * 64 + NTHR * k) * 4;      // wave-uniform base, lane l lands at + 16*l bytes
+            if (!kAblWLoad)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, RT_LDS_PTR(dst), 16, (unsigned)(tid + NTHR * k) * 16u, so, 0, 0);
+        }
+    };
     auto prefetch = [&](int ch) {
         if constexpr (XIL) {
             const int off = tab[ch * CC];                 // group offset == planar offset of its first channel
@@ -135,9 +156,13 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
                 for (int k = 0; k < NKP; k++) rin[q][k] = kAblGather ? (float)(off + (int)voff[k]) : Io<TIN>::load(rs, voff[k], so);
             }
         }
-        const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
+        if constexpr (WDMA) {
+            weights_to_lds(ch);
+        } else {
+            const unsigned so = (unsigned)ch * (unsigned)(Cfg::U_ELEMS * 4);
 #pragma unroll
-        for (int k = 0; k < NK_W; k++) rw[k] = kAblWLoad ? f32x4{(float)tid, 1.f, 2.f, (float)ch} : buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
+            for (int k = 0; k < NK_W; k++) rw[k] = kAblWLoad ? f32x4{(float)tid, 1.f, 2.f, (float)ch} : buf_load4(rs_w, (unsigned)(tid + NTHR * k) * 16u, so);
+        }
     };
     auto stage_to_lds = [&]() {
         if constexpr (XIL) {
@@ -154,8 +179,12 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
                 for (int k = 0; k < NKP; k++)
                     if (loff[k] >= 0) sIn[loff[k] + q * CHS] = rin[q][k];
         }
+        if constexpr (WDMA) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's part of the slab is in LDS
+        } else {
 #pragma unroll
-        for (int k = 0; k < NK_W; k++) reinterpret_cast<f32x4*>(sU)[tid + NTHR * k] = rw[k];
+            for (int k = 0; k < NK_W; k++) reinterpret_cast<f32x4*>(sU)[tid + NTHR * k] = rw[k];
+        }
     };
 
     // ---- output addressing + accumulator init (bias, residual) -------------------------------------------------
@@ -226,7 +255,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     // ---- one chunk: 2 k-steps x (input transform of this lane's tile + 16 MFMAs) --------------------------------
     const float* dbase = sIn + k4 * CHS + (2 * tg) * PCP + 2 * t;
     const f32x4* ubase = reinterpret_cast<const f32x4*>(sU) + (k4 * 4) * 32 + cb * 16 + t;
-    auto compute = [&]() {
+    auto compute = [&](int ub) {                          // ub: weight buffer of this chunk, in 16-byte slots
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float* dp = dbase + (4 * j) * CHS;
@@ -238,7 +267,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             }
             f32x4 a4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a4[q] = ubase[(j * 16 + q) * 32];
+            for (int q = 0; q < 4; q++) a4[q] = ubase[ub + (j * 16 + q) * 32];
             // rows: w = B^T d  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), two columns at a time
             f32x2 w[4][2];
 #pragma unroll
@@ -281,7 +310,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         stage_to_lds();
         __syncthreads();
         if (ch + 1 < nchunks) prefetch(ch + 1);
-        compute();
+        compute(WDMA ? (ch & 1) * (Cfg::U_ELEMS / 4) : 0);
     }
 
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------

@@ -169,6 +169,18 @@ static inline void buffer_store_b32(unsigned v, const buffer_rsrc& r, unsigned v
 #define __builtin_amdgcn_raw_buffer_store_b64(d, r, v, s, aux) hipemu::buffer_store_b64(d, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, aux) hipemu::buffer_store_b128(d, r, v, s)
 #define RT_WAVES_PER_EU(n)
+#define RT_LDS_PTR(p) ((void*)(p))
+// buffer_load ... lds: lane l of the wave writes `size` bytes at lds + size*l (range check per dword, like the loads)
+static inline void hipemu_buffer_load_lds(const hipemu::buffer_rsrc& r, void* lds, unsigned size, unsigned voff, unsigned soff) {
+    char* dst = static_cast<char*>(lds) + (size_t)hipemu::lane_id() * size;
+    for (unsigned i = 0; i < size; i += 4) {
+        unsigned w = 0;
+        if (hipemu::buffer_ok(r, voff + i, soff, 4)) std::memcpy(&w, r.base + (size_t)voff + i + soff, 4);
+        std::memcpy(dst + i, &w, 4);
+    }
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, size, voff, soff, off, aux) hipemu_buffer_load_lds(r, lds, size, (voff) + (off), soff)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

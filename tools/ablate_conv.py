@@ -32,6 +32,8 @@ def main():
     global VARIANTS
     if f16:
         VARIANTS = VARIANTS16
+    if os.environ.get("RT_ABL_AB") and not f16:          # fp32 A/B of two builds: `RT_ABL_AB=1 python tools/ablate_conv.py run [batch]`
+        VARIANTS = [(20000, "reference revision"), (10008, "working tree")]
     if sys.argv[1].startswith("build"):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(4) as ex:
@@ -44,7 +46,7 @@ def main():
     h, w = 185, 629
     wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
     bias = np.random.randn(cout).astype(np.float32)
-    pitch = 640 if f16 else w
+    pitch = 640 if (f16 or os.environ.get("RT_ABL_IL8")) else w
     x = torch.randn(b, cin, h, pitch, device="cuda", dtype=torch.float16 if f16 else torch.float32)
     y = torch.empty_like(x)
     r = torch.randn_like(x)
@@ -56,6 +58,9 @@ def main():
             fn = getattr(k.lib, sym)
             fn.restype, fn.argtypes = res, args
         plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+        if not f16 and os.environ.get("RT_ABL_IL8"):      # fp32 Winograd on channel-interleaved tensors
+            plan.set_pitch(pitch, pitch)
+            plan.set_layouts(1, 1, 1)
         if f16:
             plan.set_pitch(pitch, pitch)
             plan.set_io_types(capi.RT_F16, capi.RT_F16)
