@@ -204,6 +204,34 @@ def test_resnet18_2d_full_size(w, h, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("half2", [False, True])
+def test_resnet18_2d_full_size_layouts(monkeypatch, half2):
+    """BASELINE size 1257x369, batch 2: half2 mode against the oracle with the same fp16-rounded weights (reference
+    fp16 tolerance 1e-2, tests_main.cpp:320,1025), and -- fp32 and half2 -- channel-interleaved tensors against planar
+    ones (RT_NO_IL8): addressing only, so bit for bit."""
+    lib = netlib("gpu")
+    w, h, batch = 1257, 369, 2
+    weights = O.synth_weights_resnet18_2d()
+    l, r = pairs(batch, h, w)
+    outs = []
+    for no_il in ("0", "1"):
+        monkeypatch.setenv("RT_NO_IL8", no_il)
+        net = lib.create("resnet18_2D", w, h, max_batch=batch, weights=weights, fp16_weights=half2)
+        out = torch.full((batch, 1, h, w), float("nan"), device="cuda")
+        net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out, batch)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+        net.destroy()
+    assert torch.equal(outs[0], outs[1])
+    if half2:
+        wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in weights.items()}
+        with torch.no_grad():
+            ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), wq)
+        err = (outs[0] - ref).abs().max().item()
+        assert err <= 1e-2, err
+
+
+@pytest.mark.gpu
 def test_resnet18_2d_interleaved_contexts():
     """Four engines on four streams, pairs issued round-robin with no synchronisation in between (what bench.py
     times): every context must reproduce the oracle for ITS pair, i.e. no buffers are shared between contexts."""
