@@ -141,3 +141,46 @@ def test_wino_interleaved(backend, cin, cout, h, w, act, resid, batch, pitch, x_
     ref = O.elu(ref) if act == capi.RT_ACT_ELU else (torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref)
     near(outs[1], ref.numpy(), 2e-5)
     assert np.array_equal(outs[0], outs[1])
+
+
+def _il_fuzz_cases(n=20, seed=424242):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        cin, cout = int(rng.choice([4, 8, 12, 32, 36, 64, 100])), int(rng.choice([24, 28, 32, 40, 64, 96]))
+        h, w = int(rng.integers(1, 13)), int(rng.integers(1, 75))
+        resid = bool(rng.integers(0, 2))
+        cases.append((cin, cout, h, w, resid, int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)) if resid else 0,
+                      int(rng.choice([capi.RT_ACT_NONE, capi.RT_ACT_ELU, capi.RT_ACT_SIGMOID])), int(rng.integers(1, 4)),
+                      int(rng.choice([0, 32]))))
+    return cases
+
+
+@pytest.mark.parametrize("cin,cout,h,w,resid,x_il,y_il,r_il,act,batch,align", _il_fuzz_cases())
+def test_wino_interleaved_fuzz(backend, cin, cout, h, w, resid, x_il, y_il, r_il, act, batch, align):
+    """seeded random shapes (single pixels and rows, widths below a tile, channel counts that are multiples of 4 only),
+    layout mixes, epilogues and row pitches for the fp32 Winograd kernel on channel-interleaved tensors"""
+    from test_pitch_parity import pitched
+    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
+    res = rnd(batch, cout, h, w) if resid else None
+    pitch = (w + align - 1) // align * align if align else 0
+    P = pitch or w
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=resid)
+    if pitch:
+        plan.set_pitch(pitch, pitch)
+    plan.set_layouts(x_il, y_il, r_il)
+    lay = lambda a, f: to_il(a, 4) if f else a
+    xin = backend.dev(lay(pitched(x, P), x_il))
+    rin = backend.dev(lay(pitched(res, P), r_il)) if resid else None
+    y = backend.empty((batch, cout // 4, h, P, 4) if y_il else (batch, cout, h, P))
+    plan.enqueue(xin, y, rin, batch)
+    out = backend.host(y).copy()
+    out = from_il(out) if y_il else out
+    plan.destroy()
+    ref = O.conv2d(T(x), T(wt), T(b), 1, 1)
+    if resid:
+        ref = ref + T(res)
+    ref = O.elu(ref) if act == capi.RT_ACT_ELU else (torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref)
+    near(out[..., :w], ref.numpy(), 2e-5)
+    if P > w:
+        assert np.isnan(out[..., w:]).all(), "padding columns were written"
