@@ -178,9 +178,9 @@ int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
  * kNC2HW2 / kNHWC8 in NvInfer.h).  The 3x3 stride-1 kernels (fp32 Winograd, fp16 arithmetic) move such tensors in full
  * cache lines with a quarter of the memory instructions; the executor
  * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic (and, as output, the first layer)
- * touch.  rt_conv_plan_supports_il8: 1 if
- * the plan can take them (after rt_conv_plan_set_io_types(F16, F16)); rt_conv_plan_set_layouts: layout (0 planar,
- * 1 interleaved) of the input, the output and the residual tensor. */
+ * touch.  rt_conv_plan_supports_il8: which tensors of the plan may be interleaved (bit 0 input, bit 1 output, bit 2
+ * residual; call it after rt_conv_plan_set_io_types); rt_conv_plan_set_layouts: layout (0 planar, 1 interleaved) of
+ * the input, the output and the residual tensor. */
 int rt_conv_plan_supports_il8(const rtConvPlan* plan);
 int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8);
 

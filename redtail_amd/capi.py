@@ -215,6 +215,10 @@ class ConvPlan:
     def supports_il8(self):
         return bool(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
 
+    def il_caps(self):
+        """which tensors may be channel-interleaved: bit 0 input, bit 1 output, bit 2 residual"""
+        return int(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
+
     def set_layouts(self, x_il8, y_il8, r_il8=False):
         """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
         self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")

@@ -782,14 +782,15 @@ void EngineImpl::assignPitch() {
     std::vector<char> il(tensors_.size(), 0);
     for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 == f16 && t->dims.d[0] % (f16 ? 8 : 4) == 0;
     for (auto& op : ops_) {
-        if (op.kind == OpKind::kConv && rt_conv_plan_supports_il8(op.plan)) continue;
-        for (int i : op.in) il[root(i)] = 0;
-        il[root(op.out)] = 0;
-        if (op.resid >= 0) il[root(op.resid)] = 0;
+        const int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual
+        if (!(caps & 1)) for (int i : op.in) il[root(i)] = 0;
+        if (!(caps & 2)) il[root(op.out)] = 0;
+        if (op.resid >= 0 && !(caps & 4)) il[root(op.resid)] = 0;
     }
     for (auto& op : ops_) {
         if (op.kind != OpKind::kConv) continue;
         const int xi = il[root(op.in[0])], yi = il[root(op.out)], ri = op.resid >= 0 ? il[root(op.resid)] : 0;
+        if (getenv("RT_IL_TRACE")) fprintf(stderr, "[rt] %-28s x%d y%d r%d caps %d\n", op.name.c_str(), xi, yi, ri, rt_conv_plan_supports_il8(op.plan));
         if (!(xi || yi || ri)) continue;
         if (rt_conv_plan_set_layouts(op.plan, xi, yi, ri) != 0) {
             log_.log(ILogger::Severity::kERROR, rt_last_error_string());

@@ -136,9 +136,12 @@ struct ConvCfg {
 };
 
 // TIN / TOUT: storage type of the input and of the output + residual (float, or _Float16 in half2 mode)
-template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS, typename TIN = float, typename TOUT = float>
+// YIL (fp32 output, no residual): the output tensor is channel-interleaved (C/4, H, pitch, 4), see conv_wino.hip.h --
+// accumulator rows 4q .. 4q+3 of a lane are 4 consecutive channels of its pixel: one 16-byte store instead of four.
+template <int KH, int KW, int S, int TY, int TXW, int NBW, int CC, int NW, bool WLDS, typename TIN = float, typename TOUT = float, bool YIL = false>
 __global__ void __launch_bounds__(64 * NW, (ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>::MINW))
 conv_mfma_f32_kernel(ConvArgs p) {
+    static_assert(!YIL || std::is_same<TOUT, float>::value, "interleaved output: fp32");
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     using Cfg = ConvCfg<KH, KW, S, TY, TXW, NBW, CC, NW, WLDS>;
     constexpr int TX = Cfg::TX, NB = Cfg::NB, PC = Cfg::PC, WT = Cfg::WT, CPG = Cfg::CPG;
@@ -219,7 +222,9 @@ conv_mfma_f32_kernel(ConvArgs p) {
         const int t = wv + NW * i;
         const int oy = ty0 + t / TXW;
         const int ox = tx0 + (t % TXW) * 32 + l31;
-        yvoff[i] = (oy < Ho && ox < Wo) ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ESY : kBufOOB;
+        yvoff[i] = !(oy < Ho && ox < Wo) ? kBufOOB
+                   : YIL ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * half * cs32) * ESY
+                         : (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ESY;
     }
     // residual (skip connection) values of this lane's outputs: requested first thing, so their (HBM) latency
     // overlaps the first gather, and added to the accumulators before the first MFMA -- no registers are held
@@ -409,6 +414,26 @@ conv_mfma_f32_kernel(ConvArgs p) {
     // (bias and residual went in with the accumulator init; one scalar branch per activation / tail case keeps the
     //  16-element loops free of selects)
     auto epilogue = [&](auto ACT, auto TAIL) {
+        if constexpr (YIL) {
+#pragma unroll
+            for (int b = 0; b < NBW; b++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cs = nblk * NB + b * 32 + 8 * q;
+                    const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ESY), cs < p.Cout);
+                    const unsigned so = (unsigned)(cs * cs32) * ESY;
+#pragma unroll
+                    for (int i = 0; i < WT; i++) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = apply_act_fast(acc[i][b][4 * q + e], decltype(ACT)::value);
+                        const unsigned vo = (cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];      // Cout is a multiple of 4
+                        if (!kAblStore || o[0] == 12345.678f)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs, vo, so, 0);
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < NBW; b++)
 #pragma unroll
