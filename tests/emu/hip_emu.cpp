@@ -313,7 +313,11 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shm
 
 // ---- runtime API -------------------------------------------------------------------------
 hipError_t hipMalloc(void** p, size_t n) {
-    *p = aligned_alloc(256, (n + 255) & ~(size_t)255);
+    const size_t bytes = (n + 255) & ~(size_t)255;
+    *p = aligned_alloc(256, bytes ? bytes : 256);
+    // hipMalloc does not zero device memory: poison it (0xFF = NaN as fp32 / fp16, -1 as int) so that a kernel reading
+    // something nobody wrote shows up in the CPU tier as it would -- randomly -- on the GPU
+    if (*p) memset(*p, 0xFF, bytes ? bytes : 256);
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
