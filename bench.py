@@ -41,7 +41,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from redtail_amd import capi, parallel, synth  # noqa: E402
+from redtail_amd import capi, model_files, parallel, synth  # noqa: E402
 
 W, H = 1257, 369
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
@@ -49,6 +49,18 @@ HBM_PEAK_GBS = 8000.0                 # same table: HBM3E, 8 TB/s
 HALF_W, HALF_H = 629, 185
 DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
 DOMINANT_BYTES = 4.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9 + 32)     # x, residual, y, weights, bias
+NET_FLOPS = 91.87e9                    # whole network per pair at 1257x369, direct form
+
+
+def load_weights(half2):
+    """The reference's trained weight file (weights/_ref/, staged by __graft_entry__.build()) as (dict, description).
+    A missing file is not an error for a throughput benchmark, but the JSON line says which weights were timed."""
+    try:
+        path = model_files.weight_file("resnet18_2D", half2)
+        return capi.read_weights(path, half2), "reference ResNet-18_2D/TensorRT/%s" % os.path.basename(path)
+    except FileNotFoundError as e:
+        print("bench.py: %s -- timing seeded synthetic weights instead" % e, file=sys.stderr)
+        return synth.synth_weights_resnet18_2d(seed=7), "seeded He-normal (synthetic; reference weight file not staged)"
 
 
 def dominant(name):
@@ -147,9 +159,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU through
+    # torch.distributed.run on 127.0.0.1, exactly the command the driver uses -- instead of silently timing one GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        if torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, torch.cuda.device_count()))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
@@ -161,12 +188,18 @@ def main():
     torch.cuda.set_device(dev)
 
     # ---- weights: rank 0 owns the file image, everyone else receives it over RCCL/xGMI ------------------
+    weights, weights_desc = None, None
     if rank == 0:
-        weights = synth.synth_weights_resnet18_2d(seed=7)
+        weights, weights_desc = load_weights(args.half2)
         blob = capi.pack_weights(weights, fp16=args.half2)
     if distributed:
         import torch.distributed as dist
         blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
+    import zlib
+    blob_crc = zlib.crc32(blob) & 0xffffffff
+    if distributed:
+        print("bench.py: rank %d/%d (RCCL world size %d) on cuda:%d, weight image %d bytes crc32 %08x" % (
+            rank, world, torch.distributed.get_world_size(), local_rank, len(blob), blob_crc), file=sys.stderr, flush=True)
 
     lib = capi.NetLib()
     lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
@@ -201,9 +234,13 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    rank_rows = [{"rank": rank, "pairs_per_s": args.steps * b / elapsed, "weights_crc32": "%08x" % blob_crc}]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, rank_rows[0])
+        rank_rows = gathered
         elapsed = float(t.item())
     barrier()
     # the reference's own loop for comparison (sample_app/main.cpp:303-309): one context, one pair in flight
@@ -303,6 +340,19 @@ def main():
     for d in disps:
         assert torch.isfinite(d).all(), "non-finite disparity"
         assert torch.equal(d, disps[0]), "contexts disagree"
+    # ---- what was timed is also checked: every context's disparity against the oracle on the same pair(s) -------
+    # (outside the timed region; BASELINE budget 1e-3 abs on the raw `disp` output, 1e-2 = the reference's fp16
+    # tolerance in half2 mode where the fp16 activations themselves are the difference)
+    parity = None
+    if rank == 0:
+        from oracle import stereo_oracle as O
+        torch.set_num_threads(host_cores())
+        with torch.no_grad():
+            ref = O.resnet18_2d(left.cpu(), right.cpu(), {k: (np.asarray(v).astype(np.float16).astype(np.float32) if args.half2 else v)
+                                                          for k, v in weights.items()})
+        parity = max(float((d.cpu() - ref).abs().max()) for d in disps)
+        budget = 1e-2 if args.half2 else 1e-3
+        assert parity <= budget, "disparity differs from the oracle by %.3g (budget %.0e)" % (parity, budget)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream ------
@@ -346,7 +396,11 @@ def main():
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,
-                       "weights": "seeded He-normal (synthetic)", "parallelism": "pairs sharded over %d GPU(s)" % world},
+                       "weights": weights_desc, "parallelism": "pairs sharded over %d GPU(s)" % world},
+            "parity_max_abs_err": parity,
+            "parity_note": "max |disp - oracle| over the %d timed context(s), same pair(s), %s; budget %s" % (
+                nctx, "oracle on the fp16-rounded weights" if args.half2 else "fp32 oracle", "1e-2" if args.half2 else "1e-3"),
+            "ranks": rank_rows,
             "roofline": roofline,
         }
         if single is not None:
@@ -354,7 +408,7 @@ def main():
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(synth.synth_weights_resnet18_2d(seed=7))
+            out["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(out), flush=True)
     for n in nets:
         n.destroy()

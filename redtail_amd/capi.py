@@ -274,6 +274,23 @@ def pack_weights(weights, fp16=False):
     return bytes(out)
 
 
+def read_weights(path, fp16=False):
+    """trt_weights.bin / trt_weights_fp16.bin -> dict name -> float32 array (inverse of pack_weights; the reader of
+    sample_app/main.cpp:111-134: name, NUL, uint32 count, count elements)."""
+    import struct
+
+    import numpy as np
+    raw = open(path, "rb").read()
+    off, out = 0, {}
+    dt = np.dtype("<f2") if fp16 else np.dtype("<f4")
+    while off < len(raw):
+        end = raw.index(b"\0", off)
+        (cnt,) = struct.unpack_from("<I", raw, end + 1)
+        out[raw[off:end].decode()] = np.frombuffer(raw, dtype=dt, count=cnt, offset=end + 5).astype(np.float32)
+        off = end + 5 + cnt * dt.itemsize
+    return out
+
+
 class NetLib:
     """libnvstereo_inference.so: the NvInfer.h shim + plugins + executor, through the C ABI."""
 

@@ -529,8 +529,15 @@ bool EngineImpl::lower() {
                     LayerData* nx = soleConsumer(cur->id);
                     if (nx && nx->type == LayerType::kELEMENTWISE && nx->ew == ElementWiseOperation::kSUM) {
                         TensorImpl* other = nx->in[0] == cur ? nx->in[1] : nx->in[0];
-                        // the residual must already exist when the conv runs
-                        if (other != cur && (other->producer == nullptr || index_of(other->producer) < (int)li || done[index_of(other->producer)])) {
+                        auto same_dims = [](const Dims& a, const Dims& b) {
+                            if (a.nbDims != b.nbDims) return false;
+                            for (int i = 0; i < a.nbDims; i++)
+                                if (a.d[i] != b.d[i]) return false;
+                            return true;
+                        };
+                        // the residual must already exist when the conv runs, and is read with the output's strides
+                        if (other != cur && same_dims(other->dims, cur->dims) &&
+                            (other->producer == nullptr || index_of(other->producer) < (int)li || done[index_of(other->producer)])) {
                             resid = other->id;
                             done[index_of(nx)] = true;
                             cur = nx->out[0];
@@ -684,6 +691,7 @@ bool EngineImpl::lower() {
                 op.kind = OpKind::kPlugin;
                 op.plugin = l->plugin;
                 if (l->out.size() != 1) return fail(l->name + ": multi-output plugins are not supported");
+                if (l->in.size() > 8) return fail(l->name + ": plugins with more than 8 inputs are not supported");
                 ops_.push_back(op);
                 continue;
             }

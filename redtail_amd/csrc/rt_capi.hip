@@ -619,8 +619,13 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
 std::vector<float> to_f32(const void* w, size_t n, int dtype) {
     std::vector<float> out(n);
     if (dtype == RT_F16) {
-        const _Float16* h = static_cast<const _Float16*>(w);
-        for (size_t i = 0; i < n; i++) out[i] = (float)h[i];
+        // the blob of a weight file is not 2-byte aligned in general (name\0, count, data): no typed loads from it
+        const char* h = static_cast<const char*>(w);
+        for (size_t i = 0; i < n; i++) {
+            _Float16 v;
+            std::memcpy(&v, h + 2 * i, 2);
+            out[i] = (float)v;
+        }
     } else {
         std::memcpy(out.data(), w, n * sizeof(float));
     }
@@ -1227,6 +1232,50 @@ int repack_f16first(rtConvPlan* plan) {
     return 0;
 }
 
+// Back to the fp32 kernels after repack_f16mma / repack_f16first: the weights the plan was created with are packed
+// again in the fp32 slab order, tiling and gather table are rebuilt (an executor that tried half2 mode and has to fall
+// back to fp32 activations calls rt_conv_plan_set_io_types(F32, F32) on plans it already switched).
+int repack_f32(rtConvPlan* plan) {
+    SubConv& sc = plan->subs[0];
+    const rtConv2dDesc& d = plan->desc2d;
+    const std::vector<float>& w = plan->w_canon;
+    const int Cin = d.Cin, Cout = d.Cout;
+    sc.f16mma = sc.f16first = 0;
+    sc.x_f16 = sc.y_f16 = 0;
+    sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
+    choose_tiling(sc, !plan->is_deconv);
+    check_direct(sc, Cin);
+    sc.CinPad = sc.direct ? Cin : rt::round_up(Cin, sc.CC);
+    std::vector<float> packed;
+    if (!plan->is_deconv) {
+        pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; });
+    } else {
+        const int s = d.stride;
+        size_t iz = 0;
+        for (int py = 0; py < s; py++)
+            for (int px = 0; px < s; px++) {
+                if (py >= plan->out_dims[1] || px >= plan->out_dims[2]) continue;
+                const Phase1D ay = phase1d(s, d.pad_h, d.KH, py), ax = phase1d(s, d.pad_w, d.KW, px);
+                const int64_t off = pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) {
+                    if (u >= ay.K || v >= ax.K) return 0.f;
+                    return w[(((size_t)ci * Cout + co) * d.KH + ay.tap[u]) * d.KW + ax.tap[v]];
+                });
+                if (!sc.zs_host.empty()) sc.zs_host[iz++].w_off = off;
+            }
+        if (!sc.zs_host.empty())
+            RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
+    }
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    if (int rc = upload_weights(sc, packed)) return rc;
+    if (sc.choff_dev) (void)hipFree(sc.choff_dev);
+    sc.choff_dev = nullptr;
+    const int ip = sc.x_pitch ? sc.x_pitch : plan->win;
+    std::vector<int> table(sc.CinPad, -1);
+    for (int c = 0; c < Cin; c++) table[c] = c * plan->hin * ip;
+    return upload_table(sc, table);
+}
+
 bool f16mma_window(const SubConv& sc) {
     return (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
 }
@@ -1242,7 +1291,12 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
     const int op = plan->out_pitch ? plan->out_pitch : plan->out_dims[2];
     RT_REQUIRE(!yf || (op & 1) == 0, "rt_conv_plan_set_io_types: fp16 output rows need an even pitch (got %d)", op);
     for (SubConv& sc : plan->subs) {
-        if (!xf && !yf) { sc.x_f16 = sc.y_f16 = 0; continue; }
+        if (!xf && !yf) {
+            // a plan that was switched to fp16 operands holds fp16 weight slabs and the fp16 tiling: restore the fp32 form
+            if ((sc.f16mma || sc.f16first) && plan->subs.size() == 1) { if (int rc = repack_f32(plan)) return rc; }
+            sc.x_f16 = sc.y_f16 = 0;
+            continue;
+        }
         if (sc.direct) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the direct (Cout <= 2) kernel is fp32 only");
         // both tensors fp16: fp16 operands on the matrix cores (the stored values are the operands, fp32 accumulate)
         // (its gathers move 4-byte pixel pairs: row pitch, plane and sample strides must be even)

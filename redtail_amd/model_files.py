@@ -1,0 +1,54 @@
+"""Where the reference's trained weight files live inside this repository.
+
+The reference ships `stereoDNN/models/<Model>/TensorRT/trt_weights{,_fp16}.bin` (written by
+scripts/tensorrt_model_builder.py:52-60, read by sample_app/main.cpp:111-134).  `/root/reference` does not exist
+on the GPU box, so `stage_reference_weights()` (called from `__graft_entry__.build()`) copies the files into
+`weights/_ref/` -- git-ignored like every other built artefact, but shipped with the gpurun snapshot -- and tests /
+bench.py look them up through `weight_file()`, which raises when a file is missing: there is no silent fall-back to
+synthetic weights anywhere a test or a benchmark says "real weights".
+"""
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHT_DIR = os.path.join(ROOT, "weights", "_ref")
+
+# (model id of include/rt_stereo_net.h, fp16 file?) -> path below stereoDNN/models
+FILES = {
+    ("resnet18_2D", False): "ResNet-18_2D/TensorRT/trt_weights.bin",
+    ("resnet18_2D", True): "ResNet-18_2D/TensorRT/trt_weights_fp16.bin",
+    ("nvtiny", False): "NVTiny/TensorRT/trt_weights.bin",
+    ("nvtiny", True): "NVTiny/TensorRT/trt_weights_fp16.bin",
+    ("nvsmall", True): "NVSmall/TensorRT/trt_weights_fp16.bin",     # the reference ships no fp32 file
+}
+
+
+def stage_reference_weights(reference=None):
+    """Copies the weight files from the reference tree into weights/_ref/.  Returns the list of staged paths;
+    a no-op (empty list) when the reference tree is absent (GPU box)."""
+    reference = reference or os.environ.get("RT_REFERENCE", "/root/reference")
+    src_root = os.path.join(reference, "stereoDNN", "models")
+    staged = []
+    if not os.path.isdir(src_root):
+        return staged
+    for rel in sorted(set(FILES.values())):
+        src, dst = os.path.join(src_root, rel), os.path.join(WEIGHT_DIR, rel)
+        if not os.path.exists(src):
+            continue
+        if not os.path.exists(dst) or os.path.getsize(dst) != os.path.getsize(src):
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            shutil.copyfile(src, dst)
+        staged.append(dst)
+    return staged
+
+
+def weight_file(model, fp16=False):
+    """Path of the staged reference weight file; FileNotFoundError (never a fall-back) when it is not there."""
+    key = (model, bool(fp16))
+    if key not in FILES:
+        raise FileNotFoundError("the reference ships no %s weight file for %s" % ("fp16" if fp16 else "fp32", model))
+    path = os.path.join(WEIGHT_DIR, FILES[key])
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s is missing: run `python __graft_entry__.py` where /root/reference exists "
+                                "(it stages the reference's weight files; they travel with the gpurun snapshot)" % path)
+    return path

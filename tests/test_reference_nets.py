@@ -31,11 +31,14 @@ def load_ref():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,name,w,h", [(0, "resnet18_2D", 513, 257), (2, "nvtiny", 513, 161)])
+@pytest.mark.parametrize("model,name,w,h", [(0, "resnet18_2D", 513, 257), (2, "nvtiny", 513, 161), (1, "nvsmall", 1025, 321),
+                                            (3, "resnet18", 1025, 321)])
 def test_reference_generated_graph_matches_ours(model, name, w, h):
+    """all four generated builders of the reference (ref_nets_glue.cpp:60-63) at the sizes they were generated for"""
     netlib = capi.NetLib()                   # loads our libraries first (RTLD_GLOBAL)
     ref = load_ref()
-    weights = synth.synth_weights_resnet18_2d() if model == 0 else synth.synth_weights_3d(synth.NVTINY_3D)
+    weights = (synth.synth_weights_resnet18_2d() if model == 0 else
+               synth.synth_weights_3d({1: synth.NVSMALL_3D, 2: synth.NVTINY_3D, 3: synth.RESNET18_3D}[model]))
     blob = capi.pack_weights(weights)
     l, r = synth.synth_pair(h, w)
     L, R = torch.from_numpy(l)[None].cuda(), torch.from_numpy(r)[None].cuda()
