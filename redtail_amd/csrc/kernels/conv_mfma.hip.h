@@ -74,6 +74,10 @@ struct ConvArgs {
     int64_t r_cstride;     // residual: channel stride and per-sample stride (== y_cstride / y_bstride unless the
     int64_t r_bstride;     // launch writes a transposed layout, e.g. Conv3DTranspose + Transform in one pass)
     int r_il8;             // conv_f16mma_kernel: the residual tensor is channel-interleaved (see conv_f16.hip.h)
+    // persistent kernels (conv_split.hip.h): the grid is not the tile count
+    int batch;             // samples of this launch
+    int cin_real;          // input channels that exist (CinPad - zero padding)
+    int64_t x_cstride;     // input channel stride (2-D plans: Hi * x_pitch)
 };
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with

@@ -1,0 +1,241 @@
+// fp32 convolutions on the fp16 matrix pipe of gfx950: 3-term split ("fp16x3"), fp32 tensors in and out.
+//
+// Why.  v_mfma_f32_32x32x2_f32 / 16x16x4_f32 run at the fp32 VECTOR rate (157 TFLOP/s, and every other VALU
+// instruction of the wave is paid in the same issue slots); v_mfma_f32_32x32x16_f16 runs 16x faster (2.5 PFLOP/s).
+// An fp32 value is the exact sum of two fp16 values to 22 bits:
+//     x = xh + xl * 2^-11,   xh = fp16(x),   xl = fp16((x - xh) * 2^11)         (same for a weight w = wh + wl * 2^-11)
+// so      x * w = xh*wh + (xh*wl + xl*wh) * 2^-11 + O(2^-22 |x w|)
+// and each of the three products of fp16 operands is EXACT in the fp32 accumulator of the matrix core (11 x 11
+// bits).  Three MFMAs at the fp16 rate replace one at the fp32 rate (5.3x the fp32 matrix peak), the error of a
+// whole convolution against an fp64 evaluation is the one of an fp32 fmaf chain (measured on the reference's trained
+// ResNet-18 2D: 1.1e-7 on the disparity against 2.8e-7 for the torch fp32 oracle; tests/test_split_parity.py), and the
+// layer turns from MFMA/VALU-issue-bound into HBM-bound.  The cross terms go to their own accumulator (they are 2^11
+// smaller than the main term), which is scaled and added once, in the epilogue.  The low parts are pre-scaled by 2^11
+// so that they are normal fp16 numbers whenever the value itself is (|x| >= 6.1e-5): nothing depends on fp16
+// subnormals.  Domain: |x| < 65504 (activations of the Stereo DNN graphs are O(1..100)); larger inputs give inf/NaN
+// -- loudly -- and RT_CONV_EXACT_FP32=1 keeps the plans on the fp32 kernels (conv_wino.hip.h, conv_mfma.hip.h).
+//
+// conv_s3p_kernel: PERSISTENT kernel for the layer that dominates ResNet-18 2D (reference
+// resnet18_2D_513x257_net.cpp:48-719: 3x3, stride 1, Cin <= 32, Cout <= 32; 36 of the 49 launches, 83 % of the FLOPs).
+//   * grid = one workgroup (8 waves, two per SIMD) per CU; a workgroup walks a contiguous range of 8-row x 32-pixel tiles.
+//   * the split weights of the whole layer (9 taps x 32 ci x 32 co x {hi, lo} fp16 = 36 KB) are loaded into LDS once.
+//   * tile i+1 is gathered from global memory into registers while tile i is multiplied out of LDS (double-buffered
+//     patch image, ONE barrier per tile), its residual tile is requested before the MFMAs and consumed after them.
+//   * the patch image holds the split input: per pixel 32 x fp16 hi | 32 x fp16 lo | 16 B pad = 144 B, a pixel stride
+//     of 36 banks, so every ds_read_b128 lane group of a B-operand fetch touches all 64 banks exactly once.
+//   * per tap and 16-channel chunk: 2 B fetches + 2 A fetches (16 B per lane each) feed 3 MFMAs.
+// Tensors: channel-interleaved (C/4, H, pitch, 4) or planar, per tensor (conv_wino.hip.h describes the layout).
+#pragma once
+#include <type_traits>
+#include "common.hip.h"
+#include "conv_mfma.hip.h"
+
+namespace rt {
+
+constexpr float kSplitScale = 2048.f;            // 2^11: low parts are stored scaled
+constexpr float kSplitInv = 1.f / 2048.f;
+
+struct S3Split {
+    f16x4 hi, lo;
+};
+// 4 fp32 values (4 channels of a pixel) -> 4 fp16 high parts + 4 scaled fp16 low parts
+__device__ static __forceinline__ S3Split s3_split(f32x4 v) {
+    S3Split s;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const _Float16 h = (_Float16)v[j];
+        s.hi[j] = h;
+        s.lo[j] = (_Float16)((v[j] - (float)h) * kSplitScale);
+    }
+    return s;
+}
+
+template <int NW>
+struct S3PCfg {
+    static constexpr int TY = NW, TX = 32;                 // one output row of 32 pixels per wave
+    static constexpr int PR = TY + 2, PC = TX + 2, NPIX = PR * PC;
+    static constexpr int PXB = 144;                        // bytes per patch pixel in LDS (64 hi + 64 lo + 16 pad)
+    static constexpr int NT = 64 * NW;
+    static constexpr int NSLOT = NPIX * 8;                 // (pixel, group of 4 channels) gather slots per tile
+    static constexpr int NKX = (NSLOT + NT - 1) / NT;      // ... per thread
+    static constexpr int W_SLOTS = 9 * 2 * 2 * 2 * 32;     // 16-byte slots: [tap][chunk][hi/lo][k-group][co]
+    static constexpr int NK_W = (W_SLOTS + NT - 1) / NT;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+};
+
+// XIL / YIL: input / output tensor channel-interleaved (C/4, H, pitch, 4); the residual's layout is p.r_il8.
+template <int NW, bool XIL, bool YIL>
+__global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kernel(ConvArgs p) {
+    using Cfg = S3PCfg<NW>;
+    constexpr int TY = Cfg::TY, TX = Cfg::TX, PC = Cfg::PC, NPIX = Cfg::NPIX, PXB = Cfg::PXB, NT = Cfg::NT;
+    constexpr int NKX = Cfg::NKX, NK_W = Cfg::NK_W;
+
+    __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
+    __shared__ __attribute__((aligned(16))) char sX[2][NPIX * PXB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- this workgroup's tiles: a contiguous range, contiguous per XCD (workgroup b runs on XCD b % 8) ----------------
+    const int G = gridDim.x;
+    int v = blockIdx.x;
+    if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int tiles_y = (p.Ho + TY - 1) / TY;
+    const int per_img = p.tiles_x * tiles_y;
+    const int T = per_img * p.batch;
+    const int t_begin = (int)((int64_t)v * T / G), t_end = (int)((int64_t)(v + 1) * T / G);
+    if (t_begin >= t_end) return;
+
+    // ---- weights: the whole layer, once ---------------------------------------------------------------------------------
+    {
+        const buf_rsrc rs_w = make_buf(p.w);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            if (idx < Cfg::W_SLOTS) sW[idx] = buf_load4(rs_w, (unsigned)idx * 16u, 0u);
+        }
+    }
+
+    // ---- gather slots of this thread: (patch pixel, group of 4 channels), fixed for the whole kernel -------------------
+    int s_pr[NKX], s_pc[NKX], s_lds[NKX], s_g[NKX];
+    unsigned s_goff[NKX];                    // byte offset of the group's first channel plane, kBufOOB = channels do not exist
+    const unsigned cs_x = (unsigned)p.x_cstride;
+#pragma unroll
+    for (int k = 0; k < NKX; k++) {
+        const int idx = tid + NT * k;
+        const int g = idx / NPIX, pix = idx - g * NPIX;
+        const int pr = pix / PC;
+        s_pr[k] = pr;
+        s_pc[k] = pix - pr * PC;
+        s_g[k] = g;
+        const bool own = idx < Cfg::NSLOT && 4 * g < p.cin_real;
+        s_goff[k] = own ? (unsigned)(4 * g) * cs_x * 4u : kBufOOB;
+        s_lds[k] = idx < Cfg::NSLOT ? pix * PXB + g * 8 : -1;
+    }
+
+    f32x4 rin[NKX];
+    auto gather = [&](int tile) {
+        const int n = tile / per_img, rem = tile - n * per_img;
+        const int ty0 = (rem / p.tiles_x) * TY, tx0 = (rem % p.tiles_x) * TX;
+        const buf_rsrc rs = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
+#pragma unroll
+        for (int k = 0; k < NKX; k++) {
+            const int iy = ty0 - p.pad_y + s_pr[k], ix = tx0 - p.pad_x + s_pc[k];
+            const bool in = s_goff[k] != kBufOOB && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            if constexpr (XIL) {
+                rin[k] = buf_load4(rs, in ? s_goff[k] + (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB, 0u);
+            } else {
+                const unsigned vo = in ? s_goff[k] + (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // channels beyond cin_real inside the last group: the plan's zero-padded weights multiply whatever is
+                    // read, so they must read zeros -> out of range
+                    const bool cj = in && 4 * s_g[k] + j < p.cin_real;
+                    rin[k][j] = buf_load(rs, cj ? vo + (unsigned)j * cs_x * 4u : kBufOOB, 0u);
+                }
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        char* base = sX[buf];
+#pragma unroll
+        for (int k = 0; k < NKX; k++) {
+            if (s_lds[k] < 0) continue;
+            const S3Split s = s3_split(rin[k]);
+            *reinterpret_cast<f16x4*>(base + s_lds[k]) = s.hi;
+            *reinterpret_cast<f16x4*>(base + s_lds[k] + 64) = s.lo;
+        }
+    };
+
+    // ---- per-lane constants of the contraction and of the epilogue ------------------------------------------------------
+    const int b_off = (wv * PC + l31) * PXB + kg * 16;       // B operand: pixel (row wv + r, col l31 + s), k-group kg
+    const int a_off = kg * 32 + l31;                         // A operand: output channel l31, k-group kg (16-byte slots)
+    f32x4 bias4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bias4[q] = *reinterpret_cast<const f32x4*>(p.bias + 8 * q + 4 * kg);
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
+    const bool r_il = p.r_il8 != 0, has_r = p.resid != nullptr;
+    const int act = p.act;
+
+    gather(t_begin);
+    for (int tile = t_begin; tile < t_end; tile++) {
+        const int buf = (tile - t_begin) & 1;
+        stage(buf);
+        __syncthreads();       // tile staged; every wave is done with the other buffer (it finished the previous tile)
+        if (tile + 1 < t_end) gather(tile + 1);
+
+        const int n = tile / per_img, rem = tile - n * per_img;
+        const int oy = (rem / p.tiles_x) * TY + wv, ox = (rem % p.tiles_x) * TX + l31;
+        const bool inb = oy < p.Ho && ox < p.Wo;
+        // residual tile: requested now, consumed after the MFMAs
+        f32x4 rr[4];
+        if (has_r) {
+            const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.r_bstride + p.y_off, 4));
+            if (r_il) {
+                const unsigned vo = inb ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+                for (int q = 0; q < 4; q++) rr[q] = buf_load4(rs_r, (8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)(8 * q * rs32) * 4u);
+            } else {
+                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        rr[q][e] = buf_load(rs_r, (8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((8 * q + e) * rs32) * 4u);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        // ---- 9 taps x 2 chunks x 3 MFMAs -----------------------------------------------------------------------------------
+        f32x16 acc_m, acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+        const char* xb = sX[buf] + b_off;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, s = t % 3;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const char* bp = xb + (r * PC + s) * PXB + c * 32;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 64);
+                const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 0) * 64]);
+                const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 1) * 64]);
+                acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: y = main + cross * 2^-11 + bias + residual, activation, stores --------------------------------------
+        // accumulator register 4q + e of a lane = channel 8q + 4kg + e of pixel l31
+        const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
+        auto epilogue = [&](auto ACT) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bias4[q][e] + rr[q][e]), decltype(ACT)::value);
+                if constexpr (YIL) {
+                    const unsigned vo = (inb && 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)(8 * q * cs32) * 4u, 0);
+                } else {
+                    const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        buf_store(o[e], rs_y, (8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((8 * q + e) * cs32) * 4u);
+                }
+            }
+        };
+        if (act == 1) epilogue(std::integral_constant<int, 1>{});
+        else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+        else epilogue(std::integral_constant<int, 0>{});
+    }
+}
+
+}  // namespace rt

@@ -19,6 +19,7 @@
 #include "kernels/imgproc.hip.h"
 #include "kernels/conv_f16.hip.h"
 #include "kernels/conv_f16_first.hip.h"
+#include "kernels/conv_split.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
@@ -419,6 +420,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
     int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
+    int s3p = 0;                        // conv_s3p_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe, persistent (3x3 s1, Cin, Cout <= 32)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
 };
@@ -615,6 +617,53 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
 }
 
+// ---- 3-term fp16 split (conv_split.hip.h) ---------------------------------------------------------------------------
+// w = wh + wl * 2^-11 with wh = fp16(w), wl = fp16((w - wh) * 2^11)
+void split_f16(float w, uint16_t& hi, uint16_t& lo) {
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)((w - (float)h) * rt::kSplitScale);
+    std::memcpy(&hi, &h, 2);
+    std::memcpy(&lo, &l, 2);
+}
+
+bool s3p_eligible(const SubConv& sc, int cin) {
+    return !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && cin <= 32 && sc.Cout <= 32 && sc.nz == 1 &&
+           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3P", 0) == 0;
+}
+
+// conv_s3p_kernel's LDS image of the layer's weights: [tap][chunk of 16 ci][hi / lo][k-group of 8][co % 32][8 halfs]
+template <typename F>
+int upload_s3p(SubConv& sc, int cin_real, F wfun) {
+    std::vector<uint16_t> packed((size_t)rt::S3PCfg<8>::W_SLOTS * 8, 0);
+    for (int co = 0; co < sc.Cout; co++)
+        for (int ci = 0; ci < cin_real; ci++)
+            for (int t = 0; t < 9; t++) {
+                uint16_t hi, lo;
+                split_f16(wfun(co, ci, t / 3, t % 3), hi, lo);
+                const int c = ci / 16, kg = (ci % 16) / 8, e = ci % 8;
+                packed[(((((size_t)t * 2 + c) * 2 + 0) * 2 + kg) * 32 + co) * 8 + e] = hi;
+                packed[(((((size_t)t * 2 + c) * 2 + 1) * 2 + kg) * 32 + co) * 8 + e] = lo;
+            }
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
+    RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    sc.s3p = 1; sc.wino = 0;
+    sc.CinPad = 32; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 8;
+    return 0;
+}
+
+int device_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 // weights to host fp32 (fp16 weight files are widened once; activations stay fp32 in this build)
 std::vector<float> to_f32(const void* w, size_t n, int dtype) {
     std::vector<float> out(n);
@@ -728,9 +777,10 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     const std::vector<float> w = to_f32(weights, (size_t)d->Cout * d->Cin * d->KH * d->KW, d->dtype);
     plan->w_canon = w;
     const int Cin = d->Cin, KH = d->KH, KW = d->KW;
-    int rc = upload_packed(sc, Cin, [&](int co, int ci, int u, int v) {
+    auto wfun = [&](int co, int ci, int u, int v) {
         return w[(((size_t)co * Cin + ci) * KH + u) * KW + v];          // KCRS
-    });
+    };
+    int rc = s3p_eligible(sc, Cin) ? upload_s3p(sc, Cin, wfun) : upload_packed(sc, Cin, wfun);
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
     if (!rc) rc = upload_table(sc, table);
@@ -1202,7 +1252,7 @@ int repack_f16mma(rtConvPlan* plan) {
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < Cin; c++) table[c] = c * plan->hin * ip;
     if (int rc = upload_table(sc, table)) return rc;
-    sc.wino = 0; sc.f16mma = 1;
+    sc.wino = 0; sc.s3p = 0; sc.f16mma = 1;
     return 0;
 }
 
@@ -1228,7 +1278,7 @@ int repack_f16first(rtConvPlan* plan) {
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
-    sc.wino = 0; sc.f16first = 1;
+    sc.wino = 0; sc.s3p = 0; sc.f16first = 1;
     return 0;
 }
 
@@ -1240,14 +1290,16 @@ int repack_f32(rtConvPlan* plan) {
     const rtConv2dDesc& d = plan->desc2d;
     const std::vector<float>& w = plan->w_canon;
     const int Cin = d.Cin, Cout = d.Cout;
-    sc.f16mma = sc.f16first = 0;
+    sc.f16mma = sc.f16first = sc.s3p = 0;
     sc.x_f16 = sc.y_f16 = 0;
     sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
     choose_tiling(sc, !plan->is_deconv);
     check_direct(sc, Cin);
     sc.CinPad = sc.direct ? Cin : rt::round_up(Cin, sc.CC);
     std::vector<float> packed;
-    if (!plan->is_deconv) {
+    if (!plan->is_deconv && s3p_eligible(sc, Cin)) {
+        if (int rc = upload_s3p(sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; })) return rc;
+    } else if (!plan->is_deconv) {
         pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; });
     } else {
         const int s = d.stride;
@@ -1265,9 +1317,11 @@ int repack_f32(rtConvPlan* plan) {
         if (!sc.zs_host.empty())
             RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
     }
-    if (sc.w_dev) (void)hipFree(sc.w_dev);
-    sc.w_dev = nullptr;
-    if (int rc = upload_weights(sc, packed)) return rc;
+    if (!sc.s3p) {
+        if (sc.w_dev) (void)hipFree(sc.w_dev);
+        sc.w_dev = nullptr;
+        if (int rc = upload_weights(sc, packed)) return rc;
+    }
     if (sc.choff_dev) (void)hipFree(sc.choff_dev);
     sc.choff_dev = nullptr;
     const int ip = sc.x_pitch ? sc.x_pitch : plan->win;
@@ -1320,6 +1374,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
+        if (sc.s3p) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernel takes fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1335,6 +1390,7 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (!plan || !plan->is2d || plan->is_deconv || plan->subs.size() != 1) return 0;
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0 || sc.zs_dev || sc.y_xstride != 1 || sc.small3d || sc.direct) return 0;
+    if (sc.s3p) return (plan->cin % 4 == 0 ? 1 : 0) | (sc.Cout % 4 == 0 ? 6 : 0);
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
     if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
     if (sc.x_f16 || sc.y_f16) return 0;
@@ -1429,6 +1485,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.r_cstride = sc.r_cstride ? sc.r_cstride : sc.y_cstride;
         a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
         a.r_il8 = sc.r_il8;
+        a.batch = batch; a.cin_real = sc.cin_real; a.x_cstride = (int64_t)sc.Hi * a.x_pitch;
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
@@ -1447,6 +1504,21 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
 #undef RT_DIRECT
             if (!launched) return fail(RT_E_UNSUPPORTED, "conv (direct): window %dx%d not instantiated", sc.KH, sc.KW);
             RT_LAUNCH_CHECK("conv_direct_f32_kernel");
+            continue;
+        }
+        if (sc.s3p) {
+            // persistent: one 8-wave workgroup per CU walks a contiguous range of tiles (RT_S3P_GRID: test knob)
+            const int64_t T = (int64_t)a.tiles_x * tiles_y * batch;
+            int64_t g = std::min<int64_t>(T, env_int("RT_S3P_GRID", device_cus()));
+            if (g >= 8) g -= g % 8;
+            dim3 pgrid((unsigned)std::max<int64_t>(g, 1));
+            if (env_int("RT_CONV_TRACE", 0))
+                fprintf(stderr, "[rt] conv_s3p x%d y%d r%d tiles %lld grid %u\n", sc.x_il8, sc.y_il8, sc.r_il8, (long long)T, pgrid.x);
+            if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3p_kernel<8, true, true>), pgrid, dim3(512), 0, S(s), a);
+            else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3p_kernel<8, true, false>), pgrid, dim3(512), 0, S(s), a);
+            else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3p_kernel<8, false, true>), pgrid, dim3(512), 0, S(s), a);
+            else hipLaunchKernelGGL((rt::conv_s3p_kernel<8, false, false>), pgrid, dim3(512), 0, S(s), a);
+            RT_LAUNCH_CHECK("conv_s3p_kernel");
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);

@@ -1,0 +1,101 @@
+"""Parity of the split-fp16 convolution kernels (conv_split.hip.h: fp32 tensors, three fp16 MFMAs per product term,
+fp32 accumulation) against an fp64 evaluation of the same convolution, next to the fp32 fmaf-chain kernels they replace:
+the split form must be as accurate as fp32 arithmetic, not merely inside the 1e-3 budget.  Persistent tile loop
+(several tiles per workgroup, both LDS buffers), image edges, channel tails, every mix of planar and channel-interleaved
+tensors, batch > 1.  CPU tier: SIMT emulator; GPU tier: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import capi
+from test_ops_parity import rnd
+from test_pitch_parity import pitched
+from test_wino_parity import from_il, to_il
+
+
+def ref64(x, wt, b, res, act):
+    y = O.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), 1, 1)
+    if res is not None:
+        y = y + torch.from_numpy(res).double()
+    y = O.elu(y) if act == capi.RT_ACT_ELU else (torch.sigmoid(y) if act == capi.RT_ACT_SIGMOID else y)
+    return y.numpy()
+
+
+def run(backend, x, wt, b, res, act, batch, pitch=0, x_il=0, y_il=0, r_il=0):
+    cout, cin = wt.shape[:2]
+    h, w = x.shape[2:]
+    P = pitch or w
+    plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 3, 1, 1, act=act, has_residual=res is not None)
+    if pitch:
+        plan.set_pitch(pitch, pitch)
+    if x_il or y_il or r_il:
+        plan.set_layouts(x_il, y_il, r_il)
+    lay = lambda a, f: to_il(a, 4) if f else a
+    xin = backend.dev(lay(pitched(x, P), x_il))                       # NaN in the padding columns
+    rin = backend.dev(lay(pitched(res, P), r_il)) if res is not None else None
+    y = backend.empty((batch, cout // 4, h, P, 4) if y_il else (batch, cout, h, P))
+    plan.enqueue(xin, y, rin, batch)
+    out = backend.host(y).copy()
+    out = from_il(out) if y_il else out
+    plan.destroy()
+    if P > w:
+        assert np.isnan(out[..., w:]).all(), "padding columns were written"
+    return out[..., :w]
+
+
+CASES = [
+    # cin, cout, h, w, act, resid, batch, pitch, (x_il, y_il, r_il)
+    (32, 32, 19, 70, capi.RT_ACT_ELU, True, 2, 96, (1, 1, 1)),     # the resblock layer: 3 x 3 tiles per image, 2 images
+    (32, 32, 9, 33, capi.RT_ACT_ELU, True, 1, 64, (1, 1, 0)),      # one row / one pixel past a tile
+    (32, 32, 8, 32, capi.RT_ACT_NONE, False, 1, 0, (0, 0, 0)),     # exactly one tile, planar, dense rows
+    (32, 32, 17, 45, capi.RT_ACT_ELU, False, 1, 64, (1, 0, 0)),    # encoder2D_out: interleaved in, planar out
+    (32, 32, 11, 37, capi.RT_ACT_ELU, True, 1, 64, (0, 1, 1)),     # resblock1_conv1-like: planar in, interleaved out
+    (16, 24, 10, 40, capi.RT_ACT_SIGMOID, True, 2, 0, (1, 1, 1)),  # one chunk only, Cout < 32
+    (20, 30, 7, 35, capi.RT_ACT_ELU, True, 1, 0, (1, 0, 0)),       # Cout % 4 != 0 -> planar output / residual
+    (13, 9, 5, 9, capi.RT_ACT_NONE, False, 3, 0, (0, 0, 0)),       # odd channel counts, image smaller than a tile
+    (8, 8, 3, 5, capi.RT_ACT_ELU, False, 1, 32, (1, 1, 0)),        # NVTiny's 2-D encoder width
+    (3, 32, 1, 1, capi.RT_ACT_NONE, False, 2, 0, (0, 1, 0)),       # single pixel
+]
+
+
+@pytest.mark.parametrize("grid", [0, 3])
+@pytest.mark.parametrize("cin,cout,h,w,act,resid,batch,pitch,il", CASES)
+def test_split_conv2d(backend, monkeypatch, cin, cout, h, w, act, resid, batch, pitch, il, grid):
+    """grid = 3: three workgroups walk all tiles (persistent loop, double-buffered patch, prefetch across tiles and
+    images); grid = 0: the default one-workgroup-per-CU launch"""
+    if grid:
+        monkeypatch.setenv("RT_S3P_GRID", str(grid))
+    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
+    res = rnd(batch, cout, h, w) if resid else None
+    ref = ref64(x, wt, b, res, act)
+    out = run(backend, x, wt, b, res, act, batch, pitch, *il)
+    err = np.abs(out - ref).max()
+    assert err <= 5e-6, err
+    # the exact-fp32 kernels on the same input: the split form is not allowed to be (noticeably) less accurate
+    monkeypatch.setenv("RT_CONV_EXACT_FP32", "1")
+    exact = run(backend, x, wt, b, res, act, batch, pitch, 0, 0, 0)
+    assert err <= max(3.0 * np.abs(exact - ref).max(), 1.5e-6), (err, np.abs(exact - ref).max())
+
+
+def test_split_is_fp32_accurate_on_large_and_tiny_values(backend):
+    """dynamic range: activations of a few hundred next to ones of 1e-4 (low parts are pre-scaled, so nothing relies on
+    fp16 subnormals); error relative to the magnitude of the sum stays in the fp32-roundoff class"""
+    rng = np.random.default_rng(5)
+    x = rnd(1, 32, 12, 40)
+    x *= np.where(rng.random(x.shape) < 0.5, np.float32(300.0), np.float32(1e-4))
+    wt, b = rnd(32, 32, 3, 3) * np.float32(0.1), rnd(32)
+    ref = ref64(x, wt, b, None, capi.RT_ACT_NONE)
+    out = run(backend, x, wt, b, None, capi.RT_ACT_NONE, 1)
+    mag = O.conv2d(torch.from_numpy(np.abs(x)).double(), torch.from_numpy(np.abs(wt)).double(), None, 1, 1).numpy()
+    assert np.abs(ref).max() > 100
+    assert (np.abs(out - ref) / mag).max() <= 4e-7          # ~ 2^-22 + accumulation roundoff, relative to sum |x w|
+
+
+def test_split_overflow_is_loud(backend):
+    """outside the fp16 range of the high part (|x| >= 65520) the result is inf / NaN, never a silently wrong number"""
+    x = rnd(1, 32, 8, 32)
+    x[0, 3, 4, 5] = 7.0e4
+    wt, b = rnd(32, 32, 3, 3), rnd(32)
+    out = run(backend, x, wt, b, None, capi.RT_ACT_NONE, 1)
+    assert not np.isfinite(out[0, :, 3:6, 4:7]).all()

@@ -11,6 +11,13 @@ from oracle import stereo_oracle as O
 from redtail_amd import capi
 from test_ops_parity import T, near, rnd
 
+@pytest.fixture(autouse=True)
+def _winograd_only(monkeypatch):
+    """these tests are about the fp32 Winograd / direct-form kernels: keep small layers off the split-fp16 kernel
+    (tests/test_split_parity.py covers that one)"""
+    monkeypatch.setenv("RT_NO_S3P", "1")
+
+
 WINO_CASES = [
     # cin, cout, h, w, act, resid, batch
     (32, 32, 9, 33, capi.RT_ACT_ELU, True, 1),        # one pixel past a 32-wide tile
