@@ -239,3 +239,222 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
 }
 
 }  // namespace rt
+
+namespace rt {
+
+// -----------------------------------------------------------------------------------------------------------------------
+// conv_s3_kernel: the general form -- every window / gather description conv_mfma_f32_kernel serves (3x3 stride 1 / 2,
+// the 1x1 .. 2x2 windows of merged transposed-convolution phases with their ZSlice tables, the (D*C)-merged gather
+// table of Conv3DPlugin / Conv3DTransposePlugin; reference lib/conv3d_plugin.cpp:187-216,
+// conv3d_transpose_plugin.cpp:205-243) on the same 3-term fp16 split.  One workgroup = 4 rows x 32 pixels x 32 output
+// channels, 4 waves; per chunk of 16 gathered channels:
+//   global (fp32) --registers: loads of chunk i+1 fly under the MFMAs of chunk i--> split --> LDS patch image
+//       [row][col] pixels x (16 x fp16 hi | 16 x fp16 lo | 16 B pad = 80 B: 20 banks, conflict-free ds_read_b128)
+//   weights (split on the host) [chunk][tap][hi/lo][k-group][co][8 halfs]: a straight 16-byte copy into LDS
+//   per tap 2 + 2 LDS fetches, 3 MFMAs.
+// Staging: wave w gathers channel group w (4 channels) of the chunk for every patch pixel, so the plane offsets come
+// from the gather table as scalars.  Stride 2: even and odd patch columns are stored apart, so that the lanes of a B
+// fetch (pixels 2l + s) still read consecutive LDS pixels.
+// -----------------------------------------------------------------------------------------------------------------------
+template <int KH, int KW, int S>
+struct S3Cfg {
+    static constexpr int NW = 4, TY = 4, TX = 32, CC = 16, TAPS = KH * KW, NT = 256;
+    static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW;
+    static constexpr int PCH = (PC + 1) / 2;                       // stride 2: columns per parity
+    static constexpr int PCL = S == 2 ? 2 * PCH : PC;              // LDS columns per patch row
+    static constexpr int NPIX = PR * PC, NKP = (NPIX + 63) / 64;   // patch pixels per lane (each wave covers the whole patch)
+    static constexpr int PXB = 80;
+    static constexpr int W_SLOTS = TAPS * 2 * 2 * 32;              // 16-byte slots of one chunk's weights
+    static constexpr int NK_W = (W_SLOTS + NT - 1) / NT;
+    static_assert(S == 1 || S == 2, "stride 1 or 2");
+};
+
+// register budget: 4 waves per SIMD (4 workgroups per CU) for the stride-1 windows, whose patch + weight images are
+// <= 35 KB; the stride-2 patch (66 KB) allows two workgroups per CU anyway
+#ifndef RT_S3_WAVES
+#define RT_S3_WAVES(S) ((S) == 2 ? 2 : 4)
+#endif
+template <int KH, int KW, int S, bool XIL, bool YIL>
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
+    using Cfg = S3Cfg<KH, KW, S>;
+    constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
+    constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
+
+    __shared__ __attribute__((aligned(16))) char sIn[Cfg::PR * PCL * PXB];
+    __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile = blockIdx.x;
+    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (tile % p.tiles_x) * TX;
+    const int ty0 = (tile / p.tiles_x) * TY;
+    const int nblk = blockIdx.y;
+    const int zi = blockIdx.z % p.nz;
+    const int n = blockIdx.z / p.nz;
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, 4);
+    const int nchunks = p.CinPad / CC;
+    int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
+    unsigned tap_mask = ~0u;
+    if (p.zs) {
+        const ZSlice z = p.zs[zi];
+        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
+        r_off = z.r_off;
+        tap_mask = z.tap_mask;
+    }
+    const int act = p.act;
+
+    // ---- staging: wave w gathers channels 4w .. 4w+3 of each chunk for every patch pixel -----------------------------
+    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 4 * wv;
+    unsigned voff[NKP];
+    int lidx[NKP];
+#pragma unroll
+    for (int k = 0; k < NKP; k++) {
+        const int pidx = lane + 64 * k;
+        const int pr = pidx / PC, pc = pidx - pr * PC;
+        const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
+        const bool own = pidx < Cfg::NPIX;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : 4u) : kBufOOB;
+        const int col = S == 2 ? (pc & 1) * Cfg::PCH + (pc >> 1) : pc;
+        lidx[k] = own ? (pr * PCL + col) * PXB + wv * 8 : -1;
+    }
+    // w_off and the slab size count 16-byte slots
+    const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + (w_off + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS) * 16;
+    const buf_rsrc rs_w = make_buf(wsrc);
+
+    f32x4 rin[NKP];
+    f32x4 rw[NK_W];
+    auto prefetch = [&](int ch) {
+        if constexpr (XIL) {
+            const int off = tab[ch * CC];                          // group offset == planar offset of its first channel
+            const buf_rsrc rs = make_buf(xb, off >= 0);
+#pragma unroll
+            for (int k = 0; k < NKP; k++) rin[k] = buf_load4(rs, voff[k], (unsigned)off * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int off = tab[ch * CC + j];                  // wave-uniform scalar load
+                const buf_rsrc rs = make_buf(xb, off >= 0);
+#pragma unroll
+                for (int k = 0; k < NKP; k++) rin[k][j] = buf_load(rs, voff[k], (unsigned)off * 4u);
+            }
+        }
+        const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            rw[k] = buf_load4(rs_w, idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB, so);
+        }
+    };
+    auto stage_to_lds = [&]() {
+#pragma unroll
+        for (int k = 0; k < NKP; k++) {
+            if (lidx[k] < 0) continue;
+            const S3Split s = s3_split(rin[k]);
+            *reinterpret_cast<f16x4*>(sIn + lidx[k]) = s.hi;
+            *reinterpret_cast<f16x4*>(sIn + lidx[k] + 32) = s.lo;
+        }
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            if (idx < Cfg::W_SLOTS) sW[idx] = rw[k];
+        }
+    };
+
+    // ---- output addressing; the residual tile is requested first and consumed in the epilogue ----------------------------
+    const int64_t ybase = (int64_t)n * p.y_bstride + y_off;
+    const int64_t rbase = (int64_t)n * p.r_bstride + r_off;
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
+    const int oy = ty0 + wv, ox = tx0 + l31;
+    const bool inb = oy < Ho && ox < Wo;
+    const bool r_il = p.r_il8 != 0;
+    const int cb = nblk * 32;                                       // first channel of this block
+    f32x4 rr[4];
+    if (p.resid != nullptr) {
+        // interleaved tensors (2-D plans only): pixel offsets -- r_off / y_off of a transposed-convolution phase -- count
+        // 16-byte slots, i.e. 4 elements
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + 4 * r_off : rbase, 4));
+        if (r_il) {
+            const unsigned vo = inb ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rs_r, (cb + 8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q) * rs32) * 4u);
+        } else {
+            const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    rr[q][e] = buf_load(rs_r, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * rs32) * 4u);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) rr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    f32x16 acc_m, acc_c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+    const int a_off = kg * 32 + l31;
+    // B operand of tap (r, s): pixel (wv*S + r, l31*S + s); stride 2: column parity (s & 1), index l31 + (s >> 1)
+    const int b_off = (wv * S * PCL + l31) * PXB + kg * 16;
+    auto compute = [&]() {
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) {
+            if (!((tap_mask >> t) & 1u)) continue;                  // wave-uniform
+            const int r = t / KW, s = t % KW;
+            const int col = S == 2 ? (s & 1) * Cfg::PCH + (s >> 1) : s;
+            const char* bp = sIn + b_off + (r * PCL + col) * PXB;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 32);
+            const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 0) * 64]);
+            const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 1) * 64]);
+            acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+        }
+    };
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunks; ch++) {
+        if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
+        stage_to_lds();
+        __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+        compute();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------------
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, YIL ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, 4));
+    auto epilogue = [&](auto ACT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * q + 4 * kg);     // padded to 64 channels
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
+            if constexpr (YIL) {
+                const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
+            } else {
+                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    buf_store(o[e], rs_y, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * cs32) * 4u);
+            }
+        }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+}  // namespace rt

@@ -420,6 +420,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
     int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
+    int split3 = 0;                     // conv_s3_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (general form)
     int s3p = 0;                        // conv_s3p_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe, persistent (3x3 s1, Cin, Cout <= 32)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
@@ -463,6 +464,15 @@ Phase1D phase1d(int s, int p, int k, int phi) {
     return ph;
 }
 
+// ---- 3-term fp16 split (conv_split.hip.h) ---------------------------------------------------------------------------
+// w = wh + wl * 2^-11 with wh = fp16(w), wl = fp16((w - wh) * 2^11)
+void split_f16(float w, uint16_t& hi, uint16_t& lo) {
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)((w - (float)h) * rt::kSplitScale);
+    std::memcpy(&hi, &h, 2);
+    std::memcpy(&lo, &l, 2);
+}
+
 // Appends the weights of one launch (or of one phase of a multi-phase launch) to `packed`, in the exact
 // order of the kernel's LDS slab: [nblk][chunk][tap][h][NB][CC/2] with gathered channel
 // ci = chunk*CC + 2*j + h; wfun(co, ci, u, v) = weight of output channel co, gathered channel ci, window
@@ -479,6 +489,26 @@ int64_t pack_into(std::vector<float>& packed, const SubConv& sc, int cin_real, F
                     for (int v = 0; v < sc.KW; v++)
                         packed[base + ((size_t)co * cin_real + ci) * taps + u * sc.KW + v] = wfun(co, ci, u, v);
         return base;
+    }
+    if (sc.split3) {
+        // split fp16 slabs of conv_s3_kernel: [nblk of 32 co][chunk of 16 ci][tap][hi / lo][k-group of 8][co % 32][8 halfs],
+        // two halfs per float of `packed`; the returned offset counts 16-byte slots
+        const int nblk = (int)rt::cdiv(sc.Cout, 32), nch = sc.CinPad / 16;
+        const size_t slots = (size_t)nblk * nch * taps * 2 * 2 * 32;
+        packed.resize(base + slots * 4, 0.f);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(packed.data() + base);
+        for (int co = 0; co < sc.Cout; co++)
+            for (int ci = 0; ci < cin_real; ci++)
+                for (int u = 0; u < sc.KH; u++)
+                    for (int v = 0; v < sc.KW; v++) {
+                        uint16_t hi, lo;
+                        split_f16(wfun(co, ci, u, v), hi, lo);
+                        const int nb = co / 32, cc = co % 32, ch = ci / 16, kg = (ci % 16) / 8, e = ci % 8, t = u * sc.KW + v;
+                        const size_t slab = ((size_t)nb * nch + ch) * taps + t;
+                        dst[(((slab * 2 + 0) * 2 + kg) * 32 + cc) * 8 + e] = hi;
+                        dst[(((slab * 2 + 1) * 2 + kg) * 32 + cc) * 8 + e] = lo;
+                    }
+        return base / 4;
     }
     if (sc.wino) {
         // U = G g G^T per (co, ci), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; slab order of conv_wino_f32_kernel:
@@ -615,15 +645,11 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     if (sc.wino) { sc.CC = 8; sc.NBW = 1; sc.TY = env_int("RT_WINO_WAVES", 4); sc.TXW = 1; sc.NW = sc.TY; }
     const int nbw = env_int("RT_CONV_NBW", 0);
     if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
-}
-
-// ---- 3-term fp16 split (conv_split.hip.h) ---------------------------------------------------------------------------
-// w = wh + wl * 2^-11 with wh = fp16(w), wl = fp16((w - wh) * 2^11)
-void split_f16(float w, uint16_t& hi, uint16_t& lo) {
-    const _Float16 h = (_Float16)w;
-    const _Float16 l = (_Float16)((w - (float)h) * rt::kSplitScale);
-    std::memcpy(&hi, &h, 2);
-    std::memcpy(&lo, &l, 2);
+    // fp32 tensors on the fp16 matrix pipe (3-term split, conv_split.hip.h) for every window that kernel is built for;
+    // RT_CONV_EXACT_FP32=1 keeps the fp32 fmaf-chain kernels
+    const bool s3_win = (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
+    sc.split3 = (!sc.direct && s3_win && env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3", 0) == 0) ? 1 : 0;
+    if (sc.split3) { sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4; }
 }
 
 bool s3p_eligible(const SubConv& sc, int cin) {
@@ -648,7 +674,7 @@ int upload_s3p(SubConv& sc, int cin_real, F wfun) {
     sc.w_dev = nullptr;
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
-    sc.s3p = 1; sc.wino = 0;
+    sc.s3p = 1; sc.split3 = 0; sc.wino = 0;
     sc.CinPad = 32; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 8;
     return 0;
 }
@@ -1252,7 +1278,7 @@ int repack_f16mma(rtConvPlan* plan) {
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < Cin; c++) table[c] = c * plan->hin * ip;
     if (int rc = upload_table(sc, table)) return rc;
-    sc.wino = 0; sc.s3p = 0; sc.f16mma = 1;
+    sc.wino = 0; sc.s3p = sc.split3 = 0; sc.f16mma = 1;
     return 0;
 }
 
@@ -1278,7 +1304,7 @@ int repack_f16first(rtConvPlan* plan) {
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
-    sc.wino = 0; sc.s3p = 0; sc.f16first = 1;
+    sc.wino = 0; sc.s3p = sc.split3 = 0; sc.f16first = 1;
     return 0;
 }
 
@@ -1290,7 +1316,7 @@ int repack_f32(rtConvPlan* plan) {
     const rtConv2dDesc& d = plan->desc2d;
     const std::vector<float>& w = plan->w_canon;
     const int Cin = d.Cin, Cout = d.Cout;
-    sc.f16mma = sc.f16first = sc.s3p = 0;
+    sc.f16mma = sc.f16first = sc.s3p = sc.split3 = 0;
     sc.x_f16 = sc.y_f16 = 0;
     sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
     choose_tiling(sc, !plan->is_deconv);
@@ -1374,7 +1400,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
-        if (sc.s3p) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernel takes fp32 tensors (both fp16: fp16 operands instead)");
+        if (sc.s3p || sc.split3) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1387,7 +1413,11 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
 // Channel-interleaved tensors (see conv_wino.hip.h / conv_f16.hip.h): which of a plan's tensors can have the layout --
 // bit 0 input, bit 1 output, bit 2 residual; 0 = none ...
 extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
-    if (!plan || !plan->is2d || plan->is_deconv || plan->subs.size() != 1) return 0;
+    if (!plan || !plan->is2d || plan->subs.size() != 1) return 0;
+    // the general split-fp16 kernel (any 2-D window, transposed phases included) takes and writes them freely
+    if (plan->subs[0].split3 && env_int("RT_NO_IL8", 0) == 0)
+        return (plan->cin % 4 == 0 ? 1 : 0) | (plan->subs[0].Cout % 4 == 0 ? 6 : 0);
+    if (plan->is_deconv) return 0;
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0 || sc.zs_dev || sc.y_xstride != 1 || sc.small3d || sc.direct) return 0;
     if (sc.s3p) return (plan->cin % 4 == 0 ? 1 : 0) | (sc.Cout % 4 == 0 ? 6 : 0);
@@ -1522,6 +1552,24 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.split3) {
+            if (env_int("RT_CONV_TRACE", 0))
+                fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
+            bool launched = false;
+#define RT_S3(kh, kw, st)                                                                                                   \
+    if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                            \
+        if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, true, true>), grid, dim3(256), 0, S(s), a);        \
+        else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, true, false>), grid, dim3(256), 0, S(s), a);              \
+        else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, true>), grid, dim3(256), 0, S(s), a);              \
+        else hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false>), grid, dim3(256), 0, S(s), a);                           \
+        launched = true;                                                                                                    \
+    }
+            RT_S3(3, 3, 1) RT_S3(3, 3, 2) RT_S3(1, 1, 1) RT_S3(1, 2, 1) RT_S3(2, 1, 1) RT_S3(2, 2, 1)
+#undef RT_S3
+            if (!launched) return fail(RT_E_UNSUPPORTED, "conv (split fp16): window %dx%d stride %d not instantiated", sc.KH, sc.KW, sc.S);
+            RT_LAUNCH_CHECK("conv_s3_kernel");
+            continue;
+        }
         if (sc.f16first) {
             if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_f16_first il8 y%d grid %u x %u x %u\n", sc.y_il8, grid.x, grid.y, grid.z);
             if (sc.y_il8) hipLaunchKernelGGL((rt::conv_f16_first_kernel<true>), grid, dim3(256), 0, S(s), a, plan->cin);

@@ -99,3 +99,60 @@ def test_split_overflow_is_loud(backend):
     wt, b = rnd(32, 32, 3, 3), rnd(32)
     out = run(backend, x, wt, b, None, capi.RT_ACT_NONE, 1)
     assert not np.isfinite(out[0, :, 3:6, 4:7]).all()
+
+
+# ---- the general kernel (conv_s3_kernel): other windows, more channels, transposed phases ------------------------------
+def ref64_g(x, wt, b, res, act, stride, tr):
+    X, Wt, B = torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double()
+    y = O.deconv2d(X, Wt, B, stride, 1) if tr else O.conv2d(X, Wt, B, stride, wt.shape[-1] // 2)
+    if res is not None:
+        y = y + torch.from_numpy(res).double()
+    y = O.elu(y) if act == capi.RT_ACT_ELU else (torch.sigmoid(y) if act == capi.RT_ACT_SIGMOID else y)
+    return y.numpy()
+
+
+G_CASES = [
+    # cin, cout, h, w, k, stride, transposed, act, resid, batch, (x_il, y_il, r_il)
+    (33, 32, 9, 37, 3, 1, False, capi.RT_ACT_ELU, False, 1, (0, 1, 0)),      # conv2D_1: 33 channels -> 3 chunks, 15 of them padding
+    (64, 64, 10, 37, 3, 1, False, capi.RT_ACT_ELU, True, 2, (1, 1, 1)),      # conv2D_4/5: two 32-channel blocks, 4 chunks
+    (128, 128, 5, 18, 3, 1, False, capi.RT_ACT_ELU, False, 1, (1, 1, 0)),    # conv2D_7/8
+    (32, 64, 11, 37, 3, 2, False, capi.RT_ACT_ELU, False, 2, (1, 1, 0)),     # conv2D_3ds: stride 2, even / odd patch columns
+    (64, 128, 8, 66, 3, 2, False, capi.RT_ACT_ELU, False, 1, (0, 0, 0)),     # conv2D_6ds, planar
+    (20, 36, 9, 35, 3, 2, False, capi.RT_ACT_NONE, True, 1, (1, 1, 1)),      # channel tails, stride 2 with residual
+    (128, 64, 5, 9, 3, 2, True, capi.RT_ACT_ELU, True, 2, (1, 1, 1)),        # deconv2D_1: 4 phases in one launch, interleaved everywhere
+    (64, 32, 6, 13, 3, 2, True, capi.RT_ACT_ELU, True, 1, (1, 0, 0)),        # deconv2D_2: planar output + residual
+    (24, 20, 7, 33, 3, 2, True, capi.RT_ACT_SIGMOID, False, 1, (0, 1, 0)),   # transposed, odd sizes, interleaved output only
+    (16, 40, 6, 35, 1, 1, False, capi.RT_ACT_NONE, False, 2, (1, 1, 0)),     # 1x1
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k,stride,tr,act,resid,batch,il", G_CASES)
+def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act, resid, batch, il):
+    monkeypatch.setenv("RT_NO_S3P", "1")
+    x, b = rnd(batch, cin, h, w), rnd(cout)
+    wt = rnd(*((cin, cout, k, k) if tr else (cout, cin, k, k))) * np.float32(1 / np.sqrt(cin * k * k / (stride * stride if tr else 1)))
+    shape = ref64_g(x, wt, b, None, capi.RT_ACT_NONE, stride, tr).shape
+    res = rnd(*shape) if resid else None
+    ref = ref64_g(x, wt, b, res, act, stride, tr)
+    ho, wo = shape[-2:]
+    ip, op = (w + 31) // 32 * 32, (wo + 31) // 32 * 32
+    outs = []
+    for x_il, y_il, r_il in (il, (0, 0, 0)):
+        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, 1 if tr else k // 2, act=act, has_residual=resid, transposed=tr)
+        plan.set_pitch(ip, op)
+        if x_il or y_il or r_il:
+            assert plan.il_caps() == (1 if cin % 4 == 0 else 0) | (6 if cout % 4 == 0 else 0)
+            plan.set_layouts(x_il, y_il, r_il)
+        lay = lambda a, f: to_il(a, 4) if f else a
+        xin = backend.dev(lay(pitched(x, ip), x_il))
+        rin = backend.dev(lay(pitched(res, op), r_il)) if resid else None
+        y = backend.empty((batch, cout // 4, ho, op, 4) if y_il else (batch, cout, ho, op))
+        plan.enqueue(xin, y, rin, batch)
+        out = backend.host(y).copy()
+        out = from_il(out) if y_il else out
+        plan.destroy()
+        if op > wo:
+            assert np.isnan(out[..., wo:]).all(), "padding columns were written"
+        outs.append(out[..., :wo])
+    assert np.abs(outs[0] - ref).max() <= 5e-6, np.abs(outs[0] - ref).max()
+    assert np.array_equal(outs[0], outs[1])                       # layouts change addressing only

@@ -8,11 +8,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from redtail_amd import capi, synth  # noqa: E402
+from redtail_amd import capi, model_files, synth  # noqa: E402
 
 W, H, b = 1257, 369, int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = capi.NetLib()
-net = lib.create("resnet18_2D", W, H, max_batch=b, weights=synth.synth_weights_resnet18_2d())
+net = lib.create("resnet18_2D", W, H, max_batch=b, weights_path=model_files.weight_file("resnet18_2D"))
 l, r = synth.synth_pair(H, W)
 L = torch.from_numpy(np.stack([l] * b)).cuda()
 R = torch.from_numpy(np.stack([r] * b)).cuda()
