@@ -46,6 +46,7 @@ from redtail_amd import capi, model_files, parallel, synth  # noqa: E402
 W, H = 1257, 369
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0                 # same table: HBM3E, 8 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0         # same table: dense fp16 / bf16 matrix peak
 HALF_W, HALF_H = 629, 185
 DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
 DOMINANT_BYTES = 4.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9 + 32)     # x, residual, y, weights, bias
@@ -363,36 +364,65 @@ def main():
                     tot += ms
                     cnt += 1
         avg_s = tot / cnt * 1e-3
-        achieved = DOMINANT_FLOPS * b / avg_s / 1e12
+        launches = cnt // prof_runs
+        step_s = elapsed / args.steps
         traffic, traffic_src = measured_traffic(args.half2) if b == 1 else (None, None)
-        if args.half2:
-            # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the same layer HBM-bound, so it is
-            # priced in bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
-            h2_bytes = 2.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9) + 4.0 * 32
-            roofline = {"bound": "hbm", "kernel": "conv_f16mma_kernel<3,3,1> 3x3 32->32 @629x185 (+bias,+residual,+ELU), fp16 operands, fp32 accumulate",
-                        "achieved": h2_bytes * b / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": h2_bytes * b / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_unit": "bytes/launch, mean over launches with and without residual (PMC pass %s)" % traffic_src,
-                        "algorithmic_bytes": h2_bytes * b, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
-                        "flops_per_launch": DOMINANT_FLOPS * b}
-        else:
-            roofline = {"bound": "mfma", "kernel": "conv_wino_f32_kernel<4,float,float,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU), Winograd F(2x2,3x3), channel-interleaved tensors",
-                        "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
-                        "algorithmic_bytes": DOMINANT_BYTES * b,
-                        "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt // prof_runs,
-                        "flops_per_launch": DOMINANT_FLOPS * b, "mfma_flops_executed": DOMINANT_FLOPS * b * 16.0 / 36.0}
+        exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
         iso_us = isolated_dominant(lib.kernels, b, args.half2)
-        roofline["isolated_launch_us"] = iso_us
-        roofline["frac_isolated"] = (roofline["algorithmic_bytes"] / iso_us / 1e3 / HBM_PEAK_GBS if args.half2
-                                     else DOMINANT_FLOPS * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS)
+        if args.half2:
+            # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the layer HBM-bound, so it is priced in
+            # bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
+            nbytes = 2.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9) + 4.0 * 32
+            kernel = "conv_f16mma_kernel<3,3,1> 3x3 32->32 @629x185 (+bias,+residual,+ELU), fp16 operands, fp32 accumulate"
+            mfma_exec = DOMINANT_FLOPS
+        elif exact:
+            nbytes = DOMINANT_BYTES
+            kernel = "conv_wino_f32_kernel<4,float,float,il,il> (RT_CONV_EXACT_FP32=1: Winograd F(2x2,3x3) on the fp32 matrix pipe)"
+            mfma_exec = DOMINANT_FLOPS * 16.0 / 36.0
+        else:
+            # fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (conv_split.hip.h): 3 x the direct-form multiplies at
+            # 16 x the fp32 rate -- 1/5 of the fp32 matrix time -- which leaves the layer bound by its fp32 traffic:
+            # x + residual + y (+ weights, bias), every byte once
+            nbytes = DOMINANT_BYTES
+            kernel = "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate"
+            mfma_exec = 3.0 * DOMINANT_FLOPS
+        if exact and not args.half2:
+            achieved, peak, unit, bound = DOMINANT_FLOPS * b / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            iso_frac = DOMINANT_FLOPS * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
+        else:
+            achieved, peak, unit, bound = nbytes * b / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+            iso_frac = nbytes * b / iso_us / 1e3 / HBM_PEAK_GBS
+        overlapped = launches * avg_s > step_s * b            # launches of several streams / contexts run concurrently
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if (exact and not args.half2) else MFMA_F16_PEAK_TFLOPS
+        roofline = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                    "frac_note": ("in-situ launch duration (HIP events on the launch stream inside the running network); %d launches x "
+                                  "%.1f us %s one step of %.1f us, i.e. launches of the two streams / %d contexts overlap: use frac_isolated "
+                                  "and frac_step as throughput statements" % (launches, avg_s * 1e6, ">" if overlapped else "<=", step_s * 1e6, nctx)),
+                    "overlapped": bool(overlapped), "traffic": traffic,
+                    "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
+                    "algorithmic_bytes": nbytes * b, "flops_per_launch": DOMINANT_FLOPS * b,
+                    "avg_launch_us": avg_s * 1e6, "launches_per_step": launches,
+                    "isolated_launch_us": iso_us, "frac_isolated": iso_frac,
+                    # whole step against the roofs: direct-form FLOPs of the network / fp32 matrix peak, and the minimum
+                    # (perfectly fused) activation traffic of SURVEY.md 8d / HBM peak
+                    "frac_step": NET_FLOPS * b / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "frac_step_note": "91.87 GFLOP (direct form) per pair / ms_per_step / 157.3 TFLOP/s fp32 matrix peak; above 1 is "
+                                      "possible because the split kernels run on the fp16 pipe",
+                    "step_tflops": NET_FLOPS * b / step_s / 1e12,
+                    "mfma_flops_executed": mfma_exec * b,
+                    "mfma_util_executed": mfma_exec * b / iso_us / 1e6 / mfma_peak,
+                    "mfma_util_note": "executed matrix FLOPs of one launch / isolated duration / %.0f TFLOP/s (%s pipe)" % (
+                        mfma_peak, "fp32" if (exact and not args.half2) else "fp16")}
         out = {
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 (f32 accumulate)" if args.half2 else "f32", "data": "synthetic",
+            "arithmetic": ("fp16 operands, fp32 accumulate (TensorRT half2 mode)" if args.half2 else
+                           "fp32 fmaf chains on the fp32 matrix pipe (RT_CONV_EXACT_FP32=1)" if os.environ.get("RT_CONV_EXACT_FP32", "0") != "0" else
+                           "fp32 tensors; convolutions as 3-term fp16 splits (22-bit operands, exact products) with fp32 accumulation "
+                           "on the fp16 matrix pipe; correlation, soft-argmax, activations in fp32 -- error vs fp64 in the fp32-roundoff class"),
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,

@@ -161,6 +161,10 @@ int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const v
  * plan.  Not in the reference (TensorRT owns its internal layouts): lets the executor keep internal activations
  * 128-byte aligned per row.  Tensors are then (N, C, H, pitch) in memory with W valid columns. */
 int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pitch);
+/* Per-sample strides in elements (0 = unchanged) of input / output / residual: a tensor may live inside a larger buffer,
+ * e.g. as a channel range of the tensor TensorRT's addConcatenation would have copied it into
+ * (reference resnet18_2D_513x257_net.cpp:612-615).  Call after rt_conv_plan_set_pitch. */
+int rt_conv_plan_set_batch_strides(rtConvPlan* plan, int64_t x_bstride, int64_t y_bstride, int64_t r_bstride);
 
 /* Storage type (RT_F32 / RT_F16) of the input and of the output + residual tensors of a 2-D plan: TensorRT's half2
  * mode (IBuilder::setHalf2Mode, sample_app/main.cpp:256-262) keeps activations in fp16 between layers.

@@ -74,6 +74,7 @@ KERNEL_SYMBOLS = {
     "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
+    "rt_conv_plan_set_batch_strides": (c_int, [c_void_p, c_int64, c_int64, c_int64]),
     "rt_conv_plan_set_io_types": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),

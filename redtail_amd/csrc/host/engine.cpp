@@ -418,6 +418,7 @@ private:
     bool lower();
     void assignStreams();
     void assignPitch();
+    void foldConcats();
     bool ok_ = false;
     bool half2_ = false;
 public:
@@ -459,6 +460,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     ok_ = lower();
     if (ok_) assignPitch();
     if (ok_) assignStreams();
+    if (ok_) foldConcats();
 }
 
 EngineImpl::~EngineImpl() {
@@ -854,6 +856,67 @@ void EngineImpl::assignStreams() {
             for (int w : o2.wait_on) op.publish |= (w == root(op.out));
 }
 
+// Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the
+// 33-channel input of conv2D_1, resnet18_2D_513x257_net.cpp:612-615): when every input of a concatenation is written
+// by a launch that takes an output batch stride (2-D convolution plans, the fused correlation) and read only by
+// convolution plans, the inputs BECOME channel ranges of the concatenated buffer -- same planar layout and row pitch, a
+// per-sample stride of the whole buffer -- and the copy launches disappear.
+void EngineImpl::foldConcats() {
+    if (getenv("RT_NO_CONCAT_FOLD") || getenv("RT_NO_FUSION")) return;
+    for (size_t ci = 0; ci < ops_.size(); ci++) {
+        if (ops_[ci].kind != OpKind::kConcat) continue;
+        const Op cat = ops_[ci];
+        TensorImpl& out = *tensors_[cat.out];
+        if (out.is_input || out.is_output || out.alias_of >= 0 || out.dims.nbDims != 3 || out.il8) continue;
+        const int64_t P = out.pitch ? out.pitch : out.dims.d[2], plane = (int64_t)out.dims.d[1] * P;
+        bool ok = true;
+        for (int i : cat.in) {
+            const TensorImpl& t = *tensors_[i];
+            ok = ok && !t.is_input && !t.is_output && t.alias_of < 0 && t.dims.nbDims == 3 && !t.il8 && t.f16 == out.f16 &&
+                 t.pitch == out.pitch && t.bstride == 0;
+            int producers = 0;
+            for (size_t oi = 0; oi < ops_.size() && ok; oi++) {
+                const Op& op = ops_[oi];
+                if (oi == ci) continue;
+                if (op.out == i) {
+                    producers++;
+                    ok = ok && (op.kind == OpKind::kConv || op.kind == OpKind::kCorrSoftargmax) && op.stream == cat.stream && oi < ci;
+                }
+                if (op.resid == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
+                for (int x : op.in)
+                    if (x == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
+                if (op.kind == OpKind::kConcat)
+                    for (int x : op.in) ok = ok && x != i;               // member of one concatenation only
+            }
+            ok = ok && producers == 1;
+        }
+        // readers of the concatenated tensor must come after the concatenation (they do: it is their producer)
+        if (!ok) continue;
+        int coff = 0;
+        bool failed = false;
+        for (int i : cat.in) {
+            TensorImpl& t = *tensors_[i];
+            t.alias_of = out.id;
+            t.alias_off = (int64_t)coff * plane;
+            t.bstride = (int64_t)out.dims.d[0] * plane;
+            coff += t.dims.d[0];
+            for (auto& op : ops_) {
+                if (op.kind != OpKind::kConv) continue;
+                const int64_t xb = op.in[0] == i ? t.bstride : 0, yb = op.out == i ? t.bstride : 0, rb = op.resid == i ? t.bstride : 0;
+                if ((xb || yb || rb) && rt_conv_plan_set_batch_strides(op.plan, xb, yb, rb) != 0) failed = true;
+            }
+        }
+        if (failed) {
+            log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+            ok_ = false;
+            return;
+        }
+        ops_.erase(ops_.begin() + ci);
+        ci--;
+        log_.log(ILogger::Severity::kINFO, (cat.name + ": concatenation folded into its producers (no copy launch)").c_str());
+    }
+}
+
 // ---- plan (de)serialisation ------------------------------------------------------------------------------------
 // A plan is the recorded sequence of network-building calls (inputs, layers with their parameters and weights,
 // plugin blobs exactly as IPlugin::serialize() wrote them, outputs) plus the builder settings.  Deserialising replays
@@ -1004,13 +1067,14 @@ bool ContextImpl::ensureBuffers(int batch) {
 
 void* ContextImpl::addr(int tensor, int, void** bindings) const {
     int t = tensor;
-    while (eng_.tensors_[t]->alias_of >= 0) t = eng_.tensors_[t]->alias_of;
+    int64_t off = 0;                   // element offset inside the buffer it aliases (folded concatenation)
+    while (eng_.tensors_[t]->alias_of >= 0) { off += eng_.tensors_[t]->alias_off; t = eng_.tensors_[t]->alias_of; }
     const TensorImpl& ti = *eng_.tensors_[t];
     if (ti.is_input || ti.is_output) {
         for (size_t b = 0; b < eng_.bindings_.size(); b++)
-            if (eng_.bindings_[b] == t) return bindings[b];
+            if (eng_.bindings_[b] == t) return static_cast<char*>(bindings[b]) + off * 4;
     }
-    return buffers_[t];
+    return static_cast<char*>(buffers_[t]) + off * (ti.f16 ? 2 : 4);
 }
 
 bool ContextImpl::execute(int batchSize, void** bindings) {
@@ -1102,7 +1166,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
                 rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
                                                 f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
-                                                0, out.f16 ? RT_F16 : RT_F32, st);
+                                                out.bstride, out.f16 ? RT_F16 : RT_F32, st);
                 break;
             }
             case OpKind::kCopy:

@@ -74,6 +74,12 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
     __shared__ __attribute__((aligned(16))) char sX[2][NPIX * PXB];
 
     const int tid = threadIdx.x;
+#ifdef RT_KERNEL_TIMING
+    unsigned long long* dbgp = p.dbg ? p.dbg + (size_t)blockIdx.x * 16 : nullptr;
+    int dbi = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    RT_TSTAMP();                                  // 0: start
     const int lane = tid & 63;
     const int kg = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,10 +166,13 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
     const int act = p.act;
 
     gather(t_begin);
+    RT_TSTAMP();                                  // 1: weights in LDS, first gather issued
     for (int tile = t_begin; tile < t_end; tile++) {
         const int buf = (tile - t_begin) & 1;
         stage(buf);
+        RT_TSTAMP();                              // 2, 6, 10: tile gathered, split and written to LDS
         __syncthreads();       // tile staged; every wave is done with the other buffer (it finished the previous tile)
+        RT_TSTAMP();                              // 3, 7, 11: barrier passed
         if (tile + 1 < t_end) gather(tile + 1);
 
         const int n = tile / per_img, rem = tile - n * per_img;
@@ -211,6 +220,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
             }
         }
 
+        RT_TSTAMP();                              // 4, 8, 12: MFMAs issued
         // ---- epilogue: y = main + cross * 2^-11 + bias + residual, activation, stores --------------------------------------
         // accumulator register 4q + e of a lane = channel 8q + 4kg + e of pixel l31
         const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
@@ -235,7 +245,12 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
         if (act == 1) epilogue(std::integral_constant<int, 1>{});
         else if (act == 2) epilogue(std::integral_constant<int, 2>{});
         else epilogue(std::integral_constant<int, 0>{});
+        RT_TSTAMP();                              // 5, 9, 13: stores issued
     }
+#ifdef RT_KERNEL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    if (dbgp && tid == 0) { dbgp[14] = __builtin_amdgcn_s_memtime(); dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
 }
 
 }  // namespace rt
@@ -284,6 +299,12 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_k
     __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
 
     const int tid = threadIdx.x;
+#ifdef RT_KERNEL_TIMING
+    unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
+    int dbi = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    RT_TSTAMP();                                  // 0: start
     const int lane = tid & 63;
     const int kg = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -423,12 +444,15 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_k
     };
 
     prefetch(0);
+    RT_TSTAMP();                                  // 1: residual + first gathers issued
     for (int ch = 0; ch < nchunks; ch++) {
         if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
         stage_to_lds();
         __syncthreads();
+        RT_TSTAMP();                              // 2, 4: chunk in LDS
         if (ch + 1 < nchunks) prefetch(ch + 1);
         compute();
+        RT_TSTAMP();                              // 3, 5: MFMAs issued
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
@@ -443,6 +467,144 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_k
                 o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
             if constexpr (YIL) {
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
+            } else {
+                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    buf_store(o[e], rs_y, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * cs32) * 4u);
+            }
+        }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
+    RT_TSTAMP();                                  // 2 + 2 * nchunks: stores issued
+#ifdef RT_KERNEL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    if (dbgp && tid == 0) { dbgp[14] = __builtin_amdgcn_s_memtime(); dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
+}
+
+}  // namespace rt
+
+namespace rt {
+
+// -----------------------------------------------------------------------------------------------------------------------
+// conv_s3_first_kernel: the networks' first layer -- 5x5, stride 2, on the 3-channel fp32 image (reference
+// resnet18_2D_513x257_net.cpp:48-63, nvsmall_1025x321_net.cpp:36-51) -- in the row-as-contraction form of
+// conv_f16_first.hip.h on the 3-term split: with 3 input channels a channel-chunked contraction is 81 % padding, so a ROW
+// of the window is the contraction index,  k = 3*s + c  (s = window column, c = channel; 15 values, the 16th has zero
+// weights), contiguous in LDS patches stored [row][col][channel] (one of fp16 high parts, one of scaled low parts).
+// 5 window rows x 3 split terms = 15 MFMAs per 32 pixels x 32 output channels (the fp32 direct form: 50 fp32 MFMAs = 25x
+// the matrix-pipe time); the 10 A operands (hi / lo weights [r][k-half][co][8]) stay in registers, one barrier.
+// Bound by data movement: 11 x 67 x 3 fp32 in, 4 x 32 x 32 fp32 out per tile.
+// -----------------------------------------------------------------------------------------------------------------------
+struct S3FirstCfg {
+    static constexpr int KH = 5, KW = 5, S = 2, TY = 4, TX = 32, CMAX = 3;
+    static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW;      // 11 x 67 input pixels per channel
+    static constexpr int NPAIR = (PC + 1) / 2;                                // column pairs per row: 34 (68 columns)
+    static constexpr int RS = 208;                                            // LDS row stride in halfs >= 68*3 = 204, 16-byte multiple
+    static constexpr int NTASK = CMAX * PR * NPAIR, NK = (NTASK + 255) / 256; // (channel, row, pair) gathers per lane
+    static constexpr int W_SLOTS = KH * 2 * 2 * 32;                           // 16-byte slots per 32-channel block: [r][hi/lo][k-half][co]
+};
+
+template <bool YIL>
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) conv_s3_first_kernel(ConvArgs p) {
+    using Cfg = S3FirstCfg;
+    constexpr int KH = Cfg::KH, S = Cfg::S, TY = Cfg::TY, TX = Cfg::TX, PR = Cfg::PR, NPAIR = Cfg::NPAIR, RS = Cfg::RS;
+
+    __shared__ __attribute__((aligned(16))) _Float16 sHi[PR * RS];
+    __shared__ __attribute__((aligned(16))) _Float16 sLo[PR * RS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile = blockIdx.x;
+    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (tile % p.tiles_x) * TX;
+    const int ty0 = (tile / p.tiles_x) * TY;
+    const int nblk = blockIdx.y;
+    const int n = blockIdx.z;
+
+    // ---- weights: the 10 A operands of this lane (co = l31, k-half = kg), straight from global memory --------------------
+    f32x4 wa[KH][2];
+    {
+        const buf_rsrc rs_w = make_buf(reinterpret_cast<const char*>(p.w) + (int64_t)nblk * Cfg::W_SLOTS * 16);
+#pragma unroll
+        for (int r = 0; r < KH; r++)
+#pragma unroll
+            for (int part = 0; part < 2; part++) wa[r][part] = buf_load4(rs_w, (unsigned)(((r * 2 + part) * 2 + kg) * 32 + l31) * 16u, 0);
+    }
+
+    // ---- gather: fp32 image -> split patches [row][col][channel]; a lane takes a column pair of one channel --------------
+    const buf_rsrc rs_x = make_buf(p.x + (int64_t)n * p.x_bstride);
+    const int ix0 = tx0 * S - p.pad_x, iy0 = ty0 * S - p.pad_y;
+    const int cin = p.cin_real;
+#pragma unroll
+    for (int k = 0; k < Cfg::NK; k++) {
+        const int t = tid + 256 * k;
+        const int c = t / (PR * NPAIR), rem = t - c * (PR * NPAIR);
+        const int pr = rem / NPAIR, pc = 2 * (rem - pr * NPAIR);
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        const bool own = t < Cfg::NTASK && c < cin;
+        const bool row_ok = own && iy >= 0 && iy < p.Hi;
+        // the pair may straddle either edge of a dense row: each element is masked on its own
+        const bool ok0 = row_ok && ix >= 0 && ix < p.Wi, ok1 = row_ok && ix + 1 >= 0 && ix + 1 < p.Wi && pc + 1 < Cfg::PC;
+        const unsigned vo = (unsigned)((c * p.Hi + iy) * p.x_pitch + ix) * 4u;
+        const float v0 = buf_load(rs_x, ok0 ? vo : kBufOOB, 0);
+        const float v1 = buf_load(rs_x, ok1 ? vo + 4u : kBufOOB, 0);
+        if (t < Cfg::NTASK) {                     // channels >= cin are written as zeros
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const int o = pr * RS + pc * Cfg::CMAX + c;
+            sHi[o] = h0;
+            sHi[o + Cfg::CMAX] = h1;
+            sLo[o] = (_Float16)((v0 - (float)h0) * kSplitScale);
+            sLo[o + Cfg::CMAX] = (_Float16)((v1 - (float)h1) * kSplitScale);
+        }
+    }
+    __syncthreads();
+
+    // ---- 5 window rows x 3 MFMAs: B operand = 8 consecutive (column, channel) halfs of patch row 2*wv + r ---------------------
+    f32x16 acc_m, acc_c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+    const unsigned* __restrict__ hi32 = reinterpret_cast<const unsigned*>(sHi);      // 6*x + 8*h halfs is an even offset
+    const unsigned* __restrict__ lo32 = reinterpret_cast<const unsigned*>(sLo);
+#pragma unroll
+    for (int r = 0; r < KH; r++) {
+        const int base = ((wv * S + r) * RS + 6 * l31 + 8 * kg) >> 1;
+        u32x4_t bh, bl;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bh[e] = hi32[base + e]; bl[e] = lo32[base + e]; }
+        const f16x8 ah = __builtin_bit_cast(f16x8, wa[r][0]), al = __builtin_bit_cast(f16x8, wa[r][1]);
+        acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bh), acc_m, 0, 0, 0);
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, bh), acc_c, 0, 0, 0);
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, bl), acc_c, 0, 0, 0);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    const int oy = ty0 + wv, ox = tx0 + l31;
+    const bool inb = oy < p.Ho && ox < p.Wo;
+    const int cs32 = (int)p.y_cstride;
+    const int cb = nblk * 32;
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
+    const int act = p.act;
+    auto epilogue = [&](auto ACT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * q + 4 * kg);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + bv[e], decltype(ACT)::value);
+            if constexpr (YIL) {
+                const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
             } else {
                 const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;

@@ -421,6 +421,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
     int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
     int split3 = 0;                     // conv_s3_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (general form)
+    int s3first = 0;                    // conv_s3_first_kernel: 5x5 stride-2 first layer (<= 3 input channels), split fp16, row-as-contraction
     int s3p = 0;                        // conv_s3p_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe, persistent (3x3 s1, Cin, Cout <= 32)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
@@ -652,9 +653,12 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     if (sc.split3) { sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4; }
 }
 
+// The persistent form is opt-in (RT_S3P=1).  Measured on MI355X, ResNet-18 2D 1257x369 (profiles/README.md, round 2): alone it
+// runs the 32->32 layer in 13.5 us against 14.1 us for the general kernel, but one workgroup per CU holding 135 KB of LDS cannot
+// share a CU with the other stream's / other contexts' launches, so the network is slower with it (1830 vs 2081 pairs/s).
 bool s3p_eligible(const SubConv& sc, int cin) {
     return !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && cin <= 32 && sc.Cout <= 32 && sc.nz == 1 &&
-           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3P", 0) == 0;
+           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_S3P", 0) != 0;
 }
 
 // conv_s3p_kernel's LDS image of the layer's weights: [tap][chunk of 16 ci][hi / lo][k-group of 8][co % 32][8 halfs]
@@ -676,6 +680,35 @@ int upload_s3p(SubConv& sc, int cin_real, F wfun) {
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     sc.s3p = 1; sc.split3 = 0; sc.wino = 0;
     sc.CinPad = 32; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 8;
+    return 0;
+}
+
+// conv_s3_first_kernel: per 32-channel block the 10 A operands [r][hi / lo][k-half][co][8 halfs], k = 3*s + c
+bool s3first_eligible(const SubConv& sc, int cin, int has_resid) {
+    return !sc.direct && sc.KH == 5 && sc.KW == 5 && sc.S == 2 && cin <= 3 && !has_resid && sc.nz == 1 &&
+           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3", 0) == 0;
+}
+template <typename F>
+int upload_s3first(SubConv& sc, int cin_real, F wfun) {
+    const int nblk = (int)rt::cdiv(sc.Cout, 32);
+    std::vector<uint16_t> packed((size_t)nblk * rt::S3FirstCfg::W_SLOTS * 8, 0);
+    for (int co = 0; co < sc.Cout; co++)
+        for (int c = 0; c < cin_real; c++)
+            for (int r = 0; r < 5; r++)
+                for (int sx = 0; sx < 5; sx++) {
+                    uint16_t hi, lo;
+                    split_f16(wfun(co, c, r, sx), hi, lo);
+                    const int k = 3 * sx + c, h = k / 8, e = k % 8;
+                    const size_t blk = (size_t)(co / 32) * rt::S3FirstCfg::W_SLOTS * 8;
+                    packed[blk + ((((size_t)r * 2 + 0) * 2 + h) * 32 + co % 32) * 8 + e] = hi;
+                    packed[blk + ((((size_t)r * 2 + 1) * 2 + h) * 32 + co % 32) * 8 + e] = lo;
+                }
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
+    RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    sc.s3first = 1; sc.s3p = 0; sc.split3 = 0; sc.wino = 0;
+    sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
     return 0;
 }
 
@@ -806,7 +839,8 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     auto wfun = [&](int co, int ci, int u, int v) {
         return w[(((size_t)co * Cin + ci) * KH + u) * KW + v];          // KCRS
     };
-    int rc = s3p_eligible(sc, Cin) ? upload_s3p(sc, Cin, wfun) : upload_packed(sc, Cin, wfun);
+    int rc = s3p_eligible(sc, Cin) ? upload_s3p(sc, Cin, wfun)
+             : s3first_eligible(sc, Cin, d->has_residual) ? upload_s3first(sc, Cin, wfun) : upload_packed(sc, Cin, wfun);
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < Cin; c++) table[c] = c * d->Hin * d->Win;
     if (!rc) rc = upload_table(sc, table);
@@ -1218,6 +1252,22 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
     return 0;
 }
 
+// Per-sample strides (elements; 0 = leave as it is) of the input, output and residual tensor of a plan: lets an executor
+// place a tensor inside a larger buffer (a channel range of a concatenated tensor).  Call after rt_conv_plan_set_pitch,
+// which recomputes the dense strides.
+extern "C" int rt_conv_plan_set_batch_strides(rtConvPlan* plan, int64_t x_bstride, int64_t y_bstride, int64_t r_bstride) {
+    RT_REQUIRE(plan, "rt_conv_plan_set_batch_strides: null plan");
+    RT_REQUIRE(x_bstride >= 0 && y_bstride >= 0 && r_bstride >= 0, "rt_conv_plan_set_batch_strides: negative stride");
+    RT_REQUIRE(x_bstride < (1ll << 29) && y_bstride < (1ll << 29) && r_bstride < (1ll << 29), "rt_conv_plan_set_batch_strides: sample exceeds 2 GB");
+    if (x_bstride) plan->x_bstride = x_bstride;
+    if (y_bstride) {
+        if (!plan->r_bstride) plan->r_bstride = plan->y_bstride;      // the residual keeps its own (so far implied) stride
+        plan->y_bstride = y_bstride;
+    }
+    if (r_bstride) plan->r_bstride = r_bstride;
+    return 0;
+}
+
 namespace {
 // fp16 operand slabs of conv_f16mma_kernel: [nblk][chunk of 16 ci][tap][h][co % 32][8 halfs], ci = chunk*16 + 8*h + e.
 // Appends one slab set (all nblk x chunks) and returns its offset in 16-byte slots.
@@ -1278,7 +1328,7 @@ int repack_f16mma(rtConvPlan* plan) {
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < Cin; c++) table[c] = c * plan->hin * ip;
     if (int rc = upload_table(sc, table)) return rc;
-    sc.wino = 0; sc.s3p = sc.split3 = 0; sc.f16mma = 1;
+    sc.wino = 0; sc.s3p = sc.split3 = sc.s3first = 0; sc.f16mma = 1;
     return 0;
 }
 
@@ -1304,7 +1354,7 @@ int repack_f16first(rtConvPlan* plan) {
     RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
     RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
-    sc.wino = 0; sc.s3p = sc.split3 = 0; sc.f16first = 1;
+    sc.wino = 0; sc.s3p = sc.split3 = sc.s3first = 0; sc.f16first = 1;
     return 0;
 }
 
@@ -1316,7 +1366,7 @@ int repack_f32(rtConvPlan* plan) {
     const rtConv2dDesc& d = plan->desc2d;
     const std::vector<float>& w = plan->w_canon;
     const int Cin = d.Cin, Cout = d.Cout;
-    sc.f16mma = sc.f16first = sc.s3p = sc.split3 = 0;
+    sc.f16mma = sc.f16first = sc.s3p = sc.split3 = sc.s3first = 0;
     sc.x_f16 = sc.y_f16 = 0;
     sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
     choose_tiling(sc, !plan->is_deconv);
@@ -1325,6 +1375,8 @@ int repack_f32(rtConvPlan* plan) {
     std::vector<float> packed;
     if (!plan->is_deconv && s3p_eligible(sc, Cin)) {
         if (int rc = upload_s3p(sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; })) return rc;
+    } else if (!plan->is_deconv && s3first_eligible(sc, Cin, plan->has_resid)) {
+        if (int rc = upload_s3first(sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; })) return rc;
     } else if (!plan->is_deconv) {
         pack_into(packed, sc, Cin, [&](int co, int ci, int u, int v) { return w[(((size_t)co * Cin + ci) * d.KH + u) * d.KW + v]; });
     } else {
@@ -1343,7 +1395,7 @@ int repack_f32(rtConvPlan* plan) {
         if (!sc.zs_host.empty())
             RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
     }
-    if (!sc.s3p) {
+    if (!sc.s3p && !sc.s3first) {
         if (sc.w_dev) (void)hipFree(sc.w_dev);
         sc.w_dev = nullptr;
         if (int rc = upload_weights(sc, packed)) return rc;
@@ -1400,7 +1452,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
-        if (sc.s3p || sc.split3) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
+        if (sc.s3p || sc.split3 || sc.s3first) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1421,6 +1473,7 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0 || sc.zs_dev || sc.y_xstride != 1 || sc.small3d || sc.direct) return 0;
     if (sc.s3p) return (plan->cin % 4 == 0 ? 1 : 0) | (sc.Cout % 4 == 0 ? 6 : 0);
+    if (sc.s3first) return sc.Cout % 4 == 0 ? 2 : 0;           // output only (its input is the image binding)
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
     if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
     if (sc.x_f16 || sc.y_f16) return 0;
@@ -1552,6 +1605,12 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.s3first) {
+            if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_first_kernel<true>), grid, dim3(256), 0, S(s), a);
+            else hipLaunchKernelGGL((rt::conv_s3_first_kernel<false>), grid, dim3(256), 0, S(s), a);
+            RT_LAUNCH_CHECK("conv_s3_first_kernel");
+            continue;
+        }
         if (sc.split3) {
             if (env_int("RT_CONV_TRACE", 0))
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);

@@ -64,6 +64,7 @@ CASES = [
 def test_split_conv2d(backend, monkeypatch, cin, cout, h, w, act, resid, batch, pitch, il, grid):
     """grid = 3: three workgroups walk all tiles (persistent loop, double-buffered patch, prefetch across tiles and
     images); grid = 0: the default one-workgroup-per-CU launch"""
+    monkeypatch.setenv("RT_S3P", "1")
     if grid:
         monkeypatch.setenv("RT_S3P_GRID", str(grid))
     x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
@@ -128,7 +129,6 @@ G_CASES = [
 
 @pytest.mark.parametrize("cin,cout,h,w,k,stride,tr,act,resid,batch,il", G_CASES)
 def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act, resid, batch, il):
-    monkeypatch.setenv("RT_NO_S3P", "1")
     x, b = rnd(batch, cin, h, w), rnd(cout)
     wt = rnd(*((cin, cout, k, k) if tr else (cout, cin, k, k))) * np.float32(1 / np.sqrt(cin * k * k / (stride * stride if tr else 1)))
     shape = ref64_g(x, wt, b, None, capi.RT_ACT_NONE, stride, tr).shape
@@ -156,3 +156,37 @@ def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act
         outs.append(out[..., :wo])
     assert np.abs(outs[0] - ref).max() <= 5e-6, np.abs(outs[0] - ref).max()
     assert np.array_equal(outs[0], outs[1])                       # layouts change addressing only
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch,pitch,y_il", [
+    (3, 32, 21, 77, 2, 64, 1),        # ResNet-18 2D / NVSmall first layer
+    (3, 32, 9, 129, 1, 96, 0),
+    (3, 8, 13, 41, 2, 0, 1),          # NVTiny: 8 feature channels
+    (1, 32, 5, 7, 1, 0, 0),           # grey image, smaller than a tile
+    (3, 40, 8, 66, 1, 32, 1),         # two 32-channel blocks, even sizes
+])
+def test_split_first_layer(backend, cin, cout, h, w, batch, pitch, y_il):
+    """conv_s3_first_kernel: 5x5 stride 2 on <= 3 channels, window row = contraction index, against fp64"""
+    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 5, 5) * np.float32(1 / np.sqrt(cin * 25)), rnd(cout)
+    ref = O.elu(O.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), 2, 2)).numpy()
+    ho, wo = ref.shape[-2:]
+    P = (wo + pitch - 1) // pitch * pitch if pitch else wo
+    outs = []
+    for il in ((0, 1) if y_il else (0,)):
+        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, 5, 2, 2, act=capi.RT_ACT_ELU)
+        if pitch:
+            plan.set_pitch(0, P)
+        assert plan.il_caps() == (2 if cout % 4 == 0 else 0)
+        if il:
+            plan.set_layouts(0, 1)
+        y = backend.empty((batch, cout // 4, ho, P, 4) if il else (batch, cout, ho, P))
+        plan.enqueue(backend.dev(x), y, None, batch)
+        out = backend.host(y).copy()
+        out = from_il(out) if il else out
+        plan.destroy()
+        if P > wo:
+            assert np.isnan(out[..., wo:]).all(), "padding columns were written"
+        outs.append(out[..., :wo])
+    assert np.abs(outs[0] - ref).max() <= 3e-6, np.abs(outs[0] - ref).max()
+    if y_il:
+        assert np.array_equal(outs[0], outs[1])

@@ -15,7 +15,6 @@ from test_ops_parity import T, near, rnd
 def _winograd_only(monkeypatch):
     """these tests are about the fp32 Winograd / direct-form kernels: keep small layers off the split-fp16 kernel
     (tests/test_split_parity.py covers that one)"""
-    monkeypatch.setenv("RT_NO_S3P", "1")
     monkeypatch.setenv("RT_NO_S3", "1")
 
 

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 CONFIGS = [
     ("default", {}),
     ("single stream", {"RT_SINGLE_STREAM": "1"}),
-    ("no persistent split kernel", {"RT_NO_S3P": "1"}),
+    ("persistent split kernel for the 32->32 layers", {"RT_S3P": "1"}),
     ("no split kernels (round-1 fp32 kernels)", {"RT_CONV_EXACT_FP32": "1"}),
     ("no split kernels, single stream", {"RT_CONV_EXACT_FP32": "1", "RT_SINGLE_STREAM": "1"}),
     ("planar tensors", {"RT_NO_IL8": "1"}),

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-phase timing of the split-fp16 kernels on the 3x3 32->32 @185x629 layer (s_memtime stamps of thread 0 of every
+workgroup; instrumented library from redtail_amd.build.build_hip_timing).  RT_S3P=1 selects the persistent kernel
+instead of the general one (one workgroup per 4x32 tile)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redtail_amd import build, capi  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+general = os.environ.get("RT_S3P", "0") == "0"
+k = capi.KernelLib.__new__(capi.KernelLib)
+k.path = os.environ.get("RT_TIMING_LIB", os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so"))
+k.lib = ctypes.CDLL(k.path)
+for name, (res, args) in capi.KERNEL_SYMBOLS.items():
+    fn = getattr(k.lib, name)
+    fn.restype, fn.argtypes = res, args
+h, w = 185, 629
+wt = (np.random.randn(32 * 32 * 9).astype(np.float32) / np.sqrt(288))
+plan = k.conv2d_plan(wt, np.random.randn(32).astype(np.float32), 32, 32, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+plan.set_pitch(640, 640)
+plan.set_layouts(1, 1, 1)
+x = torch.randn(b, 32, h, 640, device="cuda")
+y, r = torch.empty_like(x), torch.randn_like(x)
+nwg = 47 * 20 * b if general else 256
+dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
+for _ in range(3):
+    plan.enqueue(x, y, r, b)
+torch.cuda.synchronize()
+os.environ["RT_DBG_PTR"] = str(dbg.data_ptr())
+plan.enqueue(x, y, r, b)
+torch.cuda.synchronize()
+t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
+t = t[t[:, 0] > 0]
+if general:
+    names = ["start", "loads issued", "c0 in LDS", "c0 MFMAs issued", "c1 in LDS", "c1 MFMAs issued", "stores issued"]
+    last = 6
+else:
+    names = ["start", "weights+gather0 issued", "t0 staged", "t0 barrier", "t0 MFMAs issued", "t0 stores issued",
+             "t1 staged", "t1 barrier", "t1 MFMAs issued", "t1 stores issued"]
+    t = t[t[:, 9] > 0]           # workgroups with (at least) two tiles
+    last = 9
+d = np.diff(t[:, :last + 1], axis=1)
+print("%s kernel, batch %d: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % ("general" if general else "persistent", b, len(t)))
+for i in range(last):
+    print("  %-24s -> %-24s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+print("  last stamp -> all stores acknowledged %9.1f" % (t[:, 14] - t[:, last]).mean())
+life = t[:, 14] - t[:, 0]
+print("  workgroup lifetime mean %.1f cycles; shader clock %.0f MHz" % (life.mean(), life.sum() / t[:, 15].sum() * 100.0))
+print("  kernel span (first start .. last end) %.1f cycles; starts p50 %.1f p90 %.1f max %.1f after the first; ends p10 %.1f p50 %.1f p90 %.1f" % (
+    t[:, 14].max() - t[:, 0].min(), *(np.percentile(t[:, 0] - t[:, 0].min(), q) for q in (50, 90, 100)),
+    *(np.percentile(t[:, 14] - t[:, 0].min(), q) for q in (10, 50, 90))))
