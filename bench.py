@@ -65,7 +65,12 @@ def load_weights(half2):
 
 
 def dominant(name):
-    return "resblock" in name or name.endswith("encoder2D_out")
+    return "resblock" in name
+
+
+# a fused residual block (conv_s3rb_kernel): two of the 3x3 convolutions, x read once (with its halo), y written once
+BLOCK_FLOPS = 2.0 * DOMINANT_FLOPS
+BLOCK_BYTES = 4.0 * (2 * 32 * HALF_W * HALF_H + 2 * (32 * 32 * 9 + 32))
 
 
 def measured_traffic(half2=False):
@@ -111,14 +116,18 @@ def cpu_baseline(weights, budget_s=12.0):
                 sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
 
 
-def isolated_dominant(k, b, half2, launches=50):
+def isolated_dominant(k, b, half2, launches=50, fused=False):
     """The dominant layer (3x3 32->32 @629x185 + bias + residual + ELU, the executor's tensor layouts) launched
     back-to-back on one idle stream: microseconds per launch between two HIP events.  Reported next to the in-situ
     figure (`avg_launch_us`: event pairs inside the running network, other streams' kernels in flight)."""
     import ctypes
     rng = np.random.default_rng(1)
     wt = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288)).astype(np.float32)
-    plan = k.conv2d_plan(wt, rng.standard_normal(32).astype(np.float32), 32, 32, HALF_H, HALF_W, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+    if fused:
+        plan = k.resblock_plan(wt, rng.standard_normal(32).astype(np.float32), wt[::-1].copy(), rng.standard_normal(32).astype(np.float32),
+                               32, 32, HALF_H, HALF_W)
+    else:
+        plan = k.conv2d_plan(wt, rng.standard_normal(32).astype(np.float32), 32, 32, HALF_H, HALF_W, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
     plan.set_pitch(640, 640)
     if half2:
         plan.set_io_types(capi.RT_F16, capi.RT_F16)
@@ -126,7 +135,7 @@ def isolated_dominant(k, b, half2, launches=50):
         plan.set_layouts(1, 1, 1)
     dt = torch.float16 if half2 else torch.float32
     x = torch.randn(b, 32, HALF_H, 640, device="cuda").to(dt)
-    r, y = torch.randn_like(x), torch.empty_like(x)
+    r, y = (x if fused else torch.randn_like(x)), torch.empty_like(x)
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
     for _ in range(5):
@@ -368,7 +377,9 @@ def main():
         step_s = elapsed / args.steps
         traffic, traffic_src = measured_traffic(args.half2) if b == 1 else (None, None)
         exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
-        iso_us = isolated_dominant(lib.kernels, b, args.half2)
+        fused = launches == 16                                  # residual blocks run as one launch each (conv_s3rb_kernel)
+        iso_us = isolated_dominant(lib.kernels, b, args.half2, fused=fused)
+        flops = BLOCK_FLOPS if fused else DOMINANT_FLOPS
         if args.half2:
             # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the layer HBM-bound, so it is priced in
             # bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
@@ -383,12 +394,14 @@ def main():
             # fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (conv_split.hip.h): 3 x the direct-form multiplies at
             # 16 x the fp32 rate -- 1/5 of the fp32 matrix time -- which leaves the layer bound by its fp32 traffic:
             # x + residual + y (+ weights, bias), every byte once
-            nbytes = DOMINANT_BYTES
-            kernel = "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate"
-            mfma_exec = 3.0 * DOMINANT_FLOPS
+            nbytes = BLOCK_BYTES if fused else DOMINANT_BYTES
+            kernel = ("conv_s3rb_kernel<il,il>: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
+                      "intermediate in LDS; fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate" if fused else
+                      "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate")
+            mfma_exec = 3.0 * flops * ((11.0 / 8.0 + 1.0) / 2.0 if fused else 1.0)     # conv1 is recomputed on the 10 x 34 halo region: 11 / 8
         if exact and not args.half2:
-            achieved, peak, unit, bound = DOMINANT_FLOPS * b / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
-            iso_frac = DOMINANT_FLOPS * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
+            achieved, peak, unit, bound = flops * b / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            iso_frac = flops * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
         else:
             achieved, peak, unit, bound = nbytes * b / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
             iso_frac = nbytes * b / iso_us / 1e3 / HBM_PEAK_GBS
@@ -400,7 +413,7 @@ def main():
                                   "and frac_step as throughput statements" % (launches, avg_s * 1e6, ">" if overlapped else "<=", step_s * 1e6, nctx)),
                     "overlapped": bool(overlapped), "traffic": traffic,
                     "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
-                    "algorithmic_bytes": nbytes * b, "flops_per_launch": DOMINANT_FLOPS * b,
+                    "algorithmic_bytes": nbytes * b, "flops_per_launch": flops * b,
                     "avg_launch_us": avg_s * 1e6, "launches_per_step": launches,
                     "isolated_launch_us": iso_us, "frac_isolated": iso_frac,
                     # whole step against the roofs: direct-form FLOPs of the network / fp32 matrix peak, and the minimum

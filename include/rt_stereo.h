@@ -157,6 +157,14 @@ int rt_conv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const voi
 int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const void* weights_host,
                             const void* bias_host);
 
+/* Fused residual block  y = act2(conv3x3(act1(conv3x3(x) + b1)) + b2 + x): the unit of the ResNet-18 feature towers
+ * (reference resnet18_2D_513x257_net.cpp:66-575: resblockN_conv1, ELU plugin, resblockN_conv2, addElementWise(kSUM),
+ * ELU plugin).  d1 / d2 describe the two addConvolution layers as rt_conv2d_plan_create would take them (d2->has_residual
+ * = 1); RT_E_UNSUPPORTED unless both are 3x3, stride 1, pad 1, with <= 32 channels and equal input / output channel
+ * counts.  Enqueue with residual = x (or NULL). */
+int rt_resblock_plan_create(rtConvPlan** plan, const rtConv2dDesc* d1, const void* w1, const void* b1,
+                            const rtConv2dDesc* d2, const void* w2, const void* b2);
+
 /* Row pitch (in elements, >= the row length; 0 = dense) of the input and of the output/residual planes of a 2-D
  * plan.  Not in the reference (TensorRT owns its internal layouts): lets the executor keep internal activations
  * 128-byte aligned per row.  Tensors are then (N, C, H, pitch) in memory with W valid columns. */

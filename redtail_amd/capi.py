@@ -67,6 +67,8 @@ KERNEL_SYMBOLS = {
     "rt_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "rt_conv2d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv2dDesc), c_void_p, c_void_p]),
     "rt_deconv2d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv2dDesc), c_void_p, c_void_p]),
+    "rt_resblock_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv2dDesc), c_void_p, c_void_p, POINTER(Conv2dDesc), c_void_p,
+                                        c_void_p]),
     "rt_conv3d_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), c_void_p, c_void_p]),
     "rt_conv3d_transpose_plan_create": (c_int, [POINTER(c_void_p), POINTER(Conv3dDesc), POINTER(c_int), c_void_p,
                                                 c_void_p]),
@@ -182,6 +184,15 @@ class KernelLib:
         plan = c_void_p()
         fn = self.lib.rt_deconv2d_plan_create if transposed else self.lib.rt_conv2d_plan_create
         self.check(fn(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host)), "conv2d plan")
+        return ConvPlan(self, plan)
+
+    def resblock_plan(self, w1, b1, w2, b2, C, Cmid, H, W, act1=RT_ACT_ELU, act2=RT_ACT_ELU, dtype=RT_F32):
+        """fused residual block y = act2(conv3x3(act1(conv3x3(x) + b1)) + b2 + x)"""
+        d1 = Conv2dDesc(C, Cmid, H, W, 3, 3, 1, 1, 1, act1, 0, dtype)
+        d2 = Conv2dDesc(Cmid, C, H, W, 3, 3, 1, 1, 1, act2, 1, dtype)
+        plan = c_void_p()
+        self.check(self.lib.rt_resblock_plan_create(ctypes.byref(plan), ctypes.byref(d1), _ptr(w1), _ptr(b1), ctypes.byref(d2),
+                                                    _ptr(w2), _ptr(b2)), "resblock plan")
         return ConvPlan(self, plan)
 
     def conv3d_plan(self, w_host, b_host, C, K, dims, kernel, stride, pad_start, pad_end, act=0, out_dchw=False,

@@ -304,6 +304,7 @@ struct Op {
     int resid = -1;
     int act = RT_ACT_NONE;
     rtConvPlan* plan = nullptr;        // kConv
+    const struct LayerData* conv_layer = nullptr;   // kConv: the (de)convolution layer the plan was made from
     IPlugin* plugin = nullptr;         // kPlugin / kConv3D
     IStereoPlugin* splugin = nullptr;  // kConv3D
     int max_disp = 0, is_min = 0;      // kCorrSoftargmax
@@ -419,6 +420,7 @@ private:
     void assignStreams();
     void assignPitch();
     void foldConcats();
+    void fuseResBlocks();
     bool ok_ = false;
     bool half2_ = false;
 public:
@@ -458,6 +460,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
         workspace_bytes_ = std::max(workspace_bytes_, l->plugin->getWorkspaceSize(max_batch_));
     }
     ok_ = lower();
+    if (ok_) fuseResBlocks();
     if (ok_) assignPitch();
     if (ok_) assignStreams();
     if (ok_) foldConcats();
@@ -569,6 +572,7 @@ bool EngineImpl::lower() {
                                 : rt_conv2d_plan_create(&op.plan, &d, l->kernel.values, l->bias.count ? l->bias.values : nullptr);
                 if (rc) return fail(l->name + ": " + rt_last_error_string());
                 op.kind = OpKind::kConv;
+                op.conv_layer = l;
                 op.resid = resid;
                 op.act = act;
                 op.out = cur->id;
@@ -854,6 +858,61 @@ void EngineImpl::assignStreams() {
     for (auto& op : ops_)
         for (auto& o2 : ops_)
             for (int w : o2.wait_on) op.publish |= (w == root(op.out));
+}
+
+// Residual blocks in one launch: conv3x3 (+ELU) -> conv3x3 + skip (+ELU) with the skip connection being the block's input
+// (reference resnet18_2D_513x257_net.cpp:66-575, 8 blocks per feature tower) become one rt_resblock_plan: the intermediate
+// tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  Not in half2 mode, where the two layers run on fp16
+// operands with fp16 tensors in between.
+void EngineImpl::fuseResBlocks() {
+    if (getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (half2_ && !getenv("RT_NO_F16"))) return;
+    int fused = 0;
+    for (size_t ia = 0; ia < ops_.size(); ia++) {
+        Op& a = ops_[ia];
+        if (a.kind != OpKind::kConv || !a.conv_layer || a.conv_layer->type != LayerType::kCONVOLUTION || a.resid >= 0) continue;
+        if (tensors_[a.out]->is_output) continue;
+        // the one consumer of the intermediate
+        int ib = -1, uses = 0;
+        for (size_t j = 0; j < ops_.size(); j++) {
+            if (j == ia) continue;
+            for (int x : ops_[j].in)
+                if (root(x) == root(a.out)) { uses++; ib = (int)j; }
+            if (ops_[j].resid >= 0 && root(ops_[j].resid) == root(a.out)) uses += 2;
+        }
+        if (uses != 1 || ib < (int)ia) continue;
+        Op& b = ops_[ib];
+        if (b.kind != OpKind::kConv || !b.conv_layer || b.conv_layer->type != LayerType::kCONVOLUTION || b.in.size() != 1 ||
+            root(b.in[0]) != root(a.out) || b.resid < 0 || root(b.resid) != root(a.in[0]))
+            continue;
+        auto desc = [&](const Op& op, bool resid) {
+            const LayerData* l = op.conv_layer;
+            const Dims& x = l->in[0]->dims;
+            rtConv2dDesc d{};
+            d.Cin = x.d[0]; d.Cout = l->nb_maps; d.Hin = x.d[1]; d.Win = x.d[2];
+            d.KH = l->ksize.h(); d.KW = l->ksize.w(); d.stride = l->stride.h();
+            d.pad_h = l->padding.h(); d.pad_w = l->padding.w();
+            d.act = op.act; d.has_residual = resid;
+            d.dtype = l->kernel.type == DataType::kHALF ? RT_F16 : RT_F32;
+            return d;
+        };
+        const rtConv2dDesc d1 = desc(a, false), d2 = desc(b, true);
+        const LayerData *la = a.conv_layer, *lb = b.conv_layer;
+        rtConvPlan* rb = nullptr;
+        if (rt_resblock_plan_create(&rb, &d1, la->kernel.values, la->bias.count ? la->bias.values : nullptr, &d2, lb->kernel.values,
+                                    lb->bias.count ? lb->bias.values : nullptr) != 0)
+            continue;                                   // not of that form: the two launches stay
+        rt_conv_plan_destroy(a.plan);
+        rt_conv_plan_destroy(b.plan);
+        a.plan = rb;
+        a.out = b.out;
+        a.resid = b.resid;
+        a.act = b.act;
+        ops_.erase(ops_.begin() + ib);
+        fused++;
+    }
+    if (fused)
+        log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(fused) + " residual blocks fused into one launch each; " +
+                                            std::to_string(ops_.size()) + " launches").c_str());
 }
 
 // Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the

@@ -620,3 +620,222 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) conv_s3_first_kernel(C
 }
 
 }  // namespace rt
+
+namespace rt {
+
+// -----------------------------------------------------------------------------------------------------------------------
+// conv_s3rb_kernel: a whole residual block in one launch,
+//       y = act2( conv3x3( act1( conv3x3(x) + b1 ) ) + b2 + x )          (Cin = Cmid = Cout <= 32, stride 1)
+// the unit the feature towers of ResNet-18 2D / ResNet-18 3D are made of (reference resnet18_2D_513x257_net.cpp:66-575:
+// resblockN_conv1 -> ELU -> resblockN_conv2 -> add -> ELU, 8 blocks per side = 32 of the network's 49 convolutions).
+// Layer by layer the block moves x, t, t, x, y through HBM (5 tensor passes + the weights once per tile and layer); fused,
+// the intermediate t lives in LDS and the block moves x and y (+ the halo): 2.3 passes.  Per workgroup (8 waves) and
+// 8-row x 32-pixel output tile:
+//   1. gather the 12 x 36 input region (fp32, planar or channel-interleaved), split it into fp16 hi / lo, LDS image sX
+//      (144 B per pixel as in conv_s3p_kernel); conv1's split weights go to LDS, conv2's are requested into registers
+//   2. conv1 on the 10 x 34 region conv2 needs (340 pixels = 11 MFMA column blocks of 32, spread over the 8 waves): 54
+//      MFMAs per block; epilogue = bias, activation, ZERO outside the image (conv2's padding), split, LDS image sT
+//   3. conv2's weights replace conv1's in LDS
+//   4. conv2 on the 8 x 32 tile out of sT (one row per wave); the residual (the fp32 x values, L2-hot) is requested before
+//      the MFMAs and added in the epilogue
+// The recomputed halo costs 11/8 of conv1's multiplies; the matrix pipe has that slack, HBM does not.
+// -----------------------------------------------------------------------------------------------------------------------
+struct S3RBCfg {
+    static constexpr int NW = 8, TY = 8, TX = 32, NT = 512;
+    static constexpr int XR = TY + 4, XC = TX + 4, XPIX = XR * XC;          // input region 12 x 36
+    static constexpr int TR = TY + 2, TC = TX + 2, TPIX = TR * TC;          // conv1 output region 10 x 34
+    static constexpr int TSEG = (TPIX + 31) / 32;                            // 11 column blocks of 32 pixels
+    static constexpr int PXB = 144;
+    static constexpr int NSLOT = XPIX * 8, NKX = (NSLOT + NT - 1) / NT;      // (pixel, 4-channel group) gather slots per thread
+    static constexpr int W_SLOTS = 9 * 2 * 2 * 2 * 32, NK_W = (W_SLOTS + NT - 1) / NT;
+    static constexpr int SEG_PER_WAVE = (TSEG + NW - 1) / NW;                // 2
+};
+
+struct RBArgs {
+    ConvArgs c;            // geometry, x / y / resid pointers and strides, bias = conv2's, w = conv2's split weights, act = act2
+    const float* w1;       // conv1's split weights (same LDS image layout)
+    const float* bias1;    // padded to 64
+    int act1;
+    int cmid;              // channels of the intermediate (conv1's outputs = conv2's inputs)
+};
+
+template <bool XIL, bool YIL>
+__global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArgs a) {
+    using Cfg = S3RBCfg;
+    const ConvArgs& p = a.c;
+    constexpr int TY = Cfg::TY, TX = Cfg::TX, XC = Cfg::XC, TC = Cfg::TC, PXB = Cfg::PXB, NT = Cfg::NT;
+    constexpr int NKX = Cfg::NKX, NK_W = Cfg::NK_W;
+
+    __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
+    __shared__ __attribute__((aligned(16))) char sX[Cfg::XPIX * PXB];
+    __shared__ __attribute__((aligned(16))) char sT[Cfg::TSEG * 32 * PXB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile = blockIdx.x;
+    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (tile % p.tiles_x) * TX;
+    const int ty0 = (tile / p.tiles_x) * TY;
+    const int n = blockIdx.z;
+    const int H = p.Hi, W = p.Wi;                  // stride 1, same padding: input, intermediate and output grids coincide
+
+    // ---- conv1's weights -> LDS, conv2's -> registers (they replace conv1's in LDS after phase 2) -----------------------
+    f32x4 rw2[NK_W];
+    {
+        const buf_rsrc rs_w1 = make_buf(a.w1), rs_w2 = make_buf(p.w);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            const unsigned vo = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
+            const f32x4 w1 = buf_load4(rs_w1, vo, 0u);
+            rw2[k] = buf_load4(rs_w2, vo, 0u);
+            if (idx < Cfg::W_SLOTS) sW[idx] = w1;
+        }
+    }
+
+    // ---- phase 1: gather + split the 12 x 36 input region ------------------------------------------------------------------
+    {
+        const buf_rsrc rs = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
+        const unsigned cs_x = (unsigned)p.x_cstride;
+        f32x4 rin[NKX];
+        int lds[NKX];
+#pragma unroll
+        for (int k = 0; k < NKX; k++) {
+            const int idx = tid + NT * k;
+            const int g = idx / Cfg::XPIX, pix = idx - g * Cfg::XPIX;
+            const int pr = pix / XC, pc = pix - pr * XC;
+            const int iy = ty0 - 2 + pr, ix = tx0 - 2 + pc;
+            const bool in = idx < Cfg::NSLOT && 4 * g < p.cin_real && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            lds[k] = idx < Cfg::NSLOT ? pix * PXB + g * 8 : -1;
+            if constexpr (XIL) {
+                rin[k] = buf_load4(rs, in ? (unsigned)(4 * g) * cs_x * 4u + (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB, 0u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    rin[k][j] = buf_load(rs, (in && 4 * g + j < p.cin_real) ? (unsigned)(4 * g + j) * cs_x * 4u + (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB, 0u);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NKX; k++) {
+            if (lds[k] < 0) continue;
+            const S3Split s = s3_split(rin[k]);
+            *reinterpret_cast<f16x4*>(sX + lds[k]) = s.hi;
+            *reinterpret_cast<f16x4*>(sX + lds[k] + 64) = s.lo;
+        }
+    }
+    __syncthreads();
+
+    const int a_off = kg * 32 + l31;
+    auto contract = [&](const char* bp0, int row_pitch, f32x16& acc_m, f32x16& acc_c) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, s = t % 3;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const char* bp = bp0 + (r * row_pitch + s) * PXB + c * 32;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 64);
+                const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 0) * 64]);
+                const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 1) * 64]);
+                acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- phase 2: conv1 on the 10 x 34 region, column blocks wv, wv + 8 ---------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < Cfg::SEG_PER_WAVE; i++) {
+        const int seg = wv + Cfg::NW * i;
+        if (seg >= Cfg::TSEG) break;                               // wave-uniform
+        const int pt = seg * 32 + l31;                             // pixel of the intermediate region (row-major, 34 wide)
+        const int tr = pt / TC, tc = pt - tr * TC;
+        f32x16 acc_m, acc_c;
+        // taps (r, s) of intermediate pixel (tr, tc) read input-region pixels (tr + r, tc + s); blocks past the region read
+        // whatever follows sX (their columns are dropped below)
+        contract(sX + (tr * XC + tc) * PXB + kg * 16, XC, acc_m, acc_c);
+        const int gy = ty0 - 1 + tr, gx = tx0 - 1 + tc;
+        const bool inside = pt < Cfg::TPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (pt < Cfg::TPIX) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias1 + 8 * q + 4 * kg);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + bv[e], a.act1);
+                    o[e] = (inside && 8 * q + 4 * kg + e < a.cmid) ? v : 0.f;       // conv2 pads the intermediate with zeros
+                }
+                const S3Split s = s3_split(o);
+                *reinterpret_cast<f16x4*>(sT + pt * PXB + (8 * q + 4 * kg) * 2) = s.hi;
+                *reinterpret_cast<f16x4*>(sT + pt * PXB + (8 * q + 4 * kg) * 2 + 64) = s.lo;
+            }
+        }
+    }
+    __syncthreads();               // intermediate complete; nobody reads conv1's weights any more
+#pragma unroll
+    for (int k = 0; k < NK_W; k++) {
+        const int idx = tid + NT * k;
+        if (idx < Cfg::W_SLOTS) sW[idx] = rw2[k];
+    }
+
+    // ---- phase 3: residual request, conv2 on the 8 x 32 tile (row wv), epilogue ----------------------------------------------
+    const int oy = ty0 + wv, ox = tx0 + l31;
+    const bool inb = oy < p.Ho && ox < p.Wo;
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
+    f32x4 rr[4];
+    {
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.r_bstride, 4), p.resid != nullptr);
+        if (p.r_il8) {
+            const unsigned vo = inb ? (unsigned)((oy * p.x_pitch + ox) * 4 + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rs_r, (8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)(8 * q * rs32) * 4u);
+        } else {
+            const unsigned vo = inb ? (unsigned)(oy * p.x_pitch + ox + 4 * kg * rs32) * 4u : kBufOOB;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    rr[q][e] = buf_load(rs_r, (8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((8 * q + e) * rs32) * 4u);
+        }
+    }
+    __syncthreads();               // conv2's weights are in LDS
+    f32x16 acc_m, acc_c;
+    contract(sT + (wv * TC + l31) * PXB + kg * 16, TC, acc_m, acc_c);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
+    const int act = p.act;
+    auto epilogue = [&](auto ACT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 8 * q + 4 * kg);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
+            if constexpr (YIL) {
+                const unsigned vo = (inb && 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)(8 * q * cs32) * 4u, 0);
+            } else {
+                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    buf_store(o[e], rs_y, (8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((8 * q + e) * cs32) * 4u);
+            }
+        }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 2) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+}  // namespace rt

@@ -421,6 +421,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
     int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
     int split3 = 0;                     // conv_s3_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (general form)
+    int rb = 0;                         // conv_s3rb_kernel: fused residual block (two 3x3 convolutions), rtConvPlan::rb_*
     int s3first = 0;                    // conv_s3_first_kernel: 5x5 stride-2 first layer (<= 3 input channels), split fp16, row-as-contraction
     int s3p = 0;                        // conv_s3p_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe, persistent (3x3 s1, Cin, Cout <= 32)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
@@ -442,6 +443,10 @@ struct rtConvPlan {
     rtConv2dDesc desc2d{};                        // ... and the descriptor they came with
     int is_deconv = 0;
     int in_pitch = 0, out_pitch = 0;
+    // fused residual block (rt_resblock_plan_create): the first convolution's split weights, bias, activation
+    float* rb_w1_dev = nullptr;
+    float* rb_bias1_dev = nullptr;
+    int rb_act1 = 0, rb_cmid = 0;
 };
 
 namespace {
@@ -799,6 +804,8 @@ void free_plan(rtConvPlan* p) {
         if (s.zs_dev) (void)hipFree(s.zs_dev);
     }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
+    if (p->rb_w1_dev) (void)hipFree(p->rb_w1_dev);
+    if (p->rb_bias1_dev) (void)hipFree(p->rb_bias1_dev);
     delete p;
 }
 
@@ -848,6 +855,62 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, d->Cout, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, d->Cout);
+    }
+    if (rc) { free_plan(plan); return rc; }
+    *out = plan;
+    return 0;
+}
+
+// Fused residual block  y = act2(conv3x3(act1(conv3x3(x) + b1)) + b2 + x)  (conv_s3rb_kernel).  d1 / d2 describe the two
+// convolutions as they would be planned on their own (d2->has_residual = 1, the residual being the block's input);
+// RT_E_UNSUPPORTED when the pair is not of that form -- the caller then plans the layers separately.
+extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1, const void* w1, const void* b1,
+                                       const rtConv2dDesc* d2, const void* w2, const void* b2) {
+    RT_REQUIRE(out && d1 && d2 && w1 && w2, "rt_resblock_plan_create: null pointer");
+    const bool form = d1->KH == 3 && d1->KW == 3 && d2->KH == 3 && d2->KW == 3 && d1->stride == 1 && d2->stride == 1 &&
+                      d1->pad_h == 1 && d1->pad_w == 1 && d2->pad_h == 1 && d2->pad_w == 1 && !d1->has_residual && d2->has_residual &&
+                      d1->Cout == d2->Cin && d2->Cout == d1->Cin && d1->Hin == d2->Hin && d1->Win == d2->Win &&
+                      d1->Cin <= 32 && d1->Cout <= 32 && d1->Cin > 2 && d1->Hin > 0 && d1->Win > 0;
+    if (!form || env_int("RT_CONV_EXACT_FP32", 0) != 0 || env_int("RT_NO_RB", 0) != 0)
+        return fail(RT_E_UNSUPPORTED, "rt_resblock_plan_create: not a 3x3 / 3x3 stride-1 residual block with <= 32 channels");
+    RT_REQUIRE((d1->dtype == RT_F32 || d1->dtype == RT_F16) && d1->dtype == d2->dtype, "rt_resblock_plan_create: bad dtype");
+    RT_REQUIRE((int64_t)d1->Cin * d1->Hin * d1->Win < (1ll << 29), "rt_resblock_plan_create: input sample exceeds 2 GB");
+    auto plan = new rtConvPlan();
+    plan->act = d2->act; plan->has_resid = 1; plan->dtype = RT_F32;
+    plan->out_dims[0] = d2->Cout; plan->out_dims[1] = d1->Hin; plan->out_dims[2] = d1->Win; plan->out_dims[3] = 1;
+    plan->x_bstride = (int64_t)d1->Cin * d1->Hin * d1->Win;
+    plan->y_bstride = (int64_t)d2->Cout * d1->Hin * d1->Win;
+    plan->is2d = 1; plan->cin = d1->Cin; plan->hin = d1->Hin; plan->win = d1->Win;
+    plan->desc2d = *d2; plan->is_deconv = 0;
+    plan->rb_act1 = d1->act; plan->rb_cmid = d1->Cout;
+    SubConv sc;
+    sc.KH = 3; sc.KW = 3; sc.S = 1; sc.Cout = d2->Cout; sc.Hi = d1->Hin; sc.Wi = d1->Win; sc.Ho = d1->Hin; sc.Wo = d1->Win;
+    sc.pad_y = 1; sc.pad_x = 1; sc.nz = 1;
+    sc.y_cstride = (int64_t)sc.Ho * sc.Wo; sc.y_ystride = sc.Wo; sc.y_xstride = 1;
+    sc.cin_real = d1->Cin; sc.CinPad = 32; sc.CC = 16;
+    const std::vector<float> wa = to_f32(w1, (size_t)d1->Cout * d1->Cin * 9, d1->dtype), wb = to_f32(w2, (size_t)d2->Cout * d2->Cin * 9, d2->dtype);
+    const int c1 = d1->Cin, c2 = d2->Cin;
+    // first convolution: weights into a scratch SubConv (upload_s3p packs the LDS image), then moved to the plan
+    SubConv tmp = sc;
+    tmp.Cout = d1->Cout;
+    int rc = upload_s3p(tmp, c1, [&](int co, int ci, int u, int v) { return wa[(((size_t)co * c1 + ci) * 3 + u) * 3 + v]; });
+    plan->rb_w1_dev = tmp.w_dev;
+    if (!rc) rc = upload_s3p(sc, c2, [&](int co, int ci, int u, int v) { return wb[(((size_t)co * c2 + ci) * 3 + u) * 3 + v]; });
+    sc.s3p = 0; sc.rb = 1; sc.TY = 8; sc.NW = 8; sc.TXW = 1; sc.NBW = 1;
+    std::vector<int> table(sc.CinPad, -1);
+    for (int c = 0; c < c1; c++) table[c] = c * d1->Hin * d1->Win;
+    if (!rc) rc = upload_table(sc, table);
+    plan->subs.push_back(sc);
+    if (!rc) {
+        const std::vector<float> bb = b2 ? to_f32(b2, d2->Cout, d2->dtype) : std::vector<float>();
+        rc = upload_bias(plan, b2 ? bb.data() : nullptr, d2->Cout);
+    }
+    if (!rc) {
+        std::vector<float> ba(64, 0.f);
+        if (b1) { const std::vector<float> t = to_f32(b1, d1->Cout, d1->dtype); std::copy(t.begin(), t.end(), ba.begin()); }
+        if (hipMalloc((void**)&plan->rb_bias1_dev, ba.size() * 4) != hipSuccess ||
+            hipMemcpy(plan->rb_bias1_dev, ba.data(), ba.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(RT_E_NOMEM, "rt_resblock_plan_create: device allocation failed");
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -1433,7 +1496,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
         // both tensors fp16: fp16 operands on the matrix cores (the stored values are the operands, fp32 accumulate)
         // (its gathers move 4-byte pixel pairs: row pitch, plane and sample strides must be even)
         const int xp = sc.x_pitch ? sc.x_pitch : sc.Wi;
-        if (xf && yf && !sc.small3d && !sc.f16mma && plan->subs.size() == 1 && f16mma_window(sc) && xp % 2 == 0 &&
+        if (xf && yf && !sc.small3d && !sc.f16mma && !sc.rb && plan->subs.size() == 1 && f16mma_window(sc) && xp % 2 == 0 &&
             plan->x_bstride % 2 == 0 && env_int("RT_NO_F16MMA", 0) == 0) {
             if (int rc = repack_f16mma(plan)) return rc;
         }
@@ -1452,7 +1515,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
-        if (sc.s3p || sc.split3 || sc.s3first) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
+        if (sc.s3p || sc.split3 || sc.s3first || sc.rb) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
         else if (!yf) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: fp16 -> fp32 is only built for the small-output kernel");
@@ -1473,6 +1536,7 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0 || sc.zs_dev || sc.y_xstride != 1 || sc.small3d || sc.direct) return 0;
     if (sc.s3p) return (plan->cin % 4 == 0 ? 1 : 0) | (sc.Cout % 4 == 0 ? 6 : 0);
+    if (sc.rb) return (plan->cin % 4 == 0 ? 5 : 0) | (sc.Cout % 4 == 0 ? 2 : 0);      // the residual IS the input tensor
     if (sc.s3first) return sc.Cout % 4 == 0 ? 2 : 0;           // output only (its input is the image binding)
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
     if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
@@ -1500,6 +1564,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
                     x_il8 && !(caps & 1) ? "input" : (y_il8 && !(caps & 2) ? "output" : "residual"));
     RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
     SubConv& sc = plan->subs[0];
+    RT_REQUIRE(!sc.rb || (x_il8 != 0) == (r_il8 != 0), "rt_conv_plan_set_layouts: a residual block's residual is its input tensor");
     sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
     return 0;
 }
@@ -1514,7 +1579,8 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
                                rtStream s) {
     RT_REQUIRE(plan && x && y, "rt_conv_enqueue: null pointer");
     RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
-    RT_REQUIRE(!plan->has_resid || residual, "rt_conv_enqueue: plan expects a residual tensor");
+    RT_REQUIRE(!plan->has_resid || residual || plan->rb_w1_dev, "rt_conv_enqueue: plan expects a residual tensor");
+    RT_REQUIRE(!plan->rb_w1_dev || !residual || residual == x, "rt_conv_enqueue: a residual block's skip connection is its input tensor");
     for (const SubConv& sc : plan->subs) {
         if (sc.small3d) {
             rt::Deconv3dSmallArgs a = sc.s3;
@@ -1605,6 +1671,21 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (sc.rb) {
+            rt::RBArgs ra;
+            ra.c = a;
+            ra.c.resid = static_cast<const float*>(x);          // the block's input is its skip connection
+            ra.c.r_cstride = a.x_cstride; ra.c.r_bstride = plan->x_bstride; ra.c.r_il8 = sc.x_il8;
+            ra.w1 = plan->rb_w1_dev; ra.bias1 = plan->rb_bias1_dev; ra.act1 = plan->rb_act1; ra.cmid = plan->rb_cmid;
+            dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
+            if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
+            if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(512), 0, S(s), ra);
+            else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, false>), rgrid, dim3(512), 0, S(s), ra);
+            else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, true>), rgrid, dim3(512), 0, S(s), ra);
+            else hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, false>), rgrid, dim3(512), 0, S(s), ra);
+            RT_LAUNCH_CHECK("conv_s3rb_kernel");
+            continue;
+        }
         if (sc.s3first) {
             if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_first_kernel<true>), grid, dim3(256), 0, S(s), a);
             else hipLaunchKernelGGL((rt::conv_s3_first_kernel<false>), grid, dim3(256), 0, S(s), a);

@@ -190,3 +190,53 @@ def test_split_first_layer(backend, cin, cout, h, w, batch, pitch, y_il):
     assert np.abs(outs[0] - ref).max() <= 3e-6, np.abs(outs[0] - ref).max()
     if y_il:
         assert np.array_equal(outs[0], outs[1])
+
+
+# ---- fused residual block (conv_s3rb_kernel) ------------------------------------------------------------------------------
+RB_CASES = [
+    # c, cmid, h, w, batch, pitch, (x_il, y_il)
+    (32, 32, 19, 70, 2, 96, (1, 1)),      # the tower block: 3 x 3 tiles per image
+    (32, 32, 8, 32, 1, 0, (0, 0)),        # exactly one tile, planar, dense
+    (32, 32, 9, 33, 1, 64, (1, 0)),       # one row / pixel past a tile
+    (16, 24, 11, 37, 2, 64, (0, 1)),      # Cmid != C, one chunk of input channels
+    (20, 30, 7, 35, 1, 0, (1, 1)),        # channel tails (multiples of 4 only where interleaved)
+    (13, 9, 5, 9, 3, 0, (0, 0)),          # odd channel counts, image smaller than a tile
+    (8, 8, 3, 5, 1, 32, (1, 1)),
+    (4, 4, 1, 1, 2, 0, (0, 0)),           # single pixel
+]
+
+
+@pytest.mark.parametrize("c,cmid,h,w,batch,pitch,il", RB_CASES)
+def test_split_resblock(backend, c, cmid, h, w, batch, pitch, il):
+    """whole residual block in one launch against an fp64 evaluation of the two layers, and against the same block run
+    layer by layer through the general split kernel"""
+    x = rnd(batch, c, h, w)
+    w1, b1 = rnd(cmid, c, 3, 3) * np.float32(1 / np.sqrt(c * 9)), rnd(cmid)
+    w2, b2 = rnd(c, cmid, 3, 3) * np.float32(1 / np.sqrt(cmid * 9)), rnd(c)
+    X = torch.from_numpy(x).double()
+    t = O.elu(O.conv2d(X, torch.from_numpy(w1).double(), torch.from_numpy(b1).double(), 1, 1))
+    ref = O.elu(O.conv2d(t, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), 1, 1) + X).numpy()
+    P = pitch or w
+    x_il, y_il = il
+    lay = lambda a, f: to_il(a, 4) if f else a
+    plan = backend.klib.resblock_plan(w1, b1, w2, b2, c, cmid, h, w)
+    if pitch:
+        plan.set_pitch(pitch, pitch)
+    assert plan.il_caps() == (5 if c % 4 == 0 else 0) | (2 if c % 4 == 0 else 0)
+    if x_il or y_il:
+        plan.set_layouts(x_il, y_il, x_il)
+    xin = backend.dev(lay(pitched(x, P), x_il))                        # NaN in the padding columns
+    y = backend.empty((batch, c // 4, h, P, 4) if y_il else (batch, c, h, P))
+    plan.enqueue(xin, y, xin, batch)
+    out = backend.host(y).copy()
+    out = from_il(out) if y_il else out
+    plan.destroy()
+    if P > w:
+        assert np.isnan(out[..., w:]).all(), "padding columns were written"
+    out = out[..., :w]
+    assert np.abs(out - ref).max() <= 6e-6, np.abs(out - ref).max()
+    # layer by layer (conv_s3_kernel twice): the fused form keeps the intermediate in LDS as the same hi / lo pair the second
+    # layer would have split it into; what differs is the order of the fp32 accumulation (taps x chunks)
+    t2 = run(backend, x, w1, b1, None, capi.RT_ACT_ELU, batch)
+    two = run(backend, t2, w2, b2, x, capi.RT_ACT_ELU, batch)
+    assert np.abs(out - two).max() <= 6e-6, np.abs(out - two).max()
