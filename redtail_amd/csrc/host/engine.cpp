@@ -865,7 +865,11 @@ void EngineImpl::assignStreams() {
 // tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  Not in half2 mode, where the two layers run on fp16
 // operands with fp16 tensors in between.
 void EngineImpl::fuseResBlocks() {
-    if (getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (half2_ && !getenv("RT_NO_F16"))) return;
+    // Opt-in (RT_RB=1).  Measured on MI355X (profiles/README.md, round 2): the fused block takes 27.9 us alone against 2 x 14.1 us
+    // for its two layers -- one workgroup per CU (150 KB of LDS) runs gather, conv1, conv2 and the stores back to back with nothing
+    // to overlap them, and 11 column blocks of conv1 do not spread evenly over 8 waves -- and the network is slower with it
+    // (1934 vs 2069 pairs/s).  It needs a persistent, software-pipelined tile loop to pay; until then the layers stay separate.
+    if (!getenv("RT_RB") || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (half2_ && !getenv("RT_NO_F16"))) return;
     int fused = 0;
     for (size_t ia = 0; ia < ops_.size(); ia++) {
         Op& a = ops_[ia];

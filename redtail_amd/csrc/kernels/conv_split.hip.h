@@ -671,6 +671,12 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
     __shared__ __attribute__((aligned(16))) char sT[Cfg::TSEG * 32 * PXB];
 
     const int tid = threadIdx.x;
+#ifdef RT_KERNEL_TIMING
+    unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 : nullptr;
+    int dbi = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    RT_TSTAMP();                                  // 0: start
     const int lane = tid & 63;
     const int kg = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -722,6 +728,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
                     rin[k][j] = buf_load(rs, (in && 4 * g + j < p.cin_real) ? (unsigned)(4 * g + j) * cs_x * 4u + (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB, 0u);
             }
         }
+        RT_TSTAMP();                              // 1: weights + input gathers issued
 #pragma unroll
         for (int k = 0; k < NKX; k++) {
             if (lds[k] < 0) continue;
@@ -730,7 +737,9 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
             *reinterpret_cast<f16x4*>(sX + lds[k] + 64) = s.lo;
         }
     }
+    RT_TSTAMP();                                  // 2: input split and written to LDS
     __syncthreads();
+    RT_TSTAMP();                                  // 3: barrier
 
     const int a_off = kg * 32 + l31;
     auto contract = [&](const char* bp0, int row_pitch, f32x16& acc_m, f32x16& acc_c) {
@@ -782,7 +791,9 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
             }
         }
     }
+    RT_TSTAMP();                                  // 4: conv1 done (this wave)
     __syncthreads();               // intermediate complete; nobody reads conv1's weights any more
+    RT_TSTAMP();                                  // 5: barrier
 #pragma unroll
     for (int k = 0; k < NK_W; k++) {
         const int idx = tid + NT * k;
@@ -810,8 +821,10 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
         }
     }
     __syncthreads();               // conv2's weights are in LDS
+    RT_TSTAMP();                                  // 6: conv2's weights in LDS, residual requested
     f32x16 acc_m, acc_c;
     contract(sT + (wv * TC + l31) * PXB + kg * 16, TC, acc_m, acc_c);
+    RT_TSTAMP();                                  // 7: conv2 MFMAs issued
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
     const int act = p.act;
     auto epilogue = [&](auto ACT) {
@@ -836,6 +849,11 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
     if (act == 1) epilogue(std::integral_constant<int, 1>{});
     else if (act == 2) epilogue(std::integral_constant<int, 2>{});
     else epilogue(std::integral_constant<int, 0>{});
+    RT_TSTAMP();                                  // 8: stores issued
+#ifdef RT_KERNEL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    if (dbgp && tid == 0) { dbgp[14] = __builtin_amdgcn_s_memtime(); dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
 }
 
 }  // namespace rt

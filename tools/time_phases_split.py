@@ -14,6 +14,7 @@ from redtail_amd import build, capi  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 general = os.environ.get("RT_S3P", "0") == "0"
+block = os.environ.get("RT_TIME_BLOCK", "0") != "0"      # the fused residual block (conv_s3rb_kernel)
 k = capi.KernelLib.__new__(capi.KernelLib)
 k.path = os.environ.get("RT_TIMING_LIB", os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so"))
 k.lib = ctypes.CDLL(k.path)
@@ -22,12 +23,15 @@ for name, (res, args) in capi.KERNEL_SYMBOLS.items():
     fn.restype, fn.argtypes = res, args
 h, w = 185, 629
 wt = (np.random.randn(32 * 32 * 9).astype(np.float32) / np.sqrt(288))
-plan = k.conv2d_plan(wt, np.random.randn(32).astype(np.float32), 32, 32, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+if block:
+    plan = k.resblock_plan(wt, np.random.randn(32).astype(np.float32), wt[::-1].copy(), np.random.randn(32).astype(np.float32), 32, 32, h, w)
+else:
+    plan = k.conv2d_plan(wt, np.random.randn(32).astype(np.float32), 32, 32, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
 plan.set_pitch(640, 640)
 plan.set_layouts(1, 1, 1)
 x = torch.randn(b, 32, h, 640, device="cuda")
-y, r = torch.empty_like(x), torch.randn_like(x)
-nwg = 47 * 20 * b if general else 256
+y, r = torch.empty_like(x), (x if block else torch.randn_like(x))
+nwg = 24 * 20 * b if block else (47 * 20 * b if general else 256)
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     plan.enqueue(x, y, r, b)
@@ -37,7 +41,10 @@ plan.enqueue(x, y, r, b)
 torch.cuda.synchronize()
 t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
 t = t[t[:, 0] > 0]
-if general:
+if block:
+    names = ["start", "loads issued", "x split -> LDS", "barrier", "conv1 done", "barrier", "W2 in LDS", "conv2 MFMAs issued", "stores issued"]
+    last = 8
+elif general:
     names = ["start", "loads issued", "c0 in LDS", "c0 MFMAs issued", "c1 in LDS", "c1 MFMAs issued", "stores issued"]
     last = 6
 else:
@@ -46,7 +53,7 @@ else:
     t = t[t[:, 9] > 0]           # workgroups with (at least) two tiles
     last = 9
 d = np.diff(t[:, :last + 1], axis=1)
-print("%s kernel, batch %d: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % ("general" if general else "persistent", b, len(t)))
+print("%s kernel, batch %d: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % ("residual-block" if block else "general" if general else "persistent", b, len(t)))
 for i in range(last):
     print("  %-24s -> %-24s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
 print("  last stamp -> all stores acknowledged %9.1f" % (t[:, 14] - t[:, last]).mean())
