@@ -103,6 +103,10 @@ int rt_corr_softargmax(const void* left, const void* right, void* out, int batch
 int rt_corr_softargmax_pitched(const void* left, const void* right, void* out, int batch, int C, int H, int W,
                                int max_disp, int is_min, int in_pitch, int out_pitch, int64_t out_batch_stride,
                                int dtype, rtStream stream);
+/* The same fused correlation + soft-argmax on channel-interleaved (C/4, H, pitch, 4) fp32 feature maps -- the executor's
+ * internal layout between 3x3 convolutions -- computed on the matrix cores (C a multiple of 4 up to 32, D <= 64). */
+int rt_corr_softargmax_il(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
+                          int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream stream);
 
 /* ---- layout glue of the 3-D models ------------------------------------------------------- */
 /* 4-D permute of a (N, d0,d1,d2,d3) tensor: out dim i = in dim order[i].  Replaces

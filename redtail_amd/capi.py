@@ -61,6 +61,7 @@ KERNEL_SYMBOLS = {
     "rt_softargmax": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rt_corr_softargmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int64, c_int, c_void_p]),
     "rt_corr_softargmax_pitched": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
+    "rt_corr_softargmax_il": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_void_p]),
     "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
     "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_slice_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -149,6 +150,10 @@ class KernelLib:
         self.check(self.lib.rt_corr_softargmax_pitched(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min),
                                                        in_pitch, out_pitch, out_bstride, dtype, stream),
                    "rt_corr_softargmax_pitched")
+
+    def corr_softargmax_il(self, l, r, out, batch, C, H, W, D, is_min, in_pitch=0, out_pitch=0, out_bstride=0, stream=None):
+        self.check(self.lib.rt_corr_softargmax_il(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min), in_pitch, out_pitch,
+                                                  out_bstride, stream), "rt_corr_softargmax_il")
 
     def cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, stream=None):
         self.check(self.lib.rt_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, stream),

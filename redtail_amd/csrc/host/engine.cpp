@@ -308,6 +308,7 @@ struct Op {
     IPlugin* plugin = nullptr;         // kPlugin / kConv3D
     IStereoPlugin* splugin = nullptr;  // kConv3D
     int max_disp = 0, is_min = 0;      // kCorrSoftargmax
+    bool il_in = false;                // kCorrSoftargmax: channel-interleaved feature maps -> matrix-core kernel
     int stream = 0;
     std::vector<int> wait_on;          // tensors produced on the other stream that this op consumes
     bool publish = false;              // another stream consumes the result: record an event after the launch
@@ -795,12 +796,20 @@ void EngineImpl::assignPitch() {
     // of planar and interleaved tensors, so the layout is a per-tensor property and nothing is converted anywhere.
     std::vector<char> il(tensors_.size(), 0);
     for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 == f16 && t->dims.d[0] % (f16 ? 8 : 4) == 0;
+    auto corr_takes_il = [&](const Op& op) {        // fused correlation + soft-argmax on the matrix cores (corr_mfma.hip.h)
+        const Dims& f = tensors_[op.in[0]]->dims;
+        return op.kind == OpKind::kCorrSoftargmax && !f16 && f.d[0] % 4 == 0 && f.d[0] <= 32 && op.max_disp <= 64 &&
+               !getenv("RT_NO_CORR_MFMA") && !getenv("RT_NO_IL8");
+    };
     for (auto& op : ops_) {
-        const int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual
+        int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual
+        if (corr_takes_il(op)) caps = 1;
         if (!(caps & 1)) for (int i : op.in) il[root(i)] = 0;
         if (!(caps & 2)) il[root(op.out)] = 0;
         if (op.resid >= 0 && !(caps & 4)) il[root(op.resid)] = 0;
     }
+    for (auto& op : ops_)                            // both feature maps or neither
+        if (op.kind == OpKind::kCorrSoftargmax && il[root(op.in[0])] != il[root(op.in[1])]) il[root(op.in[0])] = il[root(op.in[1])] = 0;
     for (auto& op : ops_) {
         if (op.kind != OpKind::kConv) continue;
         const int xi = il[root(op.in[0])], yi = il[root(op.out)], ri = op.resid >= 0 ? il[root(op.resid)] : 0;
@@ -812,6 +821,8 @@ void EngineImpl::assignPitch() {
             return;
         }
     }
+    for (auto& op : ops_)
+        if (op.kind == OpKind::kCorrSoftargmax) op.il_in = il[root(op.in[0])] != 0;
     int n_il = 0;
     for (auto& t : tensors_) t->il8 = il[t->id] != 0;
     for (auto& op : ops_) n_il += il[root(op.out)] != 0;         // tensors that launches really write
@@ -1227,9 +1238,13 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             }
             case OpKind::kCorrSoftargmax: {
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
-                rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
-                                                f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
-                                                out.bstride, out.f16 ? RT_F16 : RT_F32, st);
+                if (op.il_in)
+                    rc = rt_corr_softargmax_il(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
+                                               f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride, st);
+                else
+                    rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
+                                                    f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
+                                                    out.bstride, out.f16 ? RT_F16 : RT_F32, st);
                 break;
             }
             case OpKind::kCopy:

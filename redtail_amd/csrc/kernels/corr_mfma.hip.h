@@ -1,0 +1,132 @@
+// Correlation cost volume + soft-argmax in one pass ON THE MATRIX CORES: CostVolumePlugin(kCorrelation) followed by
+// SoftargmaxPlugin of ResNet-18 2D (reference lib/kernels.cu:168-200 corrCostVolumeKernel,
+// lib/softargmax_plugin.cpp:161-205; resnet18_2D_513x257_net.cpp:600-610).
+//
+//     cv[d, y, x] = sum_c L[c, y, x] * R[c, y, x - d]        (0 for x < d),   d in [0, D)
+// is, for a block of 32 output pixels x0 .. x0+31 of one row, the band d = x - x' of the Gram matrix
+//     G[x', x] = sum_c R[c, x'] * L[c, x],        x' in [x0 - 64, x0 + 31]:
+// three 32 x 32 blocks, K = C <= 32.  With the 3-term fp16 split of conv_split.hip.h (fp32-class accuracy on the fp16
+// pipe) that is 3 blocks x 2 chunks x 3 terms = 18 v_mfma_f32_32x32x16_f16 per 32 pixels instead of 32 x 48 x 32 fp32 FMAs
+// on the vector ALU (what bounded the round-1 kernel).  Rows of the MFMA are R pixels, columns are L (= output)
+// pixels, so a lane holds, for ITS output pixel, 16 of the 32 x' of each block: the soft-argmax runs per lane over its
+// registers (online, block after block), the two half-waves that share an output pixel are combined with one
+// cross-half shuffle, and nothing but the disparity is written.
+//
+// No LDS: the feature maps are channel-interleaved (C/4, H, pitch, 4) fp32 (the layout conv_s3_kernel writes), so the
+// MFMA operand of a lane -- 8 consecutive channels of one pixel -- is two 16-byte loads.  One wave per (row, 32-pixel
+// block); R blocks are shared with the neighbouring waves through L1/L2 only.
+#pragma once
+#include "common.hip.h"
+#include "conv_split.hip.h"
+
+namespace rt {
+
+struct CorrMfmaArgs {
+    const float* left;      // (C/4, H, pitch, 4) per sample
+    const float* right;
+    float* out;             // (H, out_pitch) per sample
+    int C, H, W, D;
+    int in_pitch, out_pitch;
+    int64_t in_bstride, out_bstride;     // elements
+    int blocks_x;                        // ceil(W / 32)
+    int batch;
+};
+
+__device__ static __forceinline__ void corr_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+    const S3Split s0 = s3_split(a), s1 = s3_split(b);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { hi[j] = s0.hi[j]; hi[4 + j] = s1.hi[j]; lo[j] = s0.lo[j]; lo[4 + j] = s1.lo[j]; }
+}
+
+template <bool ISMIN>
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_kernel(CorrMfmaArgs p) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // task = (sample, row, 32-pixel block); a workgroup's 4 waves take 4 consecutive blocks of a row
+    const int64_t task = (int64_t)blockIdx.x * 4 + wv;
+    const int per_row = p.blocks_x;
+    const int64_t total = (int64_t)per_row * p.H * p.batch;
+    if (task >= total) return;
+    const int bx = (int)(task % per_row);
+    const int y = (int)((task / per_row) % p.H);
+    const int n = (int)(task / ((int64_t)per_row * p.H));
+    const int x0 = bx * 32;
+
+    const buf_rsrc rs_l = make_buf(elem_ptr(p.left, (int64_t)n * p.in_bstride, 4));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.right, (int64_t)n * p.in_bstride, 4));
+    const unsigned gstride = (unsigned)(4 * p.H * p.in_pitch) * 4u;        // bytes between channel groups
+    const int nchunks = (p.C + 15) / 16;
+
+    // operand of lane (pixel px, k-group kg), chunk c: channel groups 4c + 2kg, 4c + 2kg + 1 of that pixel
+    auto load_px = [&](const buf_rsrc& rs, int px, f32x4 (&v)[2][2]) {
+        const bool ok = px >= 0 && px < p.W;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int g = 4 * c + 2 * kg + h;
+                v[c][h] = buf_load4(rs, (ok && c < nchunks && 4 * g < p.C) ? (unsigned)g * gstride + (unsigned)(y * p.in_pitch + px) * 16u : kBufOOB, 0u);
+            }
+    };
+
+    f32x4 lraw[2][2], rraw[3][2][2];
+    load_px(rs_l, x0 + l31, lraw);
+#pragma unroll
+    for (int j = 0; j < 3; j++) load_px(rs_r, x0 - 64 + 32 * j + l31, rraw[j]);
+
+    f16x8 lh[2], ll[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) corr_split8(lraw[c][0], lraw[c][1], lh[c], ll[c]);
+
+    // online soft-argmax state of this lane (its 16 of the 32 R pixels of each block)
+    float m_run = -1e30f, s_run = 0.f, w_run = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        f32x16 acc_m, acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            f16x8 rh, rl;
+            corr_split8(rraw[j][c][0], rraw[j][c][1], rh, rl);
+            acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, lh[c], acc_m, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl, lh[c], acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, ll[c], acc_c, 0, 0, 0);
+        }
+        // accumulator register r = R pixel x0 - 64 + 32 j + m, m = (r & 3) + 8 (r >> 2) + 4 kg; column = L pixel x0 + l31
+        float v[16];
+        float bm = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int d = l31 + 64 - 32 * j - m;                    // x - x'
+            const float val = fmaf(acc_c[r], kSplitInv, acc_m[r]);
+            v[r] = (d >= 0 && d < p.D) ? (ISMIN ? -val : val) : -1e30f;
+            bm = fmaxf(bm, v[r]);
+        }
+        const float m_new = fmaxf(m_run, bm);
+        const float sc = fast_exp(m_run - m_new);
+        s_run *= sc;
+        w_run *= sc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int d = l31 + 64 - 32 * j - m;
+            const float e = (d >= 0 && d < p.D) ? fast_exp(v[r] - m_new) : 0.f;
+            s_run += e;
+            w_run = fmaf(e, (float)d, w_run);
+        }
+        m_run = m_new;
+    }
+    // the other half-wave holds the other 16 R pixels of every block for the same output pixel
+    const float m2 = __shfl_xor(m_run, 32), s2 = __shfl_xor(s_run, 32), w2 = __shfl_xor(w_run, 32);
+    const float M = fmaxf(m_run, m2);
+    const float e1 = fast_exp(m_run - M), e2 = fast_exp(m2 - M);
+    const float s = s_run * e1 + s2 * e2, w = w_run * e1 + w2 * e2;
+    const int x = x0 + l31;
+    if (kg == 0 && x < p.W) p.out[(int64_t)n * p.out_bstride + (int64_t)y * p.out_pitch + x] = w / s;
+}
+
+}  // namespace rt

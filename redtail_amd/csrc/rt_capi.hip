@@ -21,6 +21,7 @@
 #include "kernels/conv_f16_first.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/cost_volume.hip.h"
+#include "kernels/corr_mfma.hip.h"
 #include "kernels/elementwise.hip.h"
 #include "kernels/layout.hip.h"
 
@@ -261,6 +262,30 @@ extern "C" int rt_corr_softargmax_pitched(const void* left, const void* right, v
                       : launch_corr<true, false, false, _Float16>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch);
     return is_min ? launch_corr<true, true>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch)
                   : launch_corr<true, false>(l, r, o, batch, C, H, W, D, out_bstride, S(s), in_pitch, out_pitch);
+}
+
+// Correlation + soft-argmax on channel-interleaved (C/4, H, pitch, 4) fp32 feature maps, on the matrix cores (corr_mfma.hip.h)
+extern "C" int rt_corr_softargmax_il(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
+                                     int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream s) {
+    RT_REQUIRE(left && right && out, "rt_corr_softargmax_il: null pointer");
+    RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax_il: bad dims");
+    if (C % 4 != 0 || C > 32 || D > 64) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_il: C must be a multiple of 4 up to 32 and max_disp <= 64 (C %d, D %d)", C, D);
+    RT_REQUIRE((in_pitch == 0 || in_pitch >= W) && (out_pitch == 0 || out_pitch >= W), "rt_corr_softargmax_il: pitch smaller than the row");
+    rt::CorrMfmaArgs a;
+    a.left = static_cast<const float*>(left); a.right = static_cast<const float*>(right); a.out = static_cast<float*>(out);
+    a.C = C; a.H = H; a.W = W; a.D = D;
+    a.in_pitch = in_pitch ? in_pitch : W; a.out_pitch = out_pitch ? out_pitch : W;
+    a.in_bstride = (int64_t)C * H * a.in_pitch;
+    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch;
+    RT_REQUIRE(a.in_bstride < (1ll << 29), "rt_corr_softargmax_il: sample exceeds 2 GB (32-bit buffer offsets)");
+    a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
+    const int64_t tasks = (int64_t)a.blocks_x * H * batch;
+    RT_REQUIRE(rt::cdiv(tasks, 4) < (1ll << 31), "rt_corr_softargmax_il: grid too large");
+    dim3 grid((unsigned)rt::cdiv(tasks, 4));
+    if (is_min) hipLaunchKernelGGL((rt::corr_softargmax_mfma_kernel<true>), grid, dim3(256), 0, S(s), a);
+    else hipLaunchKernelGGL((rt::corr_softargmax_mfma_kernel<false>), grid, dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("corr_softargmax_mfma_kernel");
+    return 0;
 }
 
 extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,

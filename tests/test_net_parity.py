@@ -98,7 +98,9 @@ def test_resnet18_2d_pitched_equals_dense(rt, monkeypatch):
     monkeypatch.setenv("RT_NO_PITCH", "1")
     dense, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
     assert not np.isnan(pitched).any()
-    assert np.array_equal(pitched, dense)
+    # the convolutions only change their addressing; the fused correlation runs on the matrix cores when its feature maps
+    # are channel-interleaved (which needs pitched rows) and on the vector ALU otherwise: fp32 roundoff apart
+    assert np.abs(pitched - dense).max() <= 2e-6
 
 
 def test_nvtiny_tiny(rt):
@@ -269,7 +271,10 @@ def test_resnet18_2d_full_size_layouts(monkeypatch, half2):
         torch.cuda.synchronize()
         outs.append(out.cpu())
         net.destroy()
-    assert torch.equal(outs[0], outs[1])
+    if half2:
+        assert torch.equal(outs[0], outs[1])
+    else:       # fp32: the correlation of interleaved feature maps runs on the matrix cores, of planar ones on the vector ALU
+        assert (outs[0] - outs[1]).abs().max().item() <= 2e-6
     if half2:
         wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in weights.items()}
         with torch.no_grad():
@@ -398,4 +403,4 @@ def test_resnet18_2d_interleaved_equals_planar(rt, monkeypatch):
     monkeypatch.setenv("RT_NO_IL8", "1")
     planar, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
     assert n1 == n2
-    assert np.array_equal(il, planar)
+    assert np.abs(il - planar).max() <= 2e-6         # bit-identical convolutions; the correlation kernel differs (see above)
