@@ -271,13 +271,15 @@ namespace rt {
 // from the gather table as scalars.  Stride 2: even and odd patch columns are stored apart, so that the lanes of a B
 // fetch (pixels 2l + s) still read consecutive LDS pixels.
 // -----------------------------------------------------------------------------------------------------------------------
-template <int KH, int KW, int S>
+template <int KH, int KW, int S, int NW_ = 4>
 struct S3Cfg {
-    static constexpr int NW = 4, TY = 4, TX = 32, CC = 16, TAPS = KH * KW, NT = 256;
+    static constexpr int NW = NW_, TY = NW_, TX = 32, CC = 16, TAPS = KH * KW, NT = 64 * NW_;       // one output row per wave
     static constexpr int PR = (TY - 1) * S + KH, PC = (TX - 1) * S + KW;
     static constexpr int PCH = (PC + 1) / 2;                       // stride 2: columns per parity
     static constexpr int PCL = S == 2 ? 2 * PCH : PC;              // LDS columns per patch row
-    static constexpr int NPIX = PR * PC, NKP = (NPIX + 63) / 64;   // patch pixels per lane (each wave covers the whole patch)
+    // staging: wave w gathers channel group w & 3 (4 channels of the chunk) for part w >> 2 of the patch pixels
+    static constexpr int NPART = NW / 4;
+    static constexpr int NPIX = PR * PC, NKP = ((NPIX + NPART - 1) / NPART + 63) / 64;   // patch pixels per lane
     static constexpr int PXB = 80;
     static constexpr int W_SLOTS = TAPS * 2 * 2 * 32;              // 16-byte slots of one chunk's weights
     static constexpr int NK_W = (W_SLOTS + NT - 1) / NT;
@@ -289,9 +291,12 @@ struct S3Cfg {
 #ifndef RT_S3_WAVES
 #define RT_S3_WAVES(S) ((S) == 2 ? 2 : 4)
 #endif
-template <int KH, int KW, int S, bool XIL, bool YIL>
-__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
-    using Cfg = S3Cfg<KH, KW, S>;
+// NW = 8 (3x3 stride 1 only): 8-row tiles, 8 waves -- the chunk's weights are fetched and staged once per 8 rows instead of
+// once per 4 and the patch halo shrinks from 6/4 to 10/8 rows: 29 % fewer bytes through the CU's vector-memory path, which
+// is what bounds the layer (profiles/README.md, round 2)
+template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
+    using Cfg = S3Cfg<KH, KW, S, NW>;
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
 
@@ -334,18 +339,19 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_k
     const int act = p.act;
 
     // ---- staging: wave w gathers channels 4w .. 4w+3 of each chunk for every patch pixel -----------------------------
-    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 4 * wv;
+    const int sg = wv & 3, spart = wv >> 2;                         // channel group / patch part of this wave
+    const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 4 * sg;
     unsigned voff[NKP];
     int lidx[NKP];
 #pragma unroll
     for (int k = 0; k < NKP; k++) {
-        const int pidx = lane + 64 * k;
+        const int pidx = spart * (NKP * 64) + lane + 64 * k;
         const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
-        const bool own = pidx < Cfg::NPIX;
+        const bool own = pidx < Cfg::NPIX && lane + 64 * k < NKP * 64;
         voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : 4u) : kBufOOB;
         const int col = S == 2 ? (pc & 1) * Cfg::PCH + (pc >> 1) : pc;
-        lidx[k] = own ? (pr * PCL + col) * PXB + wv * 8 : -1;
+        lidx[k] = own ? (pr * PCL + col) * PXB + sg * 8 : -1;
     }
     // w_off and the slab size count 16-byte slots
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + (w_off + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS) * 16;
@@ -628,47 +634,46 @@ namespace rt {
 //       y = act2( conv3x3( act1( conv3x3(x) + b1 ) ) + b2 + x )          (Cin = Cmid = Cout <= 32, stride 1)
 // the unit the feature towers of ResNet-18 2D / ResNet-18 3D are made of (reference resnet18_2D_513x257_net.cpp:66-575:
 // resblockN_conv1 -> ELU -> resblockN_conv2 -> add -> ELU, 8 blocks per side = 32 of the network's 49 convolutions).
-// Layer by layer the block moves x, t, t, x, y through HBM (5 tensor passes + the weights once per tile and layer); fused,
-// the intermediate t lives in LDS and the block moves x and y (+ the halo): 2.3 passes.  Per workgroup (8 waves) and
-// 8-row x 32-pixel output tile:
-//   1. gather the 12 x 36 input region (fp32, planar or channel-interleaved), split it into fp16 hi / lo, LDS image sX
-//      (144 B per pixel as in conv_s3p_kernel); conv1's split weights go to LDS, conv2's are requested into registers
-//   2. conv1 on the 10 x 34 region conv2 needs (340 pixels = 11 MFMA column blocks of 32, spread over the 8 waves): 54
-//      MFMAs per block; epilogue = bias, activation, ZERO outside the image (conv2's padding), split, LDS image sT
-//   3. conv2's weights replace conv1's in LDS
-//   4. conv2 on the 8 x 32 tile out of sT (one row per wave); the residual (the fp32 x values, L2-hot) is requested before
-//      the MFMAs and added in the epilogue
-// The recomputed halo costs 11/8 of conv1's multiplies; the matrix pipe has that slack, HBM does not.
+// Layer by layer the block moves x, t, t, x, y through HBM (5 tensor passes); fused, the intermediate t lives in LDS and
+// the block moves x (+ halo) and y.  Workgroup = 4 waves = a 4-row x 32-pixel output tile, ~76 KB of LDS, two workgroups
+// per CU so that one's gathers / stores overlap the other's MFMAs:
+//   1. conv1 on the 6 x 34 region conv2 needs (204 pixels = 7 MFMA column blocks of 32: two per wave), contraction in two
+//      chunks of 16 input channels staged like conv_s3_kernel does (x region 8 x 36, split into fp16 hi / lo, 80 B per pixel;
+//      split weights of the chunk; the next chunk's gathers fly under the MFMAs);
+//      epilogue = bias, activation, ZERO outside the image (conv2's padding), split, LDS image sT[chunk][pixel]
+//   2. conv2 on the 4 x 32 tile out of sT (one row per wave), its two weight chunks staged into the same buffer; the
+//      residual (the fp32 x values, L2-hot) is requested before the MFMAs and added in the epilogue.
+// The recomputed halo costs 7/4 of conv1's multiplies (11/8 of the block's); the matrix pipe has that slack, HBM does not.
 // -----------------------------------------------------------------------------------------------------------------------
 struct S3RBCfg {
-    static constexpr int NW = 8, TY = 8, TX = 32, NT = 512;
-    static constexpr int XR = TY + 4, XC = TX + 4, XPIX = XR * XC;          // input region 12 x 36
-    static constexpr int TR = TY + 2, TC = TX + 2, TPIX = TR * TC;          // conv1 output region 10 x 34
-    static constexpr int TSEG = (TPIX + 31) / 32;                            // 11 column blocks of 32 pixels
-    static constexpr int PXB = 144;
-    static constexpr int NSLOT = XPIX * 8, NKX = (NSLOT + NT - 1) / NT;      // (pixel, 4-channel group) gather slots per thread
-    static constexpr int W_SLOTS = 9 * 2 * 2 * 2 * 32, NK_W = (W_SLOTS + NT - 1) / NT;
-    static constexpr int SEG_PER_WAVE = (TSEG + NW - 1) / NW;                // 2
+    static constexpr int NW = 4, TY = 4, TX = 32, NT = 256;
+    static constexpr int XR = TY + 4, XC = TX + 4, XPIX = XR * XC;          // input region 8 x 36
+    static constexpr int TR = TY + 2, TC = TX + 2, TPIX = TR * TC;          // conv1 output region 6 x 34
+    static constexpr int TSEG = (TPIX + 31) / 32;                            // 7 column blocks of 32 pixels
+    static constexpr int SEGW = (TSEG + NW - 1) / NW;                        // 2 per wave
+    static constexpr int PXB = 80;                                           // 16 channels: 32 B hi | 32 B lo | 16 B pad
+    static constexpr int NSLOT = XPIX * 4, NKX = (NSLOT + NT - 1) / NT;      // (pixel, 4-channel group) gather slots per thread and chunk
+    static constexpr int W_SLOTS = 9 * 2 * 2 * 32, NK_W = (W_SLOTS + NT - 1) / NT;    // one 16-channel chunk of split weights
 };
 
 struct RBArgs {
-    ConvArgs c;            // geometry, x / y / resid pointers and strides, bias = conv2's, w = conv2's split weights, act = act2
-    const float* w1;       // conv1's split weights (same LDS image layout)
+    ConvArgs c;            // geometry, x / y pointers and strides, bias = conv2's, w = conv2's split weights, act = act2
+    const float* w1;       // conv1's split weights (conv_s3_kernel's slab order: [chunk][tap][hi/lo][k-group][co][8])
     const float* bias1;    // padded to 64
     int act1;
     int cmid;              // channels of the intermediate (conv1's outputs = conv2's inputs)
 };
 
 template <bool XIL, bool YIL>
-__global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArgs a) {
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArgs a) {
     using Cfg = S3RBCfg;
     const ConvArgs& p = a.c;
     constexpr int TY = Cfg::TY, TX = Cfg::TX, XC = Cfg::XC, TC = Cfg::TC, PXB = Cfg::PXB, NT = Cfg::NT;
-    constexpr int NKX = Cfg::NKX, NK_W = Cfg::NK_W;
+    constexpr int NKX = Cfg::NKX, NK_W = Cfg::NK_W, SEGW = Cfg::SEGW;
 
     __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
     __shared__ __attribute__((aligned(16))) char sX[Cfg::XPIX * PXB];
-    __shared__ __attribute__((aligned(16))) char sT[Cfg::TSEG * 32 * PXB];
+    __shared__ __attribute__((aligned(16))) char sT[2][Cfg::TSEG * 32 * PXB];
 
     const int tid = threadIdx.x;
 #ifdef RT_KERNEL_TIMING
@@ -692,115 +697,138 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
     const int n = blockIdx.z;
     const int H = p.Hi, W = p.Wi;                  // stride 1, same padding: input, intermediate and output grids coincide
 
-    // ---- conv1's weights -> LDS, conv2's -> registers (they replace conv1's in LDS after phase 2) -----------------------
-    f32x4 rw2[NK_W];
-    {
-        const buf_rsrc rs_w1 = make_buf(a.w1), rs_w2 = make_buf(p.w);
+    // ---- gather slots of this thread (the same for both chunks): patch pixel and channel group within the chunk ----------------
+    const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
+    const unsigned cs_x = (unsigned)p.x_cstride;
+    unsigned xoff[NKX];            // in-plane byte offset of the pixel, kBufOOB outside the image
+    int xg[NKX], xlds[NKX];
 #pragma unroll
-        for (int k = 0; k < NK_W; k++) {
-            const int idx = tid + NT * k;
-            const unsigned vo = idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB;
-            const f32x4 w1 = buf_load4(rs_w1, vo, 0u);
-            rw2[k] = buf_load4(rs_w2, vo, 0u);
-            if (idx < Cfg::W_SLOTS) sW[idx] = w1;
-        }
+    for (int k = 0; k < NKX; k++) {
+        const int idx = tid + NT * k;
+        const int g = idx / Cfg::XPIX, pix = idx - g * Cfg::XPIX;
+        const int pr = pix / XC, pc = pix - pr * XC;
+        const int iy = ty0 - 2 + pr, ix = tx0 - 2 + pc;
+        const bool in = idx < Cfg::NSLOT && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        xoff[k] = in ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : 4u) : kBufOOB;
+        xg[k] = g;
+        xlds[k] = idx < Cfg::NSLOT ? pix * PXB + g * 8 : -1;
     }
-
-    // ---- phase 1: gather + split the 12 x 36 input region ------------------------------------------------------------------
-    {
-        const buf_rsrc rs = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
-        const unsigned cs_x = (unsigned)p.x_cstride;
-        f32x4 rin[NKX];
-        int lds[NKX];
+    f32x4 rin[NKX];
+    f32x4 rw[NK_W];
+    auto gather_x = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < NKX; k++) {
-            const int idx = tid + NT * k;
-            const int g = idx / Cfg::XPIX, pix = idx - g * Cfg::XPIX;
-            const int pr = pix / XC, pc = pix - pr * XC;
-            const int iy = ty0 - 2 + pr, ix = tx0 - 2 + pc;
-            const bool in = idx < Cfg::NSLOT && 4 * g < p.cin_real && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            lds[k] = idx < Cfg::NSLOT ? pix * PXB + g * 8 : -1;
+            const int c0 = 16 * ch + 4 * xg[k];                          // first channel of the group
+            const bool ok = xoff[k] != kBufOOB && c0 < p.cin_real;
             if constexpr (XIL) {
-                rin[k] = buf_load4(rs, in ? (unsigned)(4 * g) * cs_x * 4u + (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB, 0u);
+                rin[k] = buf_load4(rs_x, ok ? (unsigned)c0 * cs_x * 4u + xoff[k] : kBufOOB, 0u);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    rin[k][j] = buf_load(rs, (in && 4 * g + j < p.cin_real) ? (unsigned)(4 * g + j) * cs_x * 4u + (unsigned)(iy * p.x_pitch + ix) * 4u : kBufOOB, 0u);
-            }
-        }
-        RT_TSTAMP();                              // 1: weights + input gathers issued
-#pragma unroll
-        for (int k = 0; k < NKX; k++) {
-            if (lds[k] < 0) continue;
-            const S3Split s = s3_split(rin[k]);
-            *reinterpret_cast<f16x4*>(sX + lds[k]) = s.hi;
-            *reinterpret_cast<f16x4*>(sX + lds[k] + 64) = s.lo;
-        }
-    }
-    RT_TSTAMP();                                  // 2: input split and written to LDS
-    __syncthreads();
-    RT_TSTAMP();                                  // 3: barrier
-
-    const int a_off = kg * 32 + l31;
-    auto contract = [&](const char* bp0, int row_pitch, f32x16& acc_m, f32x16& acc_c) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int r = t / 3, s = t % 3;
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const char* bp = bp0 + (r * row_pitch + s) * PXB + c * 32;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 64);
-                const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 0) * 64]);
-                const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + ((t * 2 + c) * 2 + 1) * 64]);
-                acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
-                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
-                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+                    rin[k][j] = buf_load(rs_x, (ok && c0 + j < p.cin_real) ? (unsigned)(c0 + j) * cs_x * 4u + xoff[k] : kBufOOB, 0u);
             }
         }
     };
-
-    // ---- phase 2: conv1 on the 10 x 34 region, column blocks wv, wv + 8 ---------------------------------------------------------
+    auto gather_w = [&](const float* w, int ch) {
+        const buf_rsrc rs_w = make_buf(w);
 #pragma unroll
-    for (int i = 0; i < Cfg::SEG_PER_WAVE; i++) {
-        const int seg = wv + Cfg::NW * i;
-        if (seg >= Cfg::TSEG) break;                               // wave-uniform
-        const int pt = seg * 32 + l31;                             // pixel of the intermediate region (row-major, 34 wide)
-        const int tr = pt / TC, tc = pt - tr * TC;
-        f32x16 acc_m, acc_c;
-        // taps (r, s) of intermediate pixel (tr, tc) read input-region pixels (tr + r, tc + s); blocks past the region read
-        // whatever follows sX (their columns are dropped below)
-        contract(sX + (tr * XC + tc) * PXB + kg * 16, XC, acc_m, acc_c);
-        const int gy = ty0 - 1 + tr, gx = tx0 - 1 + tc;
-        const bool inside = pt < Cfg::TPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        if (pt < Cfg::TPIX) {
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            rw[k] = buf_load4(rs_w, idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB, (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16));
+        }
+    };
+    auto stage_x = [&]() {
+#pragma unroll
+        for (int k = 0; k < NKX; k++) {
+            if (xlds[k] < 0) continue;
+            const S3Split s = s3_split(rin[k]);
+            *reinterpret_cast<f16x4*>(sX + xlds[k]) = s.hi;
+            *reinterpret_cast<f16x4*>(sX + xlds[k] + 32) = s.lo;
+        }
+    };
+    auto stage_w = [&]() {
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + NT * k;
+            if (idx < Cfg::W_SLOTS) sW[idx] = rw[k];
+        }
+    };
+    const int a_off = kg * 32 + l31;
+    // 9 taps x 3 MFMAs of one 16-channel chunk: B operand of tap (r, s) at bp0 + (r * row_pitch + s) pixels
+    auto contract = [&](const char* bp0, int row_pitch, f32x16& acc_m, f32x16& acc_c) {
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, s = t % 3;
+            const char* bp = bp0 + (r * row_pitch + s) * PXB;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 32);
+            const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 0) * 64]);
+            const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 1) * 64]);
+            acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+        }
+    };
+
+    // ---- conv1: column blocks wv and wv + 4 of the 6 x 34 intermediate region -----------------------------------------------------
+    int pt[SEGW], bx[SEGW];
+#pragma unroll
+    for (int i = 0; i < SEGW; i++) {
+        pt[i] = (wv + Cfg::NW * i) * 32 + l31;                     // intermediate pixel (row-major, 34 wide); >= TPIX: padding lanes
+        const int tr = pt[i] / TC, tc = pt[i] - tr * TC;
+        // taps (r, s) of intermediate pixel (tr, tc) read input-region pixels (tr + r, tc + s); padding lanes read pixel 0
+        bx[i] = (pt[i] < Cfg::TPIX ? (tr * XC + tc) * PXB : 0) + kg * 16;
+    }
+    f32x16 am[SEGW], ac[SEGW];
+#pragma unroll
+    for (int i = 0; i < SEGW; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { am[i][r] = 0.f; ac[i][r] = 0.f; }
+    const bool seg1 = wv + Cfg::NW < Cfg::TSEG;                     // wave-uniform: this wave has a second column block
+
+    gather_x(0);
+    gather_w(a.w1, 0);
+    RT_TSTAMP();                                  // 1: first gathers issued
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        if (ch) __syncthreads();                  // everyone finished reading the previous chunk
+        stage_x();
+        stage_w();
+        __syncthreads();
+        RT_TSTAMP();                              // 2, 4: chunk in LDS
+        if (ch == 0) { gather_x(1); gather_w(a.w1, 1); }
+        else gather_w(p.w, 0);                    // conv2's first weight chunk flies under conv1's last MFMAs
+        contract(sX + bx[0], XC, am[0], ac[0]);
+        if (seg1) contract(sX + bx[1], XC, am[1], ac[1]);
+        RT_TSTAMP();                              // 3, 5: MFMAs issued
+    }
+    // conv1 epilogue -> sT[chunk of the intermediate channel][pixel]
+#pragma unroll
+    for (int i = 0; i < SEGW; i++) {
+        if (i == 1 && !seg1) break;
+        if (pt[i] < Cfg::TPIX) {
+            const int tr = pt[i] / TC, tc = pt[i] - tr * TC;
+            const int gy = ty0 - 1 + tr, gx = tx0 - 1 + tc;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias1 + 8 * q + 4 * kg);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float v = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + bv[e], a.act1);
+                    const float v = apply_act_fast(fmaf(ac[i][4 * q + e], kSplitInv, am[i][4 * q + e]) + bv[e], a.act1);
                     o[e] = (inside && 8 * q + 4 * kg + e < a.cmid) ? v : 0.f;       // conv2 pads the intermediate with zeros
                 }
                 const S3Split s = s3_split(o);
-                *reinterpret_cast<f16x4*>(sT + pt * PXB + (8 * q + 4 * kg) * 2) = s.hi;
-                *reinterpret_cast<f16x4*>(sT + pt * PXB + (8 * q + 4 * kg) * 2 + 64) = s.lo;
+                char* dst = sT[q >> 1] + pt[i] * PXB + (8 * (q & 1) + 4 * kg) * 2;
+                *reinterpret_cast<f16x4*>(dst) = s.hi;
+                *reinterpret_cast<f16x4*>(dst + 32) = s.lo;
             }
         }
     }
-    RT_TSTAMP();                                  // 4: conv1 done (this wave)
-    __syncthreads();               // intermediate complete; nobody reads conv1's weights any more
-    RT_TSTAMP();                                  // 5: barrier
-#pragma unroll
-    for (int k = 0; k < NK_W; k++) {
-        const int idx = tid + NT * k;
-        if (idx < Cfg::W_SLOTS) sW[idx] = rw2[k];
-    }
+    RT_TSTAMP();                                  // 6: intermediate written
 
-    // ---- phase 3: residual request, conv2 on the 8 x 32 tile (row wv), epilogue ----------------------------------------------
+    // ---- conv2 on the 4 x 32 tile (row wv); residual requested first -----------------------------------------------------------------
     const int oy = ty0 + wv, ox = tx0 + l31;
     const bool inb = oy < p.Ho && ox < p.Wo;
     const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
@@ -820,11 +848,19 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
                     rr[q][e] = buf_load(rs_r, (8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((8 * q + e) * rs32) * 4u);
         }
     }
-    __syncthreads();               // conv2's weights are in LDS
-    RT_TSTAMP();                                  // 6: conv2's weights in LDS, residual requested
     f32x16 acc_m, acc_c;
-    contract(sT + (wv * TC + l31) * PXB + kg * 16, TC, acc_m, acc_c);
-    RT_TSTAMP();                                  // 7: conv2 MFMAs issued
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+    const int b2 = (wv * TC + l31) * PXB + kg * 16;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        __syncthreads();                          // conv1's (or the previous chunk's) weights are no longer read; sT complete
+        stage_w();
+        __syncthreads();
+        if (ch == 0) gather_w(p.w, 1);
+        contract(sT[ch] + b2, TC, acc_m, acc_c);
+        RT_TSTAMP();                              // 7, 8: conv2 MFMAs issued
+    }
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));
     const int act = p.act;
     auto epilogue = [&](auto ACT) {
@@ -849,7 +885,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
     if (act == 1) epilogue(std::integral_constant<int, 1>{});
     else if (act == 2) epilogue(std::integral_constant<int, 2>{});
     else epilogue(std::integral_constant<int, 0>{});
-    RT_TSTAMP();                                  // 8: stores issued
+    RT_TSTAMP();                                  // 9: stores issued
 #ifdef RT_KERNEL_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     if (dbgp && tid == 0) { dbgp[14] = __builtin_amdgcn_s_memtime(); dbgp[15] = __builtin_amdgcn_s_memrealtime() - rt0; }

@@ -680,7 +680,12 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     // RT_CONV_EXACT_FP32=1 keeps the fp32 fmaf-chain kernels
     const bool s3_win = (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
     sc.split3 = (!sc.direct && s3_win && env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3", 0) == 0) ? 1 : 0;
-    if (sc.split3) { sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4; }
+    if (sc.split3) {
+        sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4;
+        // 3x3 stride 1: 8-row tiles (8 waves, weights staged once per 8 rows, less halo) are built and opt-in (RT_S3_ROWS=8):
+        // measured on the 32->32 @629x185 layer 13.9 vs 14.5 us alone, but 2055 vs 2108 pairs/s in the network (4 contexts)
+        if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && env_int("RT_S3_ROWS", 4) == 8) sc.TY = sc.NW = 8;
+    }
 }
 
 // The persistent form is opt-in (RT_S3P=1).  Measured on MI355X, ResNet-18 2D 1257x369 (profiles/README.md, round 2): alone it
@@ -915,13 +920,14 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
     sc.cin_real = d1->Cin; sc.CinPad = 32; sc.CC = 16;
     const std::vector<float> wa = to_f32(w1, (size_t)d1->Cout * d1->Cin * 9, d1->dtype), wb = to_f32(w2, (size_t)d2->Cout * d2->Cin * 9, d2->dtype);
     const int c1 = d1->Cin, c2 = d2->Cin;
-    // first convolution: weights into a scratch SubConv (upload_s3p packs the LDS image), then moved to the plan
+    // both convolutions: split weights in conv_s3_kernel's slab order (two chunks of 16 input channels each)
+    sc.split3 = 1;
     SubConv tmp = sc;
     tmp.Cout = d1->Cout;
-    int rc = upload_s3p(tmp, c1, [&](int co, int ci, int u, int v) { return wa[(((size_t)co * c1 + ci) * 3 + u) * 3 + v]; });
+    int rc = upload_packed(tmp, c1, [&](int co, int ci, int u, int v) { return wa[(((size_t)co * c1 + ci) * 3 + u) * 3 + v]; });
     plan->rb_w1_dev = tmp.w_dev;
-    if (!rc) rc = upload_s3p(sc, c2, [&](int co, int ci, int u, int v) { return wb[(((size_t)co * c2 + ci) * 3 + u) * 3 + v]; });
-    sc.s3p = 0; sc.rb = 1; sc.TY = 8; sc.NW = 8; sc.TXW = 1; sc.NBW = 1;
+    if (!rc) rc = upload_packed(sc, c2, [&](int co, int ci, int u, int v) { return wb[(((size_t)co * c2 + ci) * 3 + u) * 3 + v]; });
+    sc.split3 = 0; sc.rb = 1; sc.TY = 4; sc.NW = 4; sc.TXW = 1; sc.NBW = 1;
     std::vector<int> table(sc.CinPad, -1);
     for (int c = 0; c < c1; c++) table[c] = c * d1->Hin * d1->Win;
     if (!rc) rc = upload_table(sc, table);
@@ -1704,10 +1710,10 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             ra.w1 = plan->rb_w1_dev; ra.bias1 = plan->rb_bias1_dev; ra.act1 = plan->rb_act1; ra.cmid = plan->rb_cmid;
             dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
             if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
-            if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(512), 0, S(s), ra);
-            else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, false>), rgrid, dim3(512), 0, S(s), ra);
-            else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, true>), rgrid, dim3(512), 0, S(s), ra);
-            else hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, false>), rgrid, dim3(512), 0, S(s), ra);
+            if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(256), 0, S(s), ra);
+            else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, false>), rgrid, dim3(256), 0, S(s), ra);
+            else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, true>), rgrid, dim3(256), 0, S(s), ra);
+            else hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, false>), rgrid, dim3(256), 0, S(s), ra);
             RT_LAUNCH_CHECK("conv_s3rb_kernel");
             continue;
         }
@@ -1721,6 +1727,13 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             if (env_int("RT_CONV_TRACE", 0))
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             bool launched = false;
+            if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
+                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, true, 8>), grid, dim3(512), 0, S(s), a);
+                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, false, 8>), grid, dim3(512), 0, S(s), a);
+                else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, false, true, 8>), grid, dim3(512), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, false, false, 8>), grid, dim3(512), 0, S(s), a);
+                launched = true;
+            }
 #define RT_S3(kh, kw, st)                                                                                                   \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                            \
         if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, true, true>), grid, dim3(256), 0, S(s), a);        \

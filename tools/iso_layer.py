@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""The dominant layer alone: 3x3 32->32 @629x185 (+bias, +residual, +ELU) on the executor's tensor layouts, or the fused
+residual block, launched back to back on an idle GPU.  For rocprofv3 passes (tools/pmc_layer.sh) and quick timings.
+
+    python tools/iso_layer.py [conv|block] [launches] [batch]
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redtail_amd import capi  # noqa: E402
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "conv"
+launches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+b = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+k = capi.KernelLib()
+H, W = 185, 629
+rng = np.random.default_rng(1)
+wt = (rng.standard_normal((32, 32, 3, 3)) / np.sqrt(288)).astype(np.float32)
+bias = rng.standard_normal(32).astype(np.float32)
+if kind == "block":
+    plan = k.resblock_plan(wt, bias, wt[::-1].copy(), bias, 32, 32, H, W)
+else:
+    plan = k.conv2d_plan(wt, bias, 32, 32, H, W, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
+plan.set_pitch(640, 640)
+plan.set_layouts(1, 1, 1)
+x = torch.randn(b, 32, H, 640, device="cuda")
+y = torch.empty_like(x)
+r = x if kind == "block" else torch.randn_like(x)
+for _ in range(3):
+    plan.enqueue(x, y, r, b)
+torch.cuda.synchronize()
+e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
+k.lib.rt_event_record(e0, None)
+for _ in range(launches):
+    plan.enqueue(x, y, r, b)
+k.lib.rt_event_record(e1, None)
+torch.cuda.synchronize()
+ms = ctypes.c_float()
+k.lib.rt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+print("%s batch %d: %.2f us per launch (%d launches back to back)" % (kind, b, ms.value * 1e3 / launches, launches))

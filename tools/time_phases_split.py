@@ -31,7 +31,7 @@ plan.set_pitch(640, 640)
 plan.set_layouts(1, 1, 1)
 x = torch.randn(b, 32, h, 640, device="cuda")
 y, r = torch.empty_like(x), (x if block else torch.randn_like(x))
-nwg = 24 * 20 * b if block else (47 * 20 * b if general else 256)
+nwg = 47 * 20 * b if block else (47 * 20 * b if general else 256)
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     plan.enqueue(x, y, r, b)
@@ -42,8 +42,9 @@ torch.cuda.synchronize()
 t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
 t = t[t[:, 0] > 0]
 if block:
-    names = ["start", "loads issued", "x split -> LDS", "barrier", "conv1 done", "barrier", "W2 in LDS", "conv2 MFMAs issued", "stores issued"]
-    last = 8
+    names = ["start", "gathers issued", "c0 in LDS", "conv1 c0 MFMAs", "c1 in LDS", "conv1 c1 MFMAs", "t written", "conv2 c0 MFMAs",
+             "conv2 c1 MFMAs", "stores issued"]
+    last = 9
 elif general:
     names = ["start", "loads issued", "c0 in LDS", "c0 MFMAs issued", "c1 in LDS", "c1 MFMAs issued", "stores issued"]
     last = 6
