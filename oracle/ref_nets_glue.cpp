@@ -38,7 +38,9 @@ struct RefNet {
 }
 
 // model: 0 resnet18_2D (513x257), 1 nvsmall (1025x321), 2 nvtiny (513x161), 3 resnet18 (1025x321)
-extern "C" void* ref_net_create(int model, int width, int height, const void* blob, size_t bytes) {
+// half != 0: the blob holds fp16 weights and the network is built the way sample_app/main.cpp does for `fp16`
+// (main.cpp:126, 248, 256-262): Weights of type kHALF, plugins created for kHALF (ResNet-18 2D only), setHalf2Mode(true)
+static void* create(int model, int width, int height, const void* blob, size_t bytes, int half) {
     auto* n = new RefNet();
     n->blob.assign((const char*)blob, (const char*)blob + bytes);
     size_t off = 0;
@@ -48,19 +50,20 @@ extern "C" void* ref_net_create(int model, int width, int height, const void* bl
         uint32_t count;
         memcpy(&count, n->blob.data() + off, 4);
         off += 4;
-        n->weights[name] = Weights{DataType::kFLOAT, n->blob.data() + off, (int64_t)count};
-        off += (size_t)count * 4;
+        n->weights[name] = Weights{half ? DataType::kHALF : DataType::kFLOAT, n->blob.data() + off, (int64_t)count};
+        off += (size_t)count * (half ? 2 : 4);
     }
     n->plugins = IPluginContainer::create(n->log);
     IBuilder* b = createInferBuilder(n->log);
     DimsCHW d{3, height, width};
     INetworkDefinition* net = nullptr;
-    if (model == 0) net = createResNet18_2D_513x257Network(*b, *n->plugins, d, n->weights, DataType::kFLOAT, n->log);
+    if (model == 0) net = createResNet18_2D_513x257Network(*b, *n->plugins, d, n->weights, half ? DataType::kHALF : DataType::kFLOAT, n->log);
     if (model == 1) net = createNVSmall1025x321Network(*b, *n->plugins, d, n->weights, DataType::kFLOAT, n->log);
     if (model == 2) net = createNVTiny513x161Network(*b, *n->plugins, d, n->weights, DataType::kFLOAT, n->log);
     if (model == 3) net = createResNet18_1025x321Network(*b, *n->plugins, d, n->weights, DataType::kFLOAT, n->log);
     if (net) {
         b->setMaxBatchSize(1);
+        b->setHalf2Mode(half != 0);
         n->engine = b->buildCudaEngine(*net);
         net->destroy();
     }
@@ -68,6 +71,12 @@ extern "C" void* ref_net_create(int model, int width, int height, const void* bl
     if (!n->engine) { delete n; return nullptr; }
     n->ctx = n->engine->createExecutionContext();
     return n;
+}
+extern "C" void* ref_net_create(int model, int width, int height, const void* blob, size_t bytes) {
+    return create(model, width, height, blob, bytes, 0);
+}
+extern "C" void* ref_net_create_half(int model, int width, int height, const void* blob, size_t bytes) {
+    return create(model, width, height, blob, bytes, 1);
 }
 extern "C" int ref_net_execute(void* h, void* left, void* right, void* disp) {
     auto* n = (RefNet*)h;

@@ -144,12 +144,41 @@ def build_ref_link_check(force=False):
     return out
 
 
+def build_sample_app(force=False, emu=False):
+    """Compiles the REFERENCE's sample application -- stereoDNN/sample_app/main.cpp and its four generated network
+    builders, untouched and where they lie -- against our NvInfer.h / redtail_tensorrt_plugins.h / cuda_runtime_api.h and
+    the test-only OpenCV subset in tests/shim/, and links it to libnvstereo_inference.so: "sample_app links unchanged".
+    Output: oracle/_ref/nvstereo_sample_app (git-ignored, travels to the GPU box); emu=True links the emulator build of
+    the libraries instead (CPU tier).  Skipped when /root/reference is absent."""
+    ref = os.environ.get("RT_REFERENCE", "/root/reference")
+    app = os.path.join(ref, "stereoDNN", "sample_app")
+    if not os.path.isdir(app):
+        return None
+    outdir = EMU_BUILD if emu else os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "nvstereo_sample_app_emu" if emu else "nvstereo_sample_app")
+    srcs = [os.path.join(app, f) for f in ("main.cpp", "resnet18_2D_513x257_net.cpp", "nvtiny_513x161_net.cpp",
+                                           "nvsmall_1025x321_net.cpp", "resnet18_1025x321_net.cpp")]
+    host = build_host_emu() if emu else build_host()
+    kern = build_emu() if emu else build_hip()
+    shim = os.path.join(ROOT, "tests", "shim")
+    if force or _newer(out, srcs + [host, shim]):
+        libdir, libname = os.path.split(host)
+        _run([GXX, "-std=c++17", "-O1", "-w", "-DNDEBUG", "-I", shim, "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(ROOT, "redtail_amd", "include"), "-I", app] + srcs +
+             ["-L", libdir, "-l:" + libname, "-l:" + os.path.basename(kern), "-lz",
+              "-Wl,-rpath,$ORIGIN/../../redtail_amd/lib", "-Wl,-rpath," + libdir, "-o", out])
+    return out
+
+
 def main(argv):
     what = argv or ["hip", "host", "emu"]
     if "hip" in what:
         build_hip()
     if "host" in what:
         build_host()
+    if "apps" in what:
+        build_sample_app()
     if "emu" in what:
         build_emu()
         if os.path.exists(os.path.join(CSRC, "host", "engine.cpp")):

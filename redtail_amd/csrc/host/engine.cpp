@@ -424,6 +424,7 @@ private:
     void fuseResBlocks();
     bool ok_ = false;
     bool half2_ = false;
+    std::vector<IPlugin*> half_plugins_;   // IPluginExt instances that only accept kHALF
 public:
     std::vector<std::unique_ptr<char[]>> weight_store_;   // weight bytes of a deserialised plan (Weights.values point here)
 };
@@ -450,10 +451,10 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
             DataType type = ext->supportsFormat(DataType::kFLOAT, PluginFormat::kNCHW) ? DataType::kFLOAT : DataType::kHALF;
             PluginFormat fmt = PluginFormat::kNCHW;
             if (!ext->supportsFormat(type, fmt)) fmt = PluginFormat::kNC2HW2;
-            if (type != DataType::kFLOAT) {
-                log_.log(ILogger::Severity::kERROR, (l->name + ": fp16 activation tensors are not supported by this engine build").c_str());
-                return;
-            }
+            // A plugin created for kHALF (the sample application passes its fp16 data type to the ResNet-18 2D builder,
+            // sample_app/main.cpp:248, 256-262) is configured with the type it asks for; it may only be used through the fused
+            // launches below -- which take whatever storage type the executor gives the tensors -- never through its own enqueue()
+            if (type != DataType::kFLOAT) half_plugins_.push_back(l->plugin);
             ext->configureWithFormat(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), type, fmt, max_batch_);
         } else {
             l->plugin->configure(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), max_batch_);
@@ -461,6 +462,13 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
         workspace_bytes_ = std::max(workspace_bytes_, l->plugin->getWorkspaceSize(max_batch_));
     }
     ok_ = lower();
+    if (ok_)
+        for (auto& op : ops_)
+            if (op.kind == OpKind::kPlugin && std::find(half_plugins_.begin(), half_plugins_.end(), op.plugin) != half_plugins_.end()) {
+                log_.log(ILogger::Severity::kERROR, (op.name + ": a plugin created for fp16 tensors would have to run on its own (not fused): "
+                                                     "fp16 plugin tensors are not supported by this engine build").c_str());
+                ok_ = false;
+            }
     if (ok_) fuseResBlocks();
     if (ok_) assignPitch();
     if (ok_) assignStreams();

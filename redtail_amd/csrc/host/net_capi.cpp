@@ -100,7 +100,10 @@ int build(rtStereoNet** out, int model, int width, int height, int max_batch, in
     n->plugins = IPluginContainer::create(n->log);
     IBuilder* builder = createInferBuilder(n->log);
     const DimsCHW dims{3, height, width};
-    // like sample_app/main.cpp:228-256 the plugins' DataType stays kFLOAT: activations are fp32 tensors
+    // The sample application keeps the plugins' DataType at kFLOAT for the 3-D models and passes its command-line data
+    // type to the ResNet-18 2D builder (sample_app/main.cpp:228-256).  Here the plugin type stays kFLOAT for every model: what
+    // an fp16 weight file switches on is half2 mode of the builder (fp16 storage between fused launches), and the executor
+    // also accepts plugins created for kHALF as long as they are fused away (tests/test_sample_app.py drives that path)
     const DataType act_type = DataType::kFLOAT;
     INetworkDefinition* net = nullptr;
     switch (model) {

@@ -31,8 +31,11 @@ def stage_reference_weights(reference=None):
     staged = []
     if not os.path.isdir(src_root):
         return staged
-    for rel in sorted(set(FILES.values())):
-        src, dst = os.path.join(src_root, rel), os.path.join(WEIGHT_DIR, rel)
+    todo = [(os.path.join(src_root, rel), os.path.join(WEIGHT_DIR, rel)) for rel in sorted(set(FILES.values()))]
+    # the sample application's stereo pair (sample_app/data/img_{left,right}.png)
+    todo += [(os.path.join(reference, "stereoDNN", "sample_app", "data", f), os.path.join(WEIGHT_DIR, "sample", f))
+             for f in ("img_left.png", "img_right.png")]
+    for src, dst in todo:
         if not os.path.exists(src):
             continue
         if not os.path.exists(dst) or os.path.getsize(dst) != os.path.getsize(src):
@@ -40,6 +43,14 @@ def stage_reference_weights(reference=None):
             shutil.copyfile(src, dst)
         staged.append(dst)
     return staged
+
+
+def sample_image(side):
+    """the reference sample application's left / right PNG, staged next to the weights"""
+    path = os.path.join(WEIGHT_DIR, "sample", "img_%s.png" % side)
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s is missing: run `python __graft_entry__.py` where /root/reference exists" % path)
+    return path
 
 
 def weight_file(model, fp16=False):

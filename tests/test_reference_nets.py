@@ -76,6 +76,30 @@ def test_reference_generated_resnet18_2d_on_emulator():
     net.destroy()
 
 
+def test_reference_generated_resnet18_2d_fp16_on_emulator():
+    """the way sample_app/main.cpp builds ResNet-18 2D for `fp16`: kHALF weights, plugins created for kHALF, half2 mode.
+    The executor fuses every such plugin away and stores the tensors as it does for our own builder with an fp16 weight
+    file: same launches, same bits (round 1 rejected the kHALF plugins)"""
+    ref = load_ref_emu()
+    ref.ref_net_create_half.restype = ctypes.c_void_p
+    ref.ref_net_create_half.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    netlib = capi.NetLib(build.build_host_emu(), build.build_emu())
+    w, h = 33, 17
+    blob = capi.pack_weights(synth.synth_weights_resnet18_2d(), fp16=True)
+    l, r = synth.synth_pair(h, w)
+    L, R = l[None].copy(), r[None].copy()
+    ours, theirs = np.full((1, 1, h, w), np.nan, np.float32), np.full((1, 1, h, w), np.nan, np.float32)
+    net = netlib.create("resnet18_2D", w, h, weights=blob, fp16_weights=True)
+    net.execute(L, R, ours, 1)
+    hnd = ref.ref_net_create_half(0, w, h, blob, len(blob))
+    assert hnd, "the reference-generated builder failed for DataType::kHALF"
+    assert ref.ref_net_execute(hnd, L.ctypes.data, R.ctypes.data, theirs.ctypes.data) == 0
+    assert ref.ref_net_num_launches(hnd) == net.num_launches
+    assert np.array_equal(ours, theirs) and not np.isnan(ours).any()
+    ref.ref_net_destroy(hnd)
+    net.destroy()
+
+
 def load_ref_emu():
     """same reference sources, linked against the emulator build of our libraries"""
     app = "/root/reference/stereoDNN/sample_app"
