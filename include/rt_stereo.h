@@ -113,6 +113,12 @@ int rt_corr_softargmax_il(const void* left, const void* right, void* out, int ba
  * TransformPlugin::enqueue -> cudnnTransformTensor (lib/transform_plugin.cpp:94-108). */
 int rt_permute4d(const void* x, void* y, int batch, int d0, int d1, int d2, int d3, const int order[4],
                  int dtype, rtStream stream);
+/* Format conversion at a plugin boundary -- the "reformat" TensorRT inserts between its fp32 tensors and an IPluginExt that
+ * asked for kHALF (reference lib/elu_plugin.cpp:45-53, lib/cost_volume_plugin.cpp:60-66; tests_main.cpp:301-321, 988-1026).
+ * Kinds: 0 = fp32 NCHW, 1 = fp16 NCHW, 2 = fp16 NC2HW2 (channel pairs of a pixel in one 4-byte slot, odd C zero padded).
+ * x / y: (batch, C, inner) with inner = the product of the remaining dims. */
+int rt_convert_format(const void* x, void* y, int batch, int C, int64_t inner, int src_kind, int dst_kind, rtStream stream);
+
 /* (N,D,inner) -> (N,D+pad_end,inner): copy + zero tail.  PaddingPlugin::enqueue (lib/padding_plugin.cpp:79-94). */
 int rt_pad_d(const void* x, void* y, int batch, int D, int64_t inner, int pad_end, int dtype, rtStream stream);
 /* (N,D,inner) -> (N,end-start,inner).  SlicePlugin::enqueue (lib/slice_plugin.cpp:80-92). */

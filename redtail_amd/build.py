@@ -171,6 +171,30 @@ def build_sample_app(force=False, emu=False):
     return out
 
 
+def build_reference_tests(force=False, emu=False):
+    """Compiles the REFERENCE's plugin test suite -- stereoDNN/tests/tests_main.cpp, 23 googletest cases that drive every
+    plugin through the public C++ API (one-plugin networks, addShuffle for 4-D inputs, build -> execute -> destroy) on its
+    TensorFlow-generated golden tensors -- untouched, against our headers, the test-only googletest / OpenCV subsets in
+    tests/shim/ and libnvstereo_inference.so.  Output: oracle/_ref/nvstereo_tests (emu=True: the emulator build)."""
+    ref = os.environ.get("RT_REFERENCE", "/root/reference")
+    src = os.path.join(ref, "stereoDNN", "tests", "tests_main.cpp")
+    if not os.path.exists(src):
+        return None
+    outdir = EMU_BUILD if emu else os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "nvstereo_tests_emu" if emu else "nvstereo_tests")
+    host = build_host_emu() if emu else build_host()
+    kern = build_emu() if emu else build_hip()
+    shim = os.path.join(ROOT, "tests", "shim")
+    if force or _newer(out, [src, host, shim]):
+        libdir, libname = os.path.split(host)
+        _run([GXX, "-std=c++17", "-O1", "-w", "-I", shim, "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(ROOT, "redtail_amd", "include"), src, os.path.join(shim, "gtest_glue.cpp"),
+              "-L", libdir, "-l:" + libname, "-l:" + os.path.basename(kern), "-lz",
+              "-Wl,-rpath,$ORIGIN/../../redtail_amd/lib", "-Wl,-rpath," + libdir, "-o", out])
+    return out
+
+
 def main(argv):
     what = argv or ["hip", "host", "emu"]
     if "hip" in what:
@@ -179,6 +203,7 @@ def main(argv):
         build_host()
     if "apps" in what:
         build_sample_app()
+        build_reference_tests()
     if "emu" in what:
         build_emu()
         if os.path.exists(os.path.join(CSRC, "host", "engine.cpp")):

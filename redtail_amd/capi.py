@@ -63,6 +63,7 @@ KERNEL_SYMBOLS = {
     "rt_corr_softargmax_pitched": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_corr_softargmax_il": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_void_p]),
     "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
+    "rt_convert_format": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_slice_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "rt_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),

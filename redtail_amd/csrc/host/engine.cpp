@@ -309,6 +309,7 @@ struct Op {
     IStereoPlugin* splugin = nullptr;  // kConv3D
     int max_disp = 0, is_min = 0;      // kCorrSoftargmax
     bool il_in = false;                // kCorrSoftargmax: channel-interleaved feature maps -> matrix-core kernel
+    int half_kind = 0;                 // kPlugin created for kHALF: 1 = fp16 NCHW, 2 = fp16 NC2HW2 (tensors are converted around it)
     int stream = 0;
     std::vector<int> wait_on;          // tensors produced on the other stream that this op consumes
     bool publish = false;              // another stream consumes the result: record an event after the launch
@@ -347,6 +348,8 @@ private:
     std::vector<void*> prof_events_;   // start/stop pair per launch (IProfiler)
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
+    std::map<std::pair<int, int>, std::pair<void*, size_t>> half_buf_;   // (op, slot) -> fp16 staging buffer of a kHALF plugin
+    void* halfBuffer(int op, int slot, size_t bytes);
 };
 
 class HostMemory : public IHostMemory {
@@ -424,7 +427,8 @@ private:
     void fuseResBlocks();
     bool ok_ = false;
     bool half2_ = false;
-    std::vector<IPlugin*> half_plugins_;   // IPluginExt instances that only accept kHALF
+    std::vector<IPlugin*> half_plugins_;   // IPluginExt instances that only accept kHALF ...
+    std::vector<int> half_kinds_;          // ... and the format they were configured with (1 = NCHW, 2 = NC2HW2)
 public:
     std::vector<std::unique_ptr<char[]>> weight_store_;   // weight bytes of a deserialised plan (Weights.values point here)
 };
@@ -454,7 +458,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
             // A plugin created for kHALF (the sample application passes its fp16 data type to the ResNet-18 2D builder,
             // sample_app/main.cpp:248, 256-262) is configured with the type it asks for; it may only be used through the fused
             // launches below -- which take whatever storage type the executor gives the tensors -- never through its own enqueue()
-            if (type != DataType::kFLOAT) half_plugins_.push_back(l->plugin);
+            if (type != DataType::kFLOAT) { half_plugins_.push_back(l->plugin); half_kinds_.push_back(fmt == PluginFormat::kNCHW ? 1 : 2); }
             ext->configureWithFormat(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), type, fmt, max_batch_);
         } else {
             l->plugin->configure(in_dims.data(), (int)in_dims.size(), out_dims.data(), (int)out_dims.size(), max_batch_);
@@ -462,13 +466,14 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
         workspace_bytes_ = std::max(workspace_bytes_, l->plugin->getWorkspaceSize(max_batch_));
     }
     ok_ = lower();
+    // a kHALF plugin that was not fused away runs on its own enqueue(): the executor converts its fp32 tensors to the format
+    // it was configured with and back (TensorRT's reformat layers; reference tests_main.cpp:301-321, 988-1026)
     if (ok_)
-        for (auto& op : ops_)
-            if (op.kind == OpKind::kPlugin && std::find(half_plugins_.begin(), half_plugins_.end(), op.plugin) != half_plugins_.end()) {
-                log_.log(ILogger::Severity::kERROR, (op.name + ": a plugin created for fp16 tensors would have to run on its own (not fused): "
-                                                     "fp16 plugin tensors are not supported by this engine build").c_str());
-                ok_ = false;
-            }
+        for (auto& op : ops_) {
+            if (op.kind != OpKind::kPlugin) continue;
+            auto it = std::find(half_plugins_.begin(), half_plugins_.end(), op.plugin);
+            if (it != half_plugins_.end()) op.half_kind = half_kinds_[it - half_plugins_.begin()];
+        }
     if (ok_) fuseResBlocks();
     if (ok_) assignPitch();
     if (ok_) assignStreams();
@@ -1107,6 +1112,8 @@ ContextImpl::~ContextImpl() {
     for (void* b : buffers_)
         if (b) rt_free(b);
     if (workspace_) rt_free(workspace_);
+    for (auto& kv : half_buf_)
+        if (kv.second.first) rt_free(kv.second.first);
     for (void* ev : events_)
         if (ev) rt_event_destroy(ev);
     for (void* ev : prof_events_)
@@ -1118,6 +1125,18 @@ ContextImpl::~ContextImpl() {
 }
 
 const ICudaEngine& ContextImpl::getEngine() const { return eng_; }
+
+void* ContextImpl::halfBuffer(int op, int slot, size_t bytes) {
+    auto& e = half_buf_[{op, slot}];
+    if (e.second < bytes) {
+        if (e.first) rt_free(e.first);
+        e.first = nullptr;
+        e.second = 0;
+        if (rt_malloc(&e.first, bytes) != 0) return nullptr;
+        e.second = bytes;
+    }
+    return e.first;
+}
 
 bool ContextImpl::ensureBuffers(int batch) {
     if (batch <= alloc_batch_) return true;
@@ -1222,6 +1241,23 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 const void* ins[8];
                 for (size_t i = 0; i < op.in.size() && i < 8; i++) ins[i] = addr(op.in[i], batch, bindings);
                 void* outs[1] = {y};
+                if (op.half_kind) {         // fp32 tensors <-> the fp16 format the plugin was configured with
+                    auto halfs = [&](const Dims& d) { return (size_t)(op.half_kind == 2 ? (d.d[0] + 1) / 2 * 2 : d.d[0]) * (volume(d) / d.d[0]); };
+                    for (size_t i = 0; i < op.in.size() && i < 8 && rc == 0; i++) {
+                        const Dims& d = eng_.tensors_[op.in[i]]->dims;
+                        void* hb = halfBuffer((int)op_index, (int)i, halfs(d) * 2 * (size_t)batch);
+                        rc = hb ? rt_convert_format(ins[i], hb, batch, d.d[0], (int64_t)(volume(d) / d.d[0]), 0, op.half_kind, st) : RT_E_NOMEM;
+                        ins[i] = hb;
+                    }
+                    void* ho = rc == 0 ? halfBuffer((int)op_index, 8, halfs(out.dims) * 2 * (size_t)batch) : nullptr;
+                    if (rc == 0 && !ho) rc = RT_E_NOMEM;
+                    if (rc == 0) {
+                        outs[0] = ho;
+                        rc = op.plugin->enqueue(batch, ins, outs, workspace_, (cudaStream_t)st);
+                    }
+                    if (rc == 0) rc = rt_convert_format(ho, y, batch, out.dims.d[0], (int64_t)(volume(out.dims) / out.dims.d[0]), op.half_kind, 0, st);
+                    break;
+                }
                 rc = op.plugin->enqueue(batch, ins, outs, workspace_, (cudaStream_t)st);
                 break;
             }

@@ -38,4 +38,31 @@ permute4d_kernel(const T* __restrict__ x, T* __restrict__ y, int o0, int o1, int
     }
 }
 
+// Tensor format conversion at a plugin boundary -- what TensorRT inserts ("reformat" layers) between an fp32 tensor and
+// an IPluginExt that asked for kHALF in kNCHW or kNC2HW2 (reference tests_main.cpp:301-321, 988-1026): kinds
+// 0 = fp32 NCHW, 1 = fp16 NCHW, 2 = fp16 NC2HW2 (channel pairs (2i, 2i+1) of a pixel in one 4-byte slot, odd C zero padded).
+// One thread per (sample, channel pair, pixel).
+__device__ static __forceinline__ float cvt_load(const void* p, int kind, int64_t n, int C, int64_t inner, int c, int64_t i) {
+    if (c >= C) return 0.f;
+    if (kind == 0) return static_cast<const float*>(p)[(n * C + c) * inner + i];
+    if (kind == 1) return (float)static_cast<const _Float16*>(p)[(n * C + c) * inner + i];
+    return (float)static_cast<const _Float16*>(p)[((n * ((C + 1) / 2) + c / 2) * inner + i) * 2 + (c & 1)];
+}
+__device__ static __forceinline__ void cvt_store(void* p, int kind, int64_t n, int C, int64_t inner, int c, int64_t i, float v) {
+    if (kind == 2) { static_cast<_Float16*>(p)[((n * ((C + 1) / 2) + c / 2) * inner + i) * 2 + (c & 1)] = (_Float16)(c < C ? v : 0.f); return; }
+    if (c >= C) return;
+    if (kind == 0) static_cast<float*>(p)[(n * C + c) * inner + i] = v;
+    else static_cast<_Float16*>(p)[(n * C + c) * inner + i] = (_Float16)v;
+}
+__global__ void __launch_bounds__(256)
+convert_format_kernel(const void* __restrict__ src, void* __restrict__ dst, int C, int64_t inner, int src_kind, int dst_kind) {
+    const int64_t n = blockIdx.z;
+    const int cp = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += stride) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) cvt_store(dst, dst_kind, n, C, inner, 2 * cp + h, i, cvt_load(src, src_kind, n, C, inner, 2 * cp + h, i));
+    }
+}
+
 }  // namespace rt

@@ -372,6 +372,16 @@ extern "C" int rt_permute4d(const void* x, void* y, int batch, int d0, int d1, i
     return 0;
 }
 
+extern "C" int rt_convert_format(const void* x, void* y, int batch, int C, int64_t inner, int src_kind, int dst_kind, rtStream s) {
+    RT_REQUIRE(x && y && batch > 0 && C > 0 && inner > 0, "rt_convert_format: bad arguments");
+    RT_REQUIRE(src_kind >= 0 && src_kind <= 2 && dst_kind >= 0 && dst_kind <= 2, "rt_convert_format: kinds are 0 (fp32 NCHW), 1 (fp16 NCHW), 2 (fp16 NC2HW2)");
+    RT_REQUIRE(batch <= 65535 && (C + 1) / 2 <= 65535, "rt_convert_format: grid too large");
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(rt::cdiv(inner, 256), 4096)), (unsigned)((C + 1) / 2), (unsigned)batch);
+    hipLaunchKernelGGL(rt::convert_format_kernel, grid, dim3(256), 0, S(s), x, y, C, inner, src_kind, dst_kind);
+    RT_LAUNCH_CHECK("convert_format_kernel");
+    return 0;
+}
+
 extern "C" int rt_pad_d(const void* x, void* y, int batch, int D, int64_t inner, int pad_end, int dtype, rtStream s) {
     RT_REQUIRE(x && y && batch > 0 && D > 0 && inner > 0 && pad_end >= 0, "rt_pad_d: bad arguments");
     return copy_rows(x, y, batch, D * inner, D * inner, (D + pad_end) * inner, pad_end * inner, dtype, S(s));

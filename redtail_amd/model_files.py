@@ -35,6 +35,10 @@ def stage_reference_weights(reference=None):
     # the sample application's stereo pair (sample_app/data/img_{left,right}.png)
     todo += [(os.path.join(reference, "stereoDNN", "sample_app", "data", f), os.path.join(WEIGHT_DIR, "sample", f))
              for f in ("img_left.png", "img_right.png")]
+    # the golden tensors of the reference's plugin tests (stereoDNN/tests/data/*.bin), for oracle/_ref/nvstereo_tests
+    data = os.path.join(reference, "stereoDNN", "tests", "data")
+    if os.path.isdir(data):
+        todo += [(os.path.join(data, f), os.path.join(WEIGHT_DIR, "tests_data", f)) for f in sorted(os.listdir(data)) if f.endswith(".bin")]
     for src, dst in todo:
         if not os.path.exists(src):
             continue
@@ -49,6 +53,14 @@ def sample_image(side):
     """the reference sample application's left / right PNG, staged next to the weights"""
     path = os.path.join(WEIGHT_DIR, "sample", "img_%s.png" % side)
     if not os.path.exists(path):
+        raise FileNotFoundError("%s is missing: run `python __graft_entry__.py` where /root/reference exists" % path)
+    return path
+
+
+def tests_data_dir():
+    """stereoDNN/tests/data as staged next to the weights"""
+    path = os.path.join(WEIGHT_DIR, "tests_data")
+    if not os.path.isdir(path):
         raise FileNotFoundError("%s is missing: run `python __graft_entry__.py` where /root/reference exists" % path)
     return path
 

@@ -20,6 +20,7 @@
 
 #define CV_8U 0
 #define CV_16U 2
+#define CV_16S 3
 #define CV_32F 5
 #define CV_BGR2RGB 4
 
@@ -40,6 +41,7 @@ public:
     Mat() {}
     Mat(int r, int c, int depth, int cn = 1) { create(r, c, depth, cn); }
     Mat(int r, int c, int depth, void* ext) : rows(r), cols(c), data(static_cast<uchar*>(ext)), depth_(depth), cn_(1) {}   // wraps, no copy
+    explicit Mat(const std::vector<float>& v) : rows((int)v.size()), cols(1), data(reinterpret_cast<uchar*>(const_cast<float*>(v.data()))), depth_(CV_32F), cn_(1) {}
 
     void create(int r, int c, int depth, int cn) {
         rows = r; cols = c; depth_ = depth; cn_ = cn;
@@ -85,7 +87,7 @@ public:
     Mat& operator/=(double k) { return scale(1.0 / k, k); }
 
 private:
-    static size_t esz(int depth) { return depth == CV_8U ? 1 : depth == CV_16U ? 2 : 4; }
+    static size_t esz(int depth) { return depth == CV_8U ? 1 : (depth == CV_16U || depth == CV_16S) ? 2 : 4; }
     Mat& scale(double k, double div = 0) {
         assert(depth_ == CV_32F);
         float* p = reinterpret_cast<float*>(data);
@@ -231,6 +233,53 @@ inline void resize(const Mat& src, Mat& dst, Size sz, double, double, int interp
             }
     }
     dst = out;
+}
+
+// fp32 <-> IEEE half stored as CV_16S (tests_main.cpp:200-201, 237-238); round to nearest even, no _Float16 in g++ 11
+namespace detail {
+inline uint16_t f2h(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                    // overflow -> inf
+    if (x < 0x38800000u) {                                                      // subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t r = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        m >>= shift;
+        if (r > half || (r == half && (m & 1))) m++;
+        return (uint16_t)(sign | m);
+    }
+    uint32_t m = x - 0x38000000u;
+    const uint32_t r = m & 0x1fffu;
+    m >>= 13;
+    if (r > 0x1000u || (r == 0x1000u && (m & 1))) m++;
+    return (uint16_t)(sign | m);
+}
+inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; s++; } x = sign | ((uint32_t)(113 - s) << 23) | ((mm & 0x3ffu) << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; std::memcpy(&f, &x, 4);
+    return f;
+}
+}  // namespace detail
+inline void convertFp16(const Mat& src, Mat& dst) {
+    const size_t n = src.total() * src.channels();
+    if (src.depth() == CV_32F) {
+        Mat out(src.rows, src.cols, CV_16S, src.channels());
+        for (size_t i = 0; i < n; i++) out.ptr<uint16_t>()[i] = detail::f2h(src.ptr<float>()[i]);
+        dst = out;
+    } else {
+        Mat out(src.rows, src.cols, CV_32F, src.channels());
+        for (size_t i = 0; i < n; i++) out.ptr<float>()[i] = detail::h2f(src.ptr<uint16_t>()[i]);
+        dst = out;
+    }
 }
 
 inline void cvtColor(const Mat& src, Mat& dst, int code) {

@@ -66,3 +66,60 @@ def test_two_rank_broadcast_and_sharding(tmp_path):
     with torch.no_grad():
         ref = O.resnet18_2d(torch.from_numpy(np.stack(ls)), torch.from_numpy(np.stack(rs)), weights, max_disp=6).numpy()
     assert np.abs(out - ref).max() <= 1e-3
+
+
+# ---- GPU tier: the same code over RCCL (torch.distributed backend "nccl") ------------------------------------------------
+def _rccl_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import zlib
+    from redtail_amd import capi, model_files
+    blob = open(model_files.weight_file("resnet18_2D"), "rb").read() if rank == 0 else b""
+    blob = parallel.broadcast_blob(blob, rank, dev, dist)
+    crc = torch.tensor([zlib.crc32(blob) & 0xffffffff], dtype=torch.int64, device=dev)
+    crcs = [torch.zeros_like(crc) for _ in range(world)]
+    dist.all_gather(crcs, crc)
+    # every rank builds its engine from the broadcast image and runs its own pair
+    lib = capi.NetLib()
+    lib.kernels.check(lib.kernels.lib.rt_set_device(rank), "rt_set_device")
+    from redtail_amd import synth
+    w, h = 257, 129
+    net = lib.create("resnet18_2D", w, h, weights=blob)
+    l, r = synth.synth_pair(h, w, 1234 + rank)
+    out = torch.full((1, 1, h, w), float("nan"), device=dev)
+    net.execute(torch.from_numpy(l)[None].to(dev), torch.from_numpy(r)[None].to(dev), out, 1)
+    torch.cuda.synchronize(dev)
+    np.save(os.path.join(tmp, "out%d.npy" % rank), out.cpu().numpy())
+    if rank == 0:
+        np.save(os.path.join(tmp, "crcs.npy"), np.array([int(c.item()) for c in crcs]))
+        np.save(os.path.join(tmp, "world.npy"), np.array([dist.get_world_size()]))
+    net.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_broadcast_of_weights(tmp_path, world):
+    """bench.py's multi-GPU start-up over the real backend: rank 0 broadcasts the weight-file image with RCCL, every rank
+    checks it (crc32 all-gathered), builds its engine from it on ITS device and matches the oracle on its own pair.
+    World size 1 always runs; world size 2 when two devices are visible (the driver's multi-GPU node)."""
+    import zlib
+    from oracle import stereo_oracle as O
+    from redtail_amd import capi, model_files, synth
+    if torch.cuda.device_count() < world:
+        pytest.skip("%d visible device(s)" % torch.cuda.device_count())
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    path = model_files.weight_file("resnet18_2D")
+    want = zlib.crc32(open(path, "rb").read()) & 0xffffffff
+    assert list(np.load(tmp_path / "crcs.npy")) == [want] * world
+    assert int(np.load(tmp_path / "world.npy")[0]) == world
+    weights = capi.read_weights(path)
+    for rank in range(world):
+        l, r = synth.synth_pair(129, 257, 1234 + rank)
+        with torch.no_grad():
+            ref = O.resnet18_2d(torch.from_numpy(l)[None], torch.from_numpy(r)[None], weights).numpy()
+        assert np.abs(np.load(tmp_path / ("out%d.npy" % rank)) - ref).max() <= 1e-3
