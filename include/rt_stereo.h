@@ -224,6 +224,10 @@ typedef struct rtConv3dDesc {
     int in_pad_end;         /* conv only: the last in_pad_end of the D input slices are zeros that do not exist  */
                             /* in memory (x is (D - in_pad_end, C, H, W)) -- the Pad plugin emitted before every  */
                             /* stride-2 Conv3D (scripts/tensorrt_model_builder.py:331-345), in the same pass     */
+    int cv_fold;            /* conv only, executor: F > 0 = the input is the DEFAULT COST VOLUME of two (F,H,W) feature  */
+                            /* maps (C == 2F; CostVolumePlugin kDefault, lib/kernels.cu:50-97) that is never built:     */
+                            /* x points to the (2F, H, W) tensor [left | right] and slice d of the volume is gathered   */
+                            /* as cv[d, 0:F] = L, cv[d, F:2F, y, x] = R[:, y, x - d] (0 for x < d)                       */
 } rtConv3dDesc;
 
 /* TensorFlow-compatible 3-D convolution.  x (N, D,C,H,W) , w (K,V,C,R,S) 3x3x3 -> y (N, K,Do,Ho,Wo).

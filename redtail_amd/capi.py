@@ -30,7 +30,7 @@ class Conv3dDesc(ctypes.Structure):
     _fields_ = [("C", c_int), ("K", c_int), ("D", c_int), ("H", c_int), ("W", c_int), ("kernel", c_int * 3),
                 ("stride", c_int * 3), ("pad_start", c_int * 3), ("pad_end", c_int * 3), ("act", c_int),
                 ("out_dchw", c_int), ("has_residual", c_int), ("dtype", c_int), ("out_depth", c_int),
-                ("in_pad_end", c_int)]
+                ("in_pad_end", c_int), ("cv_fold", c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rt_stereo.h
@@ -202,10 +202,10 @@ class KernelLib:
         return ConvPlan(self, plan)
 
     def conv3d_plan(self, w_host, b_host, C, K, dims, kernel, stride, pad_start, pad_end, act=0, out_dchw=False,
-                    has_residual=False, dtype=RT_F32, transposed_in_dims=None, out_depth=0, in_pad_end=0):
+                    has_residual=False, dtype=RT_F32, transposed_in_dims=None, out_depth=0, in_pad_end=0, cv_fold=0):
         d = Conv3dDesc(C, K, dims[0], dims[1], dims[2], (c_int * 3)(*kernel), (c_int * 3)(*stride),
                        (c_int * 3)(*pad_start), (c_int * 3)(*pad_end), act, int(out_dchw), int(has_residual), dtype,
-                       out_depth, in_pad_end)
+                       out_depth, in_pad_end, cv_fold)
         plan = c_void_p()
         if transposed_in_dims is None:
             rc = self.lib.rt_conv3d_plan_create(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host))

@@ -424,6 +424,7 @@ private:
     void assignStreams();
     void assignPitch();
     void foldConcats();
+    void foldCostVolumes();
     void fuseResBlocks();
     bool ok_ = false;
     bool half2_ = false;
@@ -478,6 +479,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) assignPitch();
     if (ok_) assignStreams();
     if (ok_) foldConcats();
+    if (ok_) foldCostVolumes();
 }
 
 EngineImpl::~EngineImpl() {
@@ -941,6 +943,80 @@ void EngineImpl::fuseResBlocks() {
     if (fused)
         log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(fused) + " residual blocks fused into one launch each; " +
                                             std::to_string(ops_.size()) + " launches").c_str());
+}
+
+// The default cost volume is never built (reference CostVolumePlugin kDefault, lib/kernels.cu:50-97: a (D, 2F, H, W) tensor
+// of D shifted copies -- 1.0 GB per pair for NVSmall, 1.44 GB for ResNet-18 3D -- that the first Conv3D reads three times):
+// when its only consumer is a Conv3D plan, the two (F,H,W) feature maps become the halves of one (2F,H,W) buffer and the
+// convolution gathers slice d of the volume from it (rtConv3dDesc::cv_fold; the gather table's plane offsets + an x shift of
+// d for the right-image half).  The CostVolume launch disappears.
+void EngineImpl::foldCostVolumes() {
+    if (getenv("RT_NO_CV_FOLD") || getenv("RT_NO_FUSION")) return;
+    for (size_t ci = 0; ci < ops_.size(); ci++) {
+        const Op cv = ops_[ci];
+        if (cv.kind != OpKind::kPlugin) continue;
+        IStereoPlugin* sp = cv.plugin ? dynamic_cast<IStereoPlugin*>(cv.plugin) : nullptr;
+        if (!sp || sp->kind() != Kind::kCostVolume || sp->costVolumeType() != CostVolumeType::kDefault || cv.half_kind || cv.in.size() != 2) continue;
+        // the one consumer: a Conv3D launch reading the volume as its input
+        int ib = -1, uses = 0;
+        for (size_t j = 0; j < ops_.size(); j++) {
+            if (j == ci) continue;
+            for (int x : ops_[j].in)
+                if (root(x) == root(cv.out)) { uses++; ib = (int)j; }
+            if (ops_[j].resid >= 0 && root(ops_[j].resid) == root(cv.out)) uses += 2;
+        }
+        if (uses != 1 || ib < (int)ci || tensors_[cv.out]->is_output) continue;
+        Op& conv = ops_[ib];
+        if (conv.kind != OpKind::kConv3D || !conv.splugin || conv.splugin->kind() != Kind::kConv3D || root(conv.in[0]) != root(cv.out)) continue;
+        TensorImpl &l = *tensors_[cv.in[0]], &r = *tensors_[cv.in[1]];
+        bool ok = l.id != r.id && l.dims.nbDims == 3 && r.dims.nbDims == 3 && l.dims.d[0] % 4 == 0;
+        for (TensorImpl* t : {&l, &r}) {
+            ok = ok && !t->is_input && !t->is_output && t->alias_of < 0 && t->pitch == 0 && !t->f16 && !t->il8 && t->bstride == 0;
+            int producers = 0;
+            for (size_t oi = 0; oi < ops_.size() && ok; oi++) {
+                const Op& op = ops_[oi];
+                if (oi == ci) continue;
+                if (op.out == t->id) { producers++; ok = ok && op.kind == OpKind::kConv && oi < ci; }
+                if (op.resid == t->id) ok = false;
+                for (int x : op.in) ok = ok && x != t->id;
+            }
+            ok = ok && producers == 1;
+        }
+        if (!ok) continue;
+        const int F = l.dims.d[0];
+        ConvFusion f = conv.splugin->fusion();
+        f.cv_fold = F;
+        if (!conv.splugin->setFusion(f)) continue;             // window without a split-fp16 kernel: the volume is built as before
+        // the (2F, H, W) buffer [left | right]
+        std::unique_ptr<TensorImpl> fused(new TensorImpl());
+        fused->id = (int)tensors_.size();
+        fused->name = cv.name + "_features";
+        fused->dims = DimsCHW(2 * F, l.dims.d[1], l.dims.d[2]);
+        const int64_t plane = (int64_t)l.dims.d[1] * l.dims.d[2];
+        const int fid = fused->id;
+        fused->stream = conv.stream;
+        tensors_.push_back(std::move(fused));
+        bool failed = false;
+        int half = 0;
+        for (TensorImpl* t : {&l, &r}) {
+            t->alias_of = fid;
+            t->alias_off = (int64_t)half * F * plane;
+            t->bstride = 2 * (int64_t)F * plane;
+            half++;
+            for (auto& op : ops_)
+                if (op.kind == OpKind::kConv && op.out == t->id && rt_conv_plan_set_batch_strides(op.plan, 0, t->bstride, 0) != 0) failed = true;
+        }
+        if (failed) {
+            log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+            ok_ = false;
+            return;
+        }
+        conv.in[0] = fid;
+        for (int w : cv.wait_on) conv.wait_on.push_back(root(w));          // the cost-volume launch's cross-stream waits move to the convolution
+        ops_.erase(ops_.begin() + ci);
+        ci--;
+        log_.log(ILogger::Severity::kINFO, (cv.name + ": default cost volume folded into " + ops_[ib - 1].name + " (never materialised)").c_str());
+    }
 }
 
 // Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the

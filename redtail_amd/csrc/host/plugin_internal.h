@@ -18,6 +18,8 @@ struct ConvFusion {            // what the executor asks a Conv3D / Conv3DTransp
     bool residual = false;     // add a residual tensor before the activation (Conv3DTranspose: always (D,C,H,W))
     int out_depth = 0;         // Conv3DTranspose only: keep output slices [0, out_depth) (elides the Slice plugin)
     int in_pad_end = 0;        // Conv3D only: the last input slices are implicit zeros (elides the Pad plugin)
+    int cv_fold = 0;           // Conv3D only: F > 0 = the input is the default cost volume of two (F,H,W) feature maps, gathered
+                               // from the (2F,H,W) tensor [left | right] instead of being built (elides the CostVolume plugin)
 };
 
 class IStereoPlugin {
@@ -36,6 +38,7 @@ public:
     virtual int sliceEnd() const { return 0; }
     // 3-D convolutions: re-plan with fused epilogue; enqueueFused takes the residual pointer
     virtual bool setFusion(const ConvFusion&) { return false; }
+    virtual ConvFusion fusion() const { return ConvFusion(); }
     virtual int enqueueFused(int, const void*, void*, const void*, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}
 };

@@ -330,10 +330,15 @@ public:
     }
     bool setFusion(const internal::ConvFusion& f) override {
         if (f.out_depth && !transposed_) return false;
-        if (f.in_pad_end && transposed_) return false;
+        if ((f.in_pad_end || f.cv_fold) && transposed_) return false;
+        const internal::ConvFusion old = fusion_;
         fusion_ = f;
-        return rebuildPlan();
+        if (rebuildPlan()) return true;
+        fusion_ = old;                       // e.g. cv_fold on a window the split kernels do not cover: keep the plan we had
+        rebuildPlan();
+        return false;
     }
+    internal::ConvFusion fusion() const override { return fusion_; }
     size_t getSerializationSize() override { return 0; }        // not serialisable, as in the reference
     void serialize(void*) override {}
 
@@ -347,6 +352,7 @@ protected:
         d.has_residual = fusion_.residual ? 1 : 0;
         d.out_depth = fusion_.out_depth;
         d.in_pad_end = fusion_.in_pad_end;
+        d.cv_fold = fusion_.cv_fold;
         d.dtype = kernel_.type == DataType::kHALF ? RT_F16 : RT_F32;   // storage type of the weight blob
         int rc = createPlan(d);
         RT_CHECKL(rc, log_);

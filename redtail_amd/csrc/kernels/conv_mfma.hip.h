@@ -78,6 +78,9 @@ struct ConvArgs {
     int batch;             // samples of this launch
     int cin_real;          // input channels that exist (CinPad - zero padding)
     int64_t x_cstride;     // input channel stride (2-D plans: Hi * x_pitch)
+    // conv_s3_kernel: per gathered channel a shift along x (same [nz][CinPad] shape as ch_off, or nullptr): the channel is read
+    // at column ix - shift and is zero for ix < shift -- the right-image half of a folded default cost volume
+    const int* ch_shift;
 };
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with

@@ -342,13 +342,15 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     const int sg = wv & 3, spart = wv >> 2;                         // channel group / patch part of this wave
     const int* __restrict__ tab = p.ch_off + (int64_t)ch_row * p.CinPad + 4 * sg;
     unsigned voff[NKP];
-    int lidx[NKP];
+    int lidx[NKP], xcol[NKP];
+    const int* __restrict__ shtab = p.ch_shift ? p.ch_shift + (int64_t)ch_row * p.CinPad + 4 * sg : nullptr;
 #pragma unroll
     for (int k = 0; k < NKP; k++) {
         const int pidx = spart * (NKP * 64) + lane + 64 * k;
         const int pr = pidx / PC, pc = pidx - pr * PC;
         const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
         const bool own = pidx < Cfg::NPIX && lane + 64 * k < NKP * 64;
+        xcol[k] = ix;
         voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : 4u) : kBufOOB;
         const int col = S == 2 ? (pc & 1) * Cfg::PCH + (pc >> 1) : pc;
         lidx[k] = own ? (pr * PCL + col) * PXB + sg * 8 : -1;
@@ -366,12 +368,17 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
 #pragma unroll
             for (int k = 0; k < NKP; k++) rin[k] = buf_load4(rs, voff[k], (unsigned)off * 4u);
         } else {
+            // folded cost volume: the 4 channels of the group share one shift (right-image channels of depth slice d: d)
+            const int sh = shtab ? shtab[ch * CC] : 0;             // wave-uniform
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int off = tab[ch * CC + j];                  // wave-uniform scalar load
                 const buf_rsrc rs = make_buf(xb, off >= 0);
 #pragma unroll
-                for (int k = 0; k < NKP; k++) rin[k][j] = buf_load(rs, voff[k], (unsigned)off * 4u);
+                for (int k = 0; k < NKP; k++) {
+                    const unsigned vo = sh == 0 ? voff[k] : ((voff[k] != kBufOOB && xcol[k] >= sh) ? voff[k] - (unsigned)sh * 4u : kBufOOB);
+                    rin[k][j] = buf_load(rs, vo, (unsigned)off * 4u);
+                }
             }
         }
         const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);

@@ -448,6 +448,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int y_ystride = 0, y_xstride = 1;
     float* w_dev = nullptr;
     int* choff_dev = nullptr;
+    int* shift_dev = nullptr;           // per gathered channel x-shift (folded cost volume), same shape as the gather table
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
     int wino = 0;                       // Winograd F(2x2,3x3) kernel (stride-1 3x3 windows)
@@ -841,6 +842,7 @@ void free_plan(rtConvPlan* p) {
     for (auto& s : p->subs) {
         if (s.w_dev) (void)hipFree(s.w_dev);
         if (s.choff_dev) (void)hipFree(s.choff_dev);
+        if (s.shift_dev) (void)hipFree(s.shift_dev);
         if (s.zs_dev) (void)hipFree(s.zs_dev);
     }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
@@ -1120,7 +1122,9 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     plan->out_dims[2] = Ho; plan->out_dims[3] = Wo;
     const int Dreal = d->D - d->in_pad_end;               // slices that exist in memory (folded Pad plugin)
     RT_REQUIRE(d->in_pad_end >= 0 && Dreal > 0, "conv3d: in_pad_end %d out of range", d->in_pad_end);
-    plan->x_bstride = (int64_t)Dreal * C * d->H * d->W;
+    const int F = d->cv_fold;                             // folded default cost volume: x is the (2F, H, W) tensor [left | right]
+    RT_REQUIRE(F == 0 || (F > 0 && C == 2 * F && F % 4 == 0 && d->in_pad_end == 0), "conv3d: cv_fold needs C == 2 * cv_fold, a multiple of 4, no folded pad");
+    plan->x_bstride = F ? (int64_t)C * d->H * d->W : (int64_t)Dreal * C * d->H * d->W;
     plan->y_bstride = (int64_t)K * Do * Ho * Wo;
 
     SubConv sc;
@@ -1141,15 +1145,26 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     });
     // gather table: z-slice `dz` reads input depth dz*sd + v - pd for tap v (the (D*C)-merged axis of
     // lib/conv_utils.cpp:27-32 with its D stride/pad multiplied by C, :58-72); out-of-range depth = zeros.
-    std::vector<int> table((size_t)Do * sc.CinPad, -1);
+    std::vector<int> table((size_t)Do * sc.CinPad, -1), shift((size_t)Do * sc.CinPad, 0);
     const int64_t plane = (int64_t)d->H * d->W;
     for (int dz = 0; dz < Do; dz++)
         for (int v = 0; v < V; v++) {
             const int din = dz * sd + v - pd;
             if (din < 0 || din >= Dreal) continue;
-            for (int c = 0; c < C; c++) table[(size_t)dz * sc.CinPad + v * C + c] = (int)(((int64_t)din * C + c) * plane);
+            for (int c = 0; c < C; c++) {
+                // folded cost volume (lib/kernels.cu:72-97): every depth slice reads the same 2F planes, the right-image half
+                // shifted by the slice's disparity
+                table[(size_t)dz * sc.CinPad + v * C + c] = F ? (int)(c * plane) : (int)(((int64_t)din * C + c) * plane);
+                if (F && c >= F) shift[(size_t)dz * sc.CinPad + v * C + c] = din;
+            }
         }
     if (!rc) rc = upload_table(sc, table);
+    if (!rc && F) {
+        if (!sc.split3 || sc.KH != 3 || sc.S > 2) rc = fail(RT_E_UNSUPPORTED, "conv3d: cv_fold is built for the split-fp16 3x3 kernels only");
+        else if (hipMalloc((void**)&sc.shift_dev, shift.size() * sizeof(int)) != hipSuccess ||
+                 hipMemcpy(sc.shift_dev, shift.data(), shift.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(RT_E_NOMEM, "conv3d: device allocation failed");
+    }
     plan->subs.push_back(sc);
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, K, d->dtype) : std::vector<float>();
@@ -1661,6 +1676,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
 #endif
         a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
         a.ch_off = sc.choff_dev;
+        a.ch_shift = sc.shift_dev;
         a.zs = sc.zs_dev;
         a.CinPad = sc.CinPad; a.Cout = sc.Cout;
         a.Hi = sc.Hi; a.Wi = sc.Wi; a.Ho = sc.Ho; a.Wo = sc.Wo;

@@ -260,3 +260,25 @@ def test_corr_softargmax_mfma(backend, shape, D, is_min, pitch):
     assert np.abs(got[..., :w] - ref).max() <= 2e-4 * max(1, D / 16), np.abs(got[..., :w] - ref).max()
     if P > w:
         assert np.isnan(got[..., w:]).all(), "padding columns were written"
+
+
+# ---- default cost volume folded into the first Conv3D's gather (never materialised) ----------------------------------------
+@pytest.mark.parametrize("f,k,h,w,D,batch", [(8, 16, 9, 37, 6, 2), (32, 32, 5, 40, 12, 1), (4, 8, 7, 33, 5, 1)])
+def test_conv3d_on_folded_cost_volume(backend, f, k, h, w, D, batch):
+    """rtConv3dDesc::cv_fold: Conv3D reads cv[d, 0:F] = L, cv[d, F:2F, y, x] = R[:, y, x - d] (0 for x < d) straight from
+    the two feature maps (reference lib/kernels.cu:72-97 builds the (D, 2F, H, W) volume first); against the oracle's
+    cost_volume + conv3d_tf in fp64"""
+    l, r = rnd(batch, f, h, w), rnd(batch, f, h, w)
+    wt, b = rnd(k, 3, 2 * f, 3, 3) * np.float32(1 / np.sqrt(27 * 2 * f)), rnd(k)
+    cv = O.cost_volume(torch.from_numpy(l).double(), torch.from_numpy(r).double(), D)            # N D 2F H W
+    ref = O.conv3d_tf(cv, torch.from_numpy(wt).double(), torch.from_numpy(b).double(), (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    ref = O.elu(O.transform(ref)).numpy()                                                         # (N, Do, K, Ho, Wo)
+    plan = backend.klib.conv3d_plan(wt, b, 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU,
+                                    out_dchw=True, cv_fold=f)
+    x = np.concatenate([l, r], axis=1)                                                            # (N, 2F, H, W): [left | right]
+    y = backend.empty((batch,) + plan.out_dims)
+    plan.enqueue(backend.dev(x), y, None, batch)
+    out = backend.host(y)
+    plan.destroy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 4e-7 * np.sqrt(27 * 2 * f) + 2e-6, np.abs(out - ref).max()
