@@ -425,6 +425,7 @@ private:
     void assignPitch();
     void foldConcats();
     void foldCostVolumes();
+    void assignHalf3D();
     void fuseResBlocks();
     bool ok_ = false;
     bool half2_ = false;
@@ -480,6 +481,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) assignStreams();
     if (ok_) foldConcats();
     if (ok_) foldCostVolumes();
+    if (ok_) assignHalf3D();
 }
 
 EngineImpl::~EngineImpl() {
@@ -1017,6 +1019,50 @@ void EngineImpl::foldCostVolumes() {
         ci--;
         log_.log(ILogger::Severity::kINFO, (cv.name + ": default cost volume folded into " + ops_[ib - 1].name + " (never materialised)").c_str());
     }
+}
+
+// half2 mode of the 3-D models (fp16 weight file -> IBuilder::setHalf2Mode, sample_app/main.cpp:256-262; the reference's Conv3D
+// plugins then convert fp32 <-> fp16 around every cuDNN call, lib/conv3d_plugin.cpp:247-274): the 4-D tensors that only fused
+// Conv3D / Conv3DTranspose launches touch are STORED as fp16 (dense, same (D,C,H,W) / (K,D,H,W) layouts) -- half the bytes of
+// the tensors that make these networks HBM-heavy -- and multiplied as fp16 operands with fp32 accumulation
+// (conv_s3_kernel<.., TIN, TOUT>).  The 2-D feature towers keep fp32 activations; so do the volume the last layer writes
+// and the soft-argmin.
+void EngineImpl::assignHalf3D() {
+    if (!half2_ || getenv("RT_NO_F16") || getenv("RT_NO_F16_3D")) return;
+    std::vector<char> h(tensors_.size(), 0);
+    for (auto& t : tensors_) h[t->id] = !t->is_input && !t->is_output && t->alias_of < 0 && t->dims.nbDims == 4 && !t->f16;
+    auto clear = [&](int t) { if (t >= 0) h[root(t)] = 0; };
+    for (auto& op : ops_) {
+        if (op.kind == OpKind::kConv3D) continue;
+        for (int i : op.in) clear(i);
+        clear(op.out);
+        clear(op.resid);
+    }
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (auto& op : ops_) {
+            if (op.kind != OpKind::kConv3D) continue;
+            const int x = root(op.in[0]), y = root(op.out), r = op.resid >= 0 ? root(op.resid) : -1;
+            if (r >= 0 && h[r] != h[y]) { h[r] = h[y] = 0; changed = true; }       // the residual is read with the output's type
+            if (!h[x] && !h[y]) continue;
+            if (!op.splugin->setIoTypes(h[x] != 0, h[y] != 0)) {                     // no fp16-storage kernel for this launch
+                op.splugin->setIoTypes(false, false);
+                if (h[x] || h[y] || (r >= 0 && h[r])) changed = true;
+                h[x] = h[y] = 0;
+                if (r >= 0) h[r] = 0;
+            }
+        }
+    }
+    int n = 0;
+    for (auto& op : ops_)
+        if (op.kind == OpKind::kConv3D) {
+            const int x = root(op.in[0]), y = root(op.out);
+            op.splugin->setIoTypes(h[x] != 0, h[y] != 0);
+            n += h[y] != 0;
+        }
+    for (auto& t : tensors_)
+        if (h[t->id]) t->f16 = true;
+    if (n) log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n) + " Conv3D / Conv3DTranspose launches write fp16 tensors").c_str());
 }
 
 // Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the

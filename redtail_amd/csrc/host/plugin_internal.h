@@ -39,6 +39,8 @@ public:
     // 3-D convolutions: re-plan with fused epilogue; enqueueFused takes the residual pointer
     virtual bool setFusion(const ConvFusion&) { return false; }
     virtual ConvFusion fusion() const { return ConvFusion(); }
+    // half2 mode: store the 3-D input / output (+ residual) tensors as fp16 (kept across setFusion)
+    virtual bool setIoTypes(bool, bool) { return false; }
     virtual int enqueueFused(int, const void*, void*, const void*, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}
 };

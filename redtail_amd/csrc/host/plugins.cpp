@@ -339,6 +339,12 @@ public:
         return false;
     }
     internal::ConvFusion fusion() const override { return fusion_; }
+    bool setIoTypes(bool x16, bool y16) override {
+        if (!plan_) return false;
+        if (rt_conv_plan_set_io_types(plan_, x16 ? RT_F16 : RT_F32, y16 ? RT_F16 : RT_F32) != 0) return false;
+        x16_ = x16; y16_ = y16;
+        return true;
+    }
     size_t getSerializationSize() override { return 0; }        // not serialisable, as in the reference
     void serialize(void*) override {}
 
@@ -356,6 +362,7 @@ protected:
         d.dtype = kernel_.type == DataType::kHALF ? RT_F16 : RT_F32;   // storage type of the weight blob
         int rc = createPlan(d);
         RT_CHECKL(rc, log_);
+        if (rc == 0 && (x16_ || y16_) && rt_conv_plan_set_io_types(plan_, x16_ ? RT_F16 : RT_F32, y16_ ? RT_F16 : RT_F32) != 0) x16_ = y16_ = false;
         return rc == 0;
     }
     virtual void fillDesc(rtConv3dDesc& d) const = 0;
@@ -366,6 +373,7 @@ protected:
     Dims w_dims_, stride_, pad_start_, pad_end_;
     Weights kernel_, bias_;
     internal::ConvFusion fusion_;
+    bool x16_ = false, y16_ = false;
     rtConvPlan* plan_ = nullptr;
     Dims x_dims_{}, y_dims_{};
     ILogger& log_;

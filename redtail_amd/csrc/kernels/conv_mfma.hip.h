@@ -81,6 +81,7 @@ struct ConvArgs {
     // conv_s3_kernel: per gathered channel a shift along x (same [nz][CinPad] shape as ch_off, or nullptr): the channel is read
     // at column ix - shift and is zero for ix < shift -- the right-image half of a folded default cost volume
     const int* ch_shift;
+    int w_exact;           // conv_s3_kernel: the weights came from an fp16 file -- their low parts are zero and are not multiplied
 };
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with

@@ -294,9 +294,17 @@ struct S3Cfg {
 // NW = 8 (3x3 stride 1 only): 8-row tiles, 8 waves -- the chunk's weights are fetched and staged once per 8 rows instead of
 // once per 4 and the patch halo shrinks from 6/4 to 10/8 rows: 29 % fewer bytes through the CU's vector-memory path, which
 // is what bounds the layer (profiles/README.md, round 2)
-template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4>
+// TIN / TOUT (planar tensors only): storage type of the input and of the output + residual -- float, or _Float16 for the
+// 3-D tensors of half2 mode (TensorRT setHalf2Mode with an fp16 weight file, reference sample_app/main.cpp:256-262; the
+// reference's Conv3D plugins convert fp32 <-> fp16 around cuDNN, lib/conv3d_plugin.cpp:247-274).  An fp16 input IS its own
+// high part (low part 0) and fp16 weights are theirs (p.w_exact), so the corresponding MFMAs are skipped: 3 -> 2 -> 1
+// matrix instructions per tap, fp32 accumulation throughout.
+template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
     using Cfg = S3Cfg<KH, KW, S, NW>;
+    constexpr bool XF16 = std::is_same<TIN, _Float16>::value;
+    constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
+    static_assert(!(XIL || YIL) || (!XF16 && std::is_same<TOUT, float>::value), "interleaved tensors are fp32");
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
 
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     const int nblk = blockIdx.y;
     const int zi = blockIdx.z % p.nz;
     const int n = blockIdx.z / p.nz;
-    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, 4);
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX);
     const int nchunks = p.CinPad / CC;
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
     int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
         const int iy = ty0 * S - pad_y + pr, ix = tx0 * S - pad_x + pc;
         const bool own = pidx < Cfg::NPIX && lane + 64 * k < NKP * 64;
         xcol[k] = ix;
-        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : 4u) : kBufOOB;
+        voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * (XIL ? 16u : ESX) : kBufOOB;
         const int col = S == 2 ? (pc & 1) * Cfg::PCH + (pc >> 1) : pc;
         lidx[k] = own ? (pr * PCL + col) * PXB + sg * 8 : -1;
     }
@@ -376,8 +384,8 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
                 const buf_rsrc rs = make_buf(xb, off >= 0);
 #pragma unroll
                 for (int k = 0; k < NKP; k++) {
-                    const unsigned vo = sh == 0 ? voff[k] : ((voff[k] != kBufOOB && xcol[k] >= sh) ? voff[k] - (unsigned)sh * 4u : kBufOOB);
-                    rin[k][j] = buf_load(rs, vo, (unsigned)off * 4u);
+                    const unsigned vo = sh == 0 ? voff[k] : ((voff[k] != kBufOOB && xcol[k] >= sh) ? voff[k] - (unsigned)sh * ESX : kBufOOB);
+                    rin[k][j] = Io<TIN>::load(rs, vo, (unsigned)off * ESX);
                 }
             }
         }
@@ -392,9 +400,16 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
 #pragma unroll
         for (int k = 0; k < NKP; k++) {
             if (lidx[k] < 0) continue;
-            const S3Split s = s3_split(rin[k]);
-            *reinterpret_cast<f16x4*>(sIn + lidx[k]) = s.hi;
-            *reinterpret_cast<f16x4*>(sIn + lidx[k] + 32) = s.lo;
+            if constexpr (XF16) {                                   // the stored fp16 values are the operands; no low part
+                f16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; j++) h[j] = (_Float16)rin[k][j];
+                *reinterpret_cast<f16x4*>(sIn + lidx[k]) = h;
+            } else {
+                const S3Split s = s3_split(rin[k]);
+                *reinterpret_cast<f16x4*>(sIn + lidx[k]) = s.hi;
+                *reinterpret_cast<f16x4*>(sIn + lidx[k] + 32) = s.lo;
+            }
         }
 #pragma unroll
         for (int k = 0; k < NK_W; k++) {
@@ -415,18 +430,18 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     if (p.resid != nullptr) {
         // interleaved tensors (2-D plans only): pixel offsets -- r_off / y_off of a transposed-convolution phase -- count
         // 16-byte slots, i.e. 4 elements
-        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + 4 * r_off : rbase, 4));
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + 4 * r_off : rbase, ESY));
         if (r_il) {
             const unsigned vo = inb ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * rs32) * 4u : kBufOOB;
 #pragma unroll
             for (int q = 0; q < 4; q++) rr[q] = buf_load4(rs_r, (cb + 8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q) * rs32) * 4u);
         } else {
-            const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * rs32) * 4u : kBufOOB;
+            const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * rs32) * ESY : kBufOOB;
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    rr[q][e] = buf_load(rs_r, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * rs32) * 4u);
+                    rr[q][e] = Io<TOUT>::load(rs_r, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * rs32) * ESY);
         }
     } else {
 #pragma unroll
@@ -437,6 +452,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
     const int a_off = kg * 32 + l31;
+    const bool w_exact = p.w_exact != 0;
     // B operand of tap (r, s): pixel (wv*S + r, l31*S + s); stride 2: column parity (s & 1), index l31 + (s >> 1)
     const int b_off = (wv * S * PCL + l31) * PXB + kg * 16;
     auto compute = [&]() {
@@ -447,12 +463,16 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
             const int col = S == 2 ? (s & 1) * Cfg::PCH + (s >> 1) : s;
             const char* bp = sIn + b_off + (r * PCL + col) * PXB;
             const f16x8 bh = *reinterpret_cast<const f16x8*>(bp);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 32);
             const f16x8 ah = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 0) * 64]);
-            const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 1) * 64]);
             acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_m, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+            if (!w_exact) {                                         // wave-uniform: fp16 weights have no low part
+                const f16x8 al = __builtin_bit_cast(f16x8, sW[a_off + (t * 2 + 1) * 64]);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_c, 0, 0, 0);
+            }
+            if constexpr (!XF16) {
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 32);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_c, 0, 0, 0);
+            }
         }
     };
 
@@ -469,7 +489,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
-    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, YIL ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, 4));
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, YIL ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, ESY));
     auto epilogue = [&](auto ACT) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -482,10 +502,10 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
             } else {
-                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
+                const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * ESY : kBufOOB;
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    buf_store(o[e], rs_y, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * cs32) * 4u);
+                    Io<TOUT>::store(o[e], rs_y, (cb + 8 * q + 4 * kg + e < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q + e) * cs32) * ESY);
             }
         }
     };

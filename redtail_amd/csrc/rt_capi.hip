@@ -448,6 +448,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int y_ystride = 0, y_xstride = 1;
     float* w_dev = nullptr;
     int* choff_dev = nullptr;
+    int w_exact = 0;                    // weights were given as fp16: split low parts are zero (conv_s3_kernel skips their MFMAs)
     int* shift_dev = nullptr;           // per gathered channel x-shift (folded cost volume), same shape as the gather table
     rt::ZSlice* zs_dev = nullptr;       // per-slice overrides (transposed-conv phases), or null
     int direct = 0, cin_real = 0;       // direct = VALU kernel for Cout <= 2
@@ -483,6 +484,7 @@ struct rtConvPlan {
     float* rb_w1_dev = nullptr;
     float* rb_bias1_dev = nullptr;
     int rb_act1 = 0, rb_cmid = 0;
+    int w_f16 = 0;                                // the weights were given as fp16 (trt_weights_fp16.bin)
 };
 
 namespace {
@@ -865,7 +867,7 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     RT_REQUIRE((int64_t)d->Cin * d->Hin * d->Win < (1ll << 29), "conv2d: input sample exceeds 2 GB (32-bit buffer offsets)");
 
     auto plan = new rtConvPlan();
-    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     plan->out_dims[0] = d->Cout; plan->out_dims[1] = Ho; plan->out_dims[2] = Wo; plan->out_dims[3] = 1;
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
@@ -918,7 +920,7 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
     RT_REQUIRE((d1->dtype == RT_F32 || d1->dtype == RT_F16) && d1->dtype == d2->dtype, "rt_resblock_plan_create: bad dtype");
     RT_REQUIRE((int64_t)d1->Cin * d1->Hin * d1->Win < (1ll << 29), "rt_resblock_plan_create: input sample exceeds 2 GB");
     auto plan = new rtConvPlan();
-    plan->act = d2->act; plan->has_resid = 1; plan->dtype = RT_F32;
+    plan->act = d2->act; plan->has_resid = 1; plan->dtype = RT_F32; plan->w_f16 = d1->dtype == RT_F16;
     plan->out_dims[0] = d2->Cout; plan->out_dims[1] = d1->Hin; plan->out_dims[2] = d1->Win; plan->out_dims[3] = 1;
     plan->x_bstride = (int64_t)d1->Cin * d1->Hin * d1->Win;
     plan->y_bstride = (int64_t)d2->Cout * d1->Hin * d1->Win;
@@ -973,7 +975,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     RT_REQUIRE((int64_t)d->Cin * d->Hin * d->Win < (1ll << 29), "deconv2d: input sample exceeds 2 GB (32-bit buffer offsets)");
 
     auto plan = new rtConvPlan();
-    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     plan->out_dims[0] = d->Cout; plan->out_dims[1] = Ho; plan->out_dims[2] = Wo; plan->out_dims[3] = 1;
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
@@ -1115,7 +1117,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     if (!window_supported(R, Sk, sh)) return fail(RT_E_UNSUPPORTED, "conv3d: window %dx%d stride %d", R, Sk, sh);
 
     auto plan = new rtConvPlan();
-    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     const int K = d->K, C = d->C;
     if (d->out_dchw) { plan->out_dims[0] = Do; plan->out_dims[1] = K; }
     else { plan->out_dims[0] = K; plan->out_dims[1] = Do; }
@@ -1196,7 +1198,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 29), "conv3d_transpose: input sample exceeds 2 GB (32-bit buffer offsets)");
 
     auto plan = new rtConvPlan();
-    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32;
+    plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     plan->out_dims[0] = cdhw ? C : Dlim; plan->out_dims[1] = cdhw ? Dlim : C; plan->out_dims[2] = Hx; plan->out_dims[3] = Wx;
     plan->x_bstride = (int64_t)K * Dy * Hy * Wy;
     plan->y_bstride = (int64_t)Dlim * C * Hx * Wx;
@@ -1536,8 +1538,19 @@ bool f16mma_window(const SubConv& sc) {
 // activations in fp16 between layers; the arithmetic stays fp32.  fp16 outputs need an even row pitch (pixel pairs
 // are written as one 4-byte word).
 extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype) {
-    RT_REQUIRE(plan && plan->is2d, "rt_conv_plan_set_io_types: 2-D convolution plans only");
+    RT_REQUIRE(plan, "rt_conv_plan_set_io_types: null plan");
     RT_REQUIRE((x_dtype == RT_F32 || x_dtype == RT_F16) && (y_dtype == RT_F32 || y_dtype == RT_F16), "rt_conv_plan_set_io_types: bad dtype");
+    if (!plan->is2d) {
+        // 3-D plans (Conv3D / Conv3DTranspose): fp16 storage of the dense (D,C,H,W) / (K,D,H,W) tensors, the split-fp16 kernel
+        // reads / writes them as they are (an fp16 input is its own high part); the small-output last layer reads fp16, writes fp32
+        for (SubConv& sc : plan->subs) {
+            const bool ok = sc.small3d ? (sc.small3d == 1 && y_dtype == RT_F32) : (sc.split3 && !sc.x_il8 && !sc.y_il8 && !sc.r_il8);
+            if (!ok && (x_dtype == RT_F16 || y_dtype == RT_F16))
+                return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: this 3-D plan has no fp16-storage kernel (window %dx%d stride %d)", sc.KH, sc.KW, sc.S);
+        }
+        for (SubConv& sc : plan->subs) { sc.x_f16 = x_dtype == RT_F16; sc.y_f16 = y_dtype == RT_F16; }
+        return 0;
+    }
     const int xf = x_dtype == RT_F16, yf = y_dtype == RT_F16;
     const int op = plan->out_pitch ? plan->out_pitch : plan->out_dims[2];
     RT_REQUIRE(!yf || (op & 1) == 0, "rt_conv_plan_set_io_types: fp16 output rows need an even pitch (got %d)", op);
@@ -1654,6 +1667,9 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
                     if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
                     else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
                 }
+            } else if (sc.small3d == 1 && sc.x_f16) {   // 3-D last layer in half2 mode: fp16 (K,D,H,W) in, fp32 volume out
+                if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
             } else if (sc.small3d == 2) {
                 if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false>), grid, dim3(256), 0, S(s), a);
                 else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false>), grid, dim3(256), 0, S(s), a);
@@ -1677,6 +1693,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.resid = plan->has_resid ? static_cast<const float*>(residual) : nullptr;
         a.ch_off = sc.choff_dev;
         a.ch_shift = sc.shift_dev;
+        a.w_exact = plan->w_f16;
         a.zs = sc.zs_dev;
         a.CinPad = sc.CinPad; a.Cout = sc.Cout;
         a.Hi = sc.Hi; a.Wi = sc.Wi; a.Ho = sc.Ho; a.Wo = sc.Wo;
@@ -1753,7 +1770,18 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             if (env_int("RT_CONV_TRACE", 0))
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             bool launched = false;
-            if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
+            if (sc.x_f16 || sc.y_f16) {                 // fp16 storage (3-D tensors of half2 mode): planar, 4-row tiles
+                RT_REQUIRE(!sc.x_il8 && !sc.y_il8 && !sc.r_il8 && sc.TY == 4 && sc.y_f16, "rt_conv_enqueue: fp16-storage variant of the split kernel not instantiated");
+#define RT_S3H(kh, kw, st)                                                                                                         \
+    if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                                   \
+        if (sc.x_f16) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a); \
+        else hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);   \
+        launched = true;                                                                                                           \
+    }
+                RT_S3H(3, 3, 1) RT_S3H(3, 3, 2) RT_S3H(1, 1, 1) RT_S3H(1, 2, 1) RT_S3H(2, 1, 1) RT_S3H(2, 2, 1)
+#undef RT_S3H
+            }
+            if (!launched && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
                 if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, true, 8>), grid, dim3(512), 0, S(s), a);
                 else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, false, 8>), grid, dim3(512), 0, S(s), a);
                 else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, false, true, 8>), grid, dim3(512), 0, S(s), a);

@@ -150,18 +150,27 @@ def test_resnet18_2d_half2_mode(rt, monkeypatch):
     assert np.array_equal(planar, half)
 
 
-def test_nvtiny_fp16_weight_file(rt):
+def test_nvtiny_fp16_weight_file(rt, monkeypatch):
     """a 3-D model built from an fp16 weight file (NVSmall only ships trt_weights_fp16.bin): the executor tries half2
     mode, the cost-volume plugin cannot take fp16 tensors, every plan already switched must go back to fp32 --
     result = fp32 arithmetic on the fp16-rounded weights (round 1: NaN with a success code)."""
     w = O.synth_weights_3d(O.NVTINY_3D)
     wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in w.items()}
     l, r = pairs(1, 25, 33)
-    out, _ = run_net(rt, "nvtiny", w, l, r, max_disp=4, fp16_weights=True)
     with torch.no_grad():
         ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), wq, O.NVTINY_3D, 4).numpy()
+    # half2 mode of a 3-D model: the 4-D tensors between the fused Conv3D / Conv3DTranspose launches are stored as fp16 and
+    # multiplied as fp16 operands (fp32 accumulation); the 2-D towers, the last layer's volume and the soft-argmin stay fp32.
+    # Reference tolerance for fp16: 1e-2 (tests_main.cpp:320, 1025)
+    out, _ = run_net(rt, "nvtiny", w, l, r, max_disp=4, fp16_weights=True)
     assert not np.isnan(out).any()
-    assert np.abs(out - ref).max() <= 1e-3, np.abs(out - ref).max()
+    err16 = np.abs(out - ref).max()
+    assert err16 <= 1e-2, err16
+    monkeypatch.setenv("RT_NO_F16_3D", "1")          # same fp16 weights, fp32 tensors everywhere
+    out32, _ = run_net(rt, "nvtiny", w, l, r, max_disp=4, fp16_weights=True)
+    err32 = np.abs(out32 - ref).max()
+    assert err32 <= 1e-3, err32
+    assert err16 > err32                              # i.e. the fp16-storage path really ran
 
 
 def test_plan_round_trip(rt):
@@ -353,7 +362,7 @@ def test_nvtiny_full_size():
 
 
 @pytest.mark.gpu
-def test_nvsmall_full_size_real_fp16_weights():
+def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
     """BASELINE config C5's model with the only weight file the reference ships for it (NVSmall trt_weights_fp16.bin),
     1025x321, D = 48 at half resolution, against the oracle on the same (fp16-valued) weights."""
     lib = netlib("gpu")
@@ -365,10 +374,22 @@ def test_nvsmall_full_size_real_fp16_weights():
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), weights, O.NVSMALL_3D, 48)
-    err = (out.cpu() - ref).abs().max().item()
-    print("NVSmall 1025x321, real fp16 weights: max |disp - oracle| = %.3g px" % err)
+    err = (out.cpu() - ref).abs()
+    print("NVSmall 1025x321, real fp16 weights, half2 mode (fp16 3-D tensors): max |disp - oracle| = %.3g px, mean %.3g px, disparities up to %.1f px"
+          % (err.max().item(), err.mean().item(), ref.max().item()))
     assert not torch.isnan(out).any()
-    assert err <= 1e-3, err
+    # fp16 storage of 11 stacked 3-D layers on disparities up to ~100 px: asserted against a tenth of a pixel (the reference's
+    # accuracy metric D1 counts errors above 3 px); with fp32 tensors (RT_NO_F16_3D) the same weights give < 1e-3 px, below
+    assert err.max().item() <= 0.1, err.max().item()
+    net.destroy()
+    monkeypatch.setenv("RT_NO_F16_3D", "1")
+    net = lib.create("nvsmall", 1025, 321, weights_path=model_files.weight_file("nvsmall", True), fp16_weights=True)
+    out32 = torch.full((1, 1, 321, 1025), float("nan"), device="cuda")
+    net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out32, 1)
+    torch.cuda.synchronize()
+    err32 = (out32.cpu() - ref).abs().max().item()
+    print("NVSmall 1025x321, real fp16 weights, fp32 tensors: max |disp - oracle| = %.3g px" % err32)
+    assert err32 <= 1e-3, err32
     net.destroy()
 
 

@@ -282,3 +282,59 @@ def test_conv3d_on_folded_cost_volume(backend, f, k, h, w, D, batch):
     plan.destroy()
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 4e-7 * np.sqrt(27 * 2 * f) + 2e-6, np.abs(out - ref).max()
+
+
+# ---- fp16 storage of the 3-D tensors (half2 mode of the 3-D models) ------------------------------------------------------------
+def _h16(a):
+    return np.ascontiguousarray(a.astype(np.float16))
+
+
+def _dev16(backend, a):
+    return torch.from_numpy(_h16(a)).cuda() if backend.name == "gpu" else _h16(a)
+
+
+def _host32(backend, t):
+    if backend.name == "gpu":
+        torch.cuda.synchronize()
+        return t.cpu().numpy().astype(np.float32)
+    return np.asarray(t).astype(np.float32)
+
+
+def _empty16(backend, shape):
+    if backend.name == "gpu":
+        return torch.full(tuple(shape), float("nan"), dtype=torch.float16, device="cuda")
+    return np.full(shape, np.nan, np.float16)
+
+
+@pytest.mark.parametrize("x16", [True, False])
+@pytest.mark.parametrize("c,k,d,h,w,stride,resid", [(8, 32, 5, 9, 35, 1, False), (16, 24, 6, 8, 37, 2, False), (32, 16, 4, 7, 33, 1, True)])
+def test_conv3d_fp16_storage(backend, c, k, d, h, w, stride, resid, x16):
+    """Conv3D with (D,C,H,W) tensors stored as fp16 (x16: input too -- inner layers; otherwise fp32 in, fp16 out -- the
+    first layer after the fp32 feature towers), fp16 weight values, fp32 accumulation: against the oracle on the same
+    (fp16-rounded) operands, one rounding of the output"""
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x = q16(rnd(2, d, c, h, w)) if x16 else rnd(2, d, c, h, w)
+    wt, b = q16(rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * c))), rnd(k)
+    if stride == 2:
+        pads = (0, 1, 1) if d % 2 == 0 else (1, 1, 1)
+        xin = O.pad_d(torch.from_numpy(x).double(), 1) if d % 2 == 0 else torch.from_numpy(x).double()
+        ref = O.conv3d_tf(xin, torch.from_numpy(wt).double(), torch.from_numpy(b).double(), (2, 2, 2), pads, pads)
+    else:
+        pads = (1, 1, 1)
+        ref = O.conv3d_tf(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), (1, 1, 1), pads, pads)
+    ref = O.transform(ref)                                                                        # (N, Do, K, Ho, Wo)
+    res = q16(rnd(*ref.shape)) if resid else None
+    if resid:
+        ref = ref + torch.from_numpy(res).double()
+    ref = O.elu(ref).numpy()
+    plan = backend.klib.conv3d_plan(_h16(wt), b.astype(np.float16), c, k, (d + (1 if stride == 2 and d % 2 == 0 else 0), h, w), (3, 3, 3), (stride,) * 3,
+                                    pads, pads, act=capi.RT_ACT_ELU, out_dchw=True, has_residual=resid, dtype=capi.RT_F16,
+                                    in_pad_end=1 if stride == 2 and d % 2 == 0 else 0)
+    plan.set_io_types(capi.RT_F16 if x16 else capi.RT_F32, capi.RT_F16)
+    y = _empty16(backend, ref.shape)
+    plan.enqueue(_dev16(backend, x) if x16 else backend.dev(x), y, _dev16(backend, res) if resid else None, 2)
+    out = _host32(backend, y)
+    plan.destroy()
+    bq = b.astype(np.float16).astype(np.float32)                      # the bias travels in the fp16 weight file too
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max())) + np.abs(b - bq).max()
+    assert np.abs(out - ref).max() <= tol, (np.abs(out - ref).max(), tol)
