@@ -796,16 +796,7 @@ int launch_window(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream
                            dim3(64 * nw), 0, st, a);                                                      \
         return 0;                                                                                         \
     }
-    // interleaved fp32 output: the first layer and the stride-2 3x3 layers, default tile
-    if (sc.y_il8) {
-        if constexpr (NBW == 1 && S == 2 && ((KH == 5 && KW == 5 && CC == 4) || (KH == 3 && KW == 3 && CC == 8))) {
-            if (!(sc.TY == 4 && sc.TXW == 1 && sc.NW == 4 && sc.WLDS) || sc.x_f16 || sc.y_f16) return 1;
-            hipLaunchKernelGGL((rt::conv_mfma_f32_kernel<KH, KW, S, 4, 1, NBW, CC, 4, true, float, float, true>), grid, dim3(256), 0, st, a);
-            return 0;
-        } else {
-            return 1;
-        }
-    }
+    if (sc.y_il8) return 1;          // no interleaved-output form of the direct kernel (removed in round 2)
     // fp16 storage (half2 mode): the default tile only; fp32 in -> fp16 out (first layer) or fp16 -> fp16
     if (sc.x_f16 || sc.y_f16) {
         if (!(sc.TY == 4 && sc.TXW == 1 && sc.NW == 4 && sc.WLDS) || !sc.y_f16) return 1;
@@ -1612,11 +1603,9 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (sc.x_f16 || sc.y_f16) return 0;
     // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three ...
     if (sc.wino) return (sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
-    // ... the direct-form kernel can write them (first layer and stride-2 3x3 layers without a residual, default tile).
-    // OFF unless RT_IL_DIRECT=1: the kernel passes its parity tests on the emulator and on the GPU, but with it the whole
-    // network differs from the oracle on the GPU (not on the emulator, run-to-run different) -- open at the end of round 1.
-    const bool win = sc.S == 2 && sc.NBW == 1 && ((sc.KH == 5 && sc.KW == 5 && sc.CC == 4) || (sc.KH == 3 && sc.KW == 3 && sc.CC == 8));
-    if (win && !plan->has_resid && sc.TY == 4 && sc.TXW == 1 && sc.NW == 4 && sc.WLDS && sc.Cout % 4 == 0 && env_int("RT_IL_DIRECT", 0) != 0) return 2;
+    // (the direct-form kernel had an interleaved-output form for the first layer and the stride-2 layers behind RT_IL_DIRECT in round 1;
+    //  whole networks were wrong with it on the GPU only -- tools/race_hunt.py reproduced that in round 2 even with one stream and one
+    //  context -- and the split-fp16 kernels that now serve those layers write interleaved tensors themselves, so the form was removed)
     return 0;
 }
 // ... and the layout of each of them (0 = planar NCHW with a row pitch, 1 = (C/4, H, pitch, 4) fp32 / (C/8, H, pitch, 8) fp16)

@@ -191,42 +191,3 @@ def test_wino_interleaved_fuzz(backend, cin, cout, h, w, resid, x_il, y_il, r_il
     near(out[..., :w], ref.numpy(), 2e-5)
     if P > w:
         assert np.isnan(out[..., w:]).all(), "padding columns were written"
-
-
-@pytest.mark.parametrize("cin,cout,h,w,k,pad,batch,pitch", [
-    (3, 32, 21, 77, 5, 2, 2, 64),        # first layer
-    (3, 32, 9, 129, 5, 2, 1, 96),
-    (32, 64, 11, 37, 3, 1, 2, 32),       # stride-2 3x3
-    (64, 128, 8, 66, 3, 1, 1, 0),        # dense rows, four 32-channel blocks
-    (16, 36, 7, 35, 3, 1, 1, 32),        # channel tail: 36 = 32 + 4
-])
-def test_direct_form_interleaved_output(backend, monkeypatch, cin, cout, h, w, k, pad, batch, pitch):
-    """stride-2 layers of the direct-form kernel (first 5x5 layer, 3x3 stride 2) writing a channel-interleaved
-    (C/4, H, pitch, 4) tensor: same bits as the planar output, padding columns untouched.  (The executor does not use
-    this output form yet -- RT_IL_DIRECT -- see rt_conv_plan_supports_il8.)"""
-    monkeypatch.setenv("RT_IL_DIRECT", "1")
-    x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, k, k) * np.float32(1 / np.sqrt(cin * k * k)), rnd(cout)
-    ref = O.elu(O.conv2d(T(x), T(wt), T(b), 2, pad)).numpy()
-    ho, wo = ref.shape[-2:]
-    P = (wo + pitch - 1) // pitch * pitch if pitch else wo
-    outs = []
-    for il in (0, 1):
-        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, 2, pad, act=capi.RT_ACT_ELU)
-        if pitch:
-            plan.set_pitch(0, P)
-        assert plan.il_caps() == 2                                   # output only
-        if il:
-            plan.set_layouts(0, 1)
-            with pytest.raises(capi.RtError):
-                plan.set_layouts(1, 1)
-            plan.set_layouts(0, 1)
-        y = backend.empty((batch, cout // 4, ho, P, 4) if il else (batch, cout, ho, P))
-        plan.enqueue(backend.dev(x), y, None, batch)
-        out = backend.host(y).copy()
-        out = from_il(out) if il else out
-        if P > wo:
-            assert np.isnan(out[..., wo:]).all(), "padding columns were written"
-        outs.append(out[..., :wo])
-        plan.destroy()
-    near(outs[1], ref, 2e-5)
-    assert np.array_equal(outs[0], outs[1])

@@ -24,8 +24,7 @@ CONFIGS = [
     ("no split kernels (round-1 fp32 kernels)", {"RT_CONV_EXACT_FP32": "1"}),
     ("no split kernels, single stream", {"RT_CONV_EXACT_FP32": "1", "RT_SINGLE_STREAM": "1"}),
     ("planar tensors", {"RT_NO_IL8": "1"}),
-    ("direct-form interleaved output", {"RT_IL_DIRECT": "1", "RT_CONV_EXACT_FP32": "1"}),
-    ("direct-form interleaved output, single stream", {"RT_IL_DIRECT": "1", "RT_CONV_EXACT_FP32": "1", "RT_SINGLE_STREAM": "1"}),
+    ("fused residual blocks", {"RT_RB": "1"}),
 ]
 
 
