@@ -17,11 +17,11 @@ import os
 import shutil
 import sys
 
-DOMINANT = "conv_wino_f32_kernel<4, float, float, ...>"      # every tensor-layout variant of the fp32 4-wave kernel
+DOMINANT = "conv_s3_kernel<3, 3, 1, ...>"      # every tensor-layout variant of the split-fp16 3x3 stride-1 kernel
 
 
 def is_dom(name):
-    return name.startswith("conv_wino_f32_kernel<4, float, float") or name == "conv_wino_f32_kernel<4>"
+    return name.startswith("conv_s3_kernel<3, 3, 1,")
 
 DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (the kernel also runs the low-resolution layers)
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
@@ -43,6 +43,9 @@ def main():
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
     shutil.copy(os.path.join(run, "bench_plain.json"), os.path.join(out, tag + "_bench.json"))
+    for extra in ("bench_20_5.json", "bench_half2_b1.json", "bench_half2_b8.json", "bench_3d.txt", "layers.txt", "race.txt"):
+        if os.path.exists(os.path.join(run, extra)):
+            shutil.copy(os.path.join(run, extra), os.path.join(out, tag + "_" + extra))
 
     # ---- counters: mean per launch and kernel ---------------------------------------------------------
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -81,7 +84,10 @@ def main():
 
     # ---- one steady-state step as a timeline (last full step of the trace) -----------------------------
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per_step = 49
+    try:
+        per_step = json.loads([l for l in open(os.path.join(run, "bench_plain.json")) if l.startswith("{")][-1])["config"]["launches_per_step"]
+    except Exception:
+        per_step = 48
     last = rows[-per_step:]
     base = int(last[0]["Start_Timestamp"])
     with open(os.path.join(out, tag + "_timeline.txt"), "w") as f:
