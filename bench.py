@@ -440,6 +440,10 @@ def main():
                     "frac_step_note": "91.87 GFLOP (direct form) per pair / ms_per_step / 157.3 TFLOP/s fp32 matrix peak; above 1 is "
                                       "possible because the split kernels run on the fp16 pipe",
                     "step_tflops": NET_FLOPS * b / step_s / 1e12,
+                    # the same launch on round 1's scale (direct-form FLOPs / fp32 matrix peak, where the Winograd kernel had 0.63 / 0.69)
+                    "direct_form_tflops": flops * b / avg_s / 1e12, "direct_form_tflops_isolated": flops * b / iso_us / 1e6,
+                    "frac_of_fp32_mfma_peak": flops * b / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "frac_of_fp32_mfma_peak_isolated": flops * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
                     "mfma_flops_executed": mfma_exec * b,
                     "mfma_util_executed": mfma_exec * b / iso_us / 1e6 / mfma_peak,
                     "mfma_util_note": "executed matrix FLOPs of one launch / isolated duration / %.0f TFLOP/s (%s pipe)" % (
