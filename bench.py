@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
-network (49 fused launches) with the inputs already resident in HBM (the reference times
+network (48 fused launches) with the inputs already resident in HBM (the reference times
 context->execute the same way, sample_app/main.cpp:303-309).  Steps are issued round-robin over
 --contexts execution contexts of the same engine configuration, each on its own stream (default 4, the
 usual TensorRT throughput set-up): the serial low-resolution tail of one pair then overlaps the encoder
@@ -15,18 +15,18 @@ share nothing but the weights: rank 0 builds the weight-file image and broadcast
 processes its own K pairs).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = conv_wino_f32_kernel<4,...> (the 34 residual-block 3x3 32->32 convolutions at
-                629x185 = 79 % of the network's FLOPs; the same kernel also runs conv2D_1/2/4/5/7/8):
-                ALGORITHMIC FLOPs per launch (direct form, 2*Cin*Cout*9*H*W) / average launch
-                duration measured with HIP events on the launch stream (IProfiler path of the executor) right
-                after the timed region.  The kernel is the Winograd F(2x2,3x3) form: it issues 16/36 of those
-                multiplies on the matrix cores ("mfma_flops_executed"), which is why `achieved` can approach
-                the direct-form MFMA peak.
-                With --half2 (TensorRT half2 mode, BASELINE config C3) the same layers run conv_f16mma_kernel with
-                fp16 operands; at 2.5 PFLOP/s they are HBM-bound, so the object is priced in algorithmic bytes
-                against 8 TB/s.
+  roofline      dominant kernel = conv_s3_kernel<3,3,1,il,il> (the 34 residual-block 3x3 32->32 convolutions at 629x185 = 79 %
+                of the network's FLOPs and ~85 % of its GPU time): fp32 tensors, 3-term fp16 split on
+                v_mfma_f32_32x32x16_f16 with fp32 accumulation.  At 16x the fp32 matrix rate the layer is bound by moving its
+                tensors, so the object is priced in ALGORITHMIC bytes per launch (x + residual + y + weights + bias, each once,
+                SURVEY.md 8d) / average launch duration measured with HIP events on the launch stream (IProfiler path of the
+                executor) right after the timed region, against 8 TB/s.  `traffic` = HBM bytes per launch from the committed
+                PMC passes (profiles/rNN_traffic.json).  RT_CONV_EXACT_FP32=1 (round 1's fp32 Winograd kernel) is priced in
+                direct-form FLOPs against the fp32 matrix peak instead; --half2 (TensorRT half2 mode, BASELINE config C3) in
+                fp16 bytes.
                 `frac` uses the in-situ duration (event pairs inside the running network, other streams busy);
-                `isolated_launch_us` / `frac_isolated` are the same layer launched back-to-back on an idle GPU.
+                `isolated_launch_us` / `frac_isolated` are the same layer launched back-to-back on an idle GPU; `frac_step`
+                and `frac_of_fp32_mfma_peak*` put the step and the launch on round 1's scale (direct-form FLOPs / 157.3 TFLOP/s).
   cpu_baseline  the oracle (torch CPU restatement of the reference graph, oracle/stereo_oracle.py) timed
                 on this host's cores on a bounded sample of the same workload.
 """
@@ -277,6 +277,13 @@ def main():
         torch.cuda.synchronize(dev)
         dt1 = time.perf_counter() - t1
         single = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3, "steps": n1}
+        # ... and literally: IExecutionContext::execute (returns when the disparity is there), one call after the other
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            nets[0].execute(left, right, disps[0], b)
+        dt1 = time.perf_counter() - t1
+        single["synchronous_execute"] = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3,
+                                         "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309)"}
     # PCIe-inclusive rate (never `value`): the same K steps with each pair's two images copied host -> device and its
     # disparity device -> host, pinned buffers, copies on a per-context copy stream ordered by events so that they
     # overlap the convolutions of the other contexts (double-buffered H2D)

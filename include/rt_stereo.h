@@ -54,6 +54,7 @@ int rt_stream_destroy(rtStream stream);
 int rt_stream_sync(rtStream stream);
 int rt_stream_wait_event(rtStream stream, void* ev);   /* later work on `stream` waits for `ev` */
 int rt_event_create(void** ev);
+int rt_event_create_ordering(void** ev);              /* no timestamps: for rt_stream_wait_event only (cudaEventDisableTiming) */
 int rt_event_destroy(void* ev);
 int rt_event_record(void* ev, rtStream stream);
 int rt_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */

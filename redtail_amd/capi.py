@@ -50,6 +50,7 @@ KERNEL_SYMBOLS = {
     "rt_stream_sync": (c_int, [c_void_p]),
     "rt_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "rt_event_create": (c_int, [POINTER(c_void_p)]),
+    "rt_event_create_ordering": (c_int, [POINTER(c_void_p)]),
     "rt_event_destroy": (c_int, [c_void_p]),
     "rt_event_record": (c_int, [c_void_p, c_void_p]),
     "rt_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),

@@ -397,6 +397,7 @@ public:
     int max_batch_;
     size_t workspace_bytes_ = 0;
     bool two_streams_ = false;
+    std::vector<size_t> issue_sync_;   // op indices in the issue order of execute() (two streams alternating); empty = ops_ order
     ILogger& log_;
 
 private:
@@ -422,6 +423,7 @@ private:
     static bool isKind(LayerData* l, Kind k) { auto* s = stereo(l); return s && s->kind() == k; }
     bool lower();
     void assignStreams();
+    void planIssueOrder();
     void assignPitch();
     void foldConcats();
     void foldCostVolumes();
@@ -482,6 +484,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) foldConcats();
     if (ok_) foldCostVolumes();
     if (ok_) assignHalf3D();
+    if (ok_) planIssueOrder();          // last: the passes above remove ops
 }
 
 EngineImpl::~EngineImpl() {
@@ -886,6 +889,39 @@ void EngineImpl::assignStreams() {
     for (auto& op : ops_)
         for (auto& o2 : ops_)
             for (int w : o2.wait_on) op.publish |= (w == root(op.out));
+}
+
+void EngineImpl::planIssueOrder() {
+    if (!two_streams_) return;
+    // Issue order of the synchronous API (execute(): the reference's loop, sample_app/main.cpp:303-309): alternate between
+    // the two streams.  The network definition lists the whole left tower before the right one and a launch costs the host
+    // 3-4 us: with an idle GPU at the call the side stream's first kernel would start 18 launches (60-90 us) after the main
+    // stream's -- measured on MI355X, one context, round 2: 645 -> 613 us per pair.  Per stream the order is unchanged, and an
+    // op that waits for a tensor of the other stream is issued after that tensor's producer (the event it waits for must
+    // have been recorded).  enqueue() keeps the definition order: there the host runs ahead of the GPU and alternating
+    // streams costs it more per launch (167 vs 127 us per step; 2087 vs 2097 pairs/s with four contexts).
+    {
+        std::vector<size_t> q[2];
+        for (size_t i = 0; i < ops_.size(); i++) q[ops_[i].stream].push_back(i);
+        std::vector<char> produced(tensors_.size(), 0);
+        auto ready = [&](const Op& op) {
+            for (int w : op.wait_on)
+                if (!produced[w]) return false;
+            return true;
+        };
+        size_t h[2] = {0, 0};
+        int turn = 1;
+        while (issue_sync_.size() < ops_.size()) {
+            int st = turn;
+            if (h[st] >= q[st].size() || !ready(ops_[q[st][h[st]]])) st ^= 1;
+            if (h[st] >= q[st].size() || !ready(ops_[q[st][h[st]]])) break;        // cannot happen for a topological order
+            const size_t i = q[st][h[st]++];
+            issue_sync_.push_back(i);
+            for (int r = ops_[i].out; r >= 0; r = tensors_[r]->alias_of) produced[r] = 1;
+            turn = st ^ 1;
+        }
+        if (issue_sync_.size() != ops_.size()) issue_sync_.clear();
+    }
 }
 
 // Residual blocks in one launch: conv3x3 (+ELU) -> conv3x3 + skip (+ELU) with the skip connection being the block's input
@@ -1300,6 +1336,12 @@ void* ContextImpl::addr(int tensor, int, void** bindings) const {
     return static_cast<char*>(buffers_[t]) + off * (ti.f16 ? 2 : 4);
 }
 
+// events that only order streams carry no timestamps (RT_SYNC_EVENTS_TIMED=1: the round-1 behaviour, for A/B timing)
+static void order_event(void** ev) {
+    static const bool timed = getenv("RT_SYNC_EVENTS_TIMED") && atoi(getenv("RT_SYNC_EVENTS_TIMED")) != 0;
+    if (timed) rt_event_create(ev); else rt_event_create_ordering(ev);
+}
+
 bool ContextImpl::execute(int batchSize, void** bindings) {
     if (!main_stream_ && rt_stream_create(&main_stream_) != 0) return false;
     // execute() is the synchronous API: whatever the caller queued on the NULL stream (uploads, fills)
@@ -1326,8 +1368,8 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
     rtStream main = stream;
     if (two) {
         if (!side_stream_ && rt_stream_create(&side_stream_) != 0) return false;
-        if (!ev_fork_) rt_event_create(&ev_fork_);
-        if (!ev_join_) rt_event_create(&ev_join_);
+        if (!ev_fork_) order_event(&ev_fork_);
+        if (!ev_join_) order_event(&ev_join_);
         // the side stream must not start before work already queued on the caller's stream
         // (e.g. the H2D copies of the inputs) is done
         rt_event_record(ev_fork_, main);
@@ -1339,10 +1381,14 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         prof_events_.assign(2 * eng_.ops_.size(), nullptr);
         for (void*& e : prof_events_) rt_event_create(&e);
     }
-    size_t op_index = 0;
+    // issue order: see assignStreams(); event pairs and half buffers are indexed by the op's position in ops_
+    const int want = getenv("RT_INTERLEAVE") ? atoi(getenv("RT_INTERLEAVE")) : -1;     // A/B: 0 never, 1 always
+    const bool interleave = two && eng_.issue_sync_.size() == eng_.ops_.size() && (want < 0 ? sync : want != 0);
 
     bool ok = true;
-    for (const Op& op : eng_.ops_) {
+    for (size_t k = 0; k < eng_.ops_.size(); k++) {
+        const size_t op_index = interleave ? eng_.issue_sync_[k] : k;
+        const Op& op = eng_.ops_[op_index];
         rtStream st = (two && op.stream == 1) ? side_stream_ : main;
         if (two)
             for (int w : op.wait_on)
@@ -1422,11 +1468,10 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             break;
         }
         if (profile) rt_event_record(prof_events_[2 * op_index + 1], st);
-        op_index++;
         if (two && op.publish) {       // make the result visible to the consumer on the other stream
             int r = op.out;
             while (eng_.tensors_[r]->alias_of >= 0) r = eng_.tensors_[r]->alias_of;
-            if (!events_[r]) rt_event_create(&events_[r]);
+            if (!events_[r]) order_event(&events_[r]);
             rt_event_record(events_[r], st);
         }
         if (debug_sync_) rt_stream_sync(st);
@@ -1437,7 +1482,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
     }
     if (sync || profile) ok = (rt_stream_sync(main) == 0) && ok;
     if (profile && ok) {
-        for (size_t i = 0; i < op_index; i++) {
+        for (size_t i = 0; i < eng_.ops_.size(); i++) {
             float ms = 0.f;
             rt_event_elapsed_ms(prof_events_[2 * i], prof_events_[2 * i + 1], &ms);
             profiler_->reportLayerTime(eng_.ops_[i].name.c_str(), ms);

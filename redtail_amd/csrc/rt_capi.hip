@@ -184,6 +184,13 @@ extern "C" int rt_event_create(void** ev) {
     *ev = e;
     return 0;
 }
+extern "C" int rt_event_create_ordering(void** ev) {
+    RT_REQUIRE(ev, "rt_event_create_ordering: null");
+    hipEvent_t e;
+    RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return 0;
+}
 extern "C" int rt_event_destroy(void* ev) { RT_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
 extern "C" int rt_event_record(void* ev, rtStream s) { RT_HIP(hipEventRecord((hipEvent_t)ev, S(s))); return 0; }
 extern "C" int rt_event_elapsed_ms(void* a, void* b, float* ms) {

@@ -208,6 +208,8 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipEventCreate(hipEvent_t* e);
+enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

@@ -12,8 +12,22 @@ out = torch.empty(1, 1, 369, 1257, device="cuda")
 st = torch.cuda.Stream()
 for _ in range(5): net.execute(L, R, out, 1, stream=st.cuda_stream)
 torch.cuda.synchronize()
-ts = []
-for _ in range(50):
+ts, lat = [], []
+for _ in range(200):
     t0 = time.perf_counter(); net.execute(L, R, out, 1, stream=st.cuda_stream); ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
+    lat.append(time.perf_counter() - t0)
 print("host time per enqueue (GPU idle at call): median %.0f us  min %.0f us" % (np.median(ts) * 1e6, min(ts) * 1e6))
+print("synchronous loop (the reference's: execute, wait, next; sample_app/main.cpp:303-309): median %.0f us per pair = %.0f pairs/s" % (
+    np.median(lat[50:]) * 1e6, 1.0 / np.median(lat[50:])))
+# the same calls back to back (the bench loop): does the host run ahead of the GPU, or does a call block until the previous step
+# has drained?  host time per call and the time of the whole loop (GPU-bound if the host is ahead)
+ts = []
+t_all = time.perf_counter()
+for _ in range(60):
+    t0 = time.perf_counter(); net.execute(L, R, out, 1, stream=st.cuda_stream); ts.append(time.perf_counter() - t0)
+t_issue = time.perf_counter() - t_all
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t_all
+print("pipelined: host time per enqueue median %.0f us, first ten %s; all 60 issued after %.1f ms, finished after %.1f ms" % (
+    np.median(ts) * 1e6, " ".join("%.0f" % (t * 1e6) for t in ts[:10]), t_issue * 1e3, t_all * 1e3))
