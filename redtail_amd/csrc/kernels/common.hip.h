@@ -74,6 +74,16 @@ __device__ static __forceinline__ f32x2_t buf_load2(buf_rsrc r, unsigned voff, u
 __device__ static __forceinline__ void buf_store2(f32x2_t v, buf_rsrc r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
 }
+// 16-byte store.  The plane / channel offset is ADDED TO THE VECTOR OFFSET on purpose.  With a register in the soffset field the
+// compiler's hazard recognizer assumes the hardware protects the store data (no wait state before the data registers are
+// written again); on gfx950 it does not always: measured in round 2 (conv_rbs.hip.h, reproducible on every launch)
+//     buffer_store_dwordx4 v[0:3], v116, s[20:23], s3 offen ;  v_pk_add_f32 v[0:1], ...      <- next instruction
+// stores the NEW value of v1 in lanes 12-15 / 28-31 of each half wave.  With an immediate soffset the recognizer inserts the
+// wait state of the documented ">64-bit store data followed by a write of the data registers" hazard itself.  Offsets stay
+// below 2^31 and kBufOOB + soff is still out of range, so dropped lanes stay dropped.
+__device__ static __forceinline__ void buf_store4(f32x4 v, buf_rsrc r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff + soff, 0u, 0);
+}
 __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }

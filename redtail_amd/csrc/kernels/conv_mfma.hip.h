@@ -437,7 +437,7 @@ conv_mfma_f32_kernel(ConvArgs p) {
                         for (int e = 0; e < 4; e++) o[e] = apply_act_fast(acc[i][b][4 * q + e], decltype(ACT)::value);
                         const unsigned vo = (cs + 4 * half >= p.Cout) ? kBufOOB : yvoff[i];      // Cout is a multiple of 4
                         if (!kAblStore || o[0] == 12345.678f)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs, vo, so, 0);
+                            buf_store4(o, rs, vo, so);
                     }
                 }
             return;

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(NW / 4) conv_s3p_kern
                     o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bias4[q][e] + rr[q][e]), decltype(ACT)::value);
                 if constexpr (YIL) {
                     const unsigned vo = (inb && 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)(8 * q * cs32) * 4u, 0);
+                    buf_store4(o, rs_y, vo, (unsigned)(8 * q * cs32) * 4u);
                 } else {
                     const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
 #pragma unroll
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
                 o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
             if constexpr (YIL) {
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
+                buf_store4(o, rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u);
             } else {
                 const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * ESY : kBufOOB;
 #pragma unroll
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) conv_s3_first_kernel(C
             for (int e = 0; e < 4; e++) o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + bv[e], decltype(ACT)::value);
             if constexpr (YIL) {
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u, 0);
+                buf_store4(o, rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u);
             } else {
                 const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
 #pragma unroll
@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) conv_s3rb_kernel(RBArg
                 o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
             if constexpr (YIL) {
                 const unsigned vo = (inb && 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, vo, (unsigned)(8 * q * cs32) * 4u, 0);
+                buf_store4(o, rs_y, vo, (unsigned)(8 * q * cs32) * 4u);
             } else {
                 const unsigned vo = inb ? (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * kg * cs32) * 4u : kBufOOB;
 #pragma unroll

@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
                 for (int b = 0; b < 2; b++) {
                     const f32x4 o = {yo[0][a][b], yo[1][a][b], yo[2][a][b], yo[3][a][b]};
                     if (!kAblStore || o[0] == 12345.678f)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_y, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u, 0);
+                        buf_store4(o, rs_y, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
                 }
         }
     };

@@ -20,6 +20,7 @@
 #include "kernels/conv_f16.hip.h"
 #include "kernels/conv_f16_first.hip.h"
 #include "kernels/conv_split.hip.h"
+#include "kernels/conv_rbs.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/corr_mfma.hip.h"
 #include "kernels/elementwise.hip.h"
@@ -1747,6 +1748,17 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             ra.c.resid = static_cast<const float*>(x);          // the block's input is its skip connection
             ra.c.r_cstride = a.x_cstride; ra.c.r_bstride = plan->x_bstride; ra.c.r_il8 = sc.x_il8;
             ra.w1 = plan->rb_w1_dev; ra.bias1 = plan->rb_bias1_dev; ra.act1 = plan->rb_act1; ra.cmid = plan->rb_cmid;
+            // 32 -> 32 -> 32 channels, ELU after both, on interleaved tensors (the feature towers): the streaming form, strips of 30 columns x
+            // segments of 16 rows (conv_rbs.hip.h); everything else: one 4 x 32 tile per workgroup
+            if (sc.x_il8 && sc.y_il8 && plan->cin == 32 && plan->rb_cmid == 32 && sc.Cout == 32 && plan->rb_act1 == 1 && plan->act == 1 &&
+                env_int("RT_RB_TILES", 0) == 0) {
+                ra.c.tiles_x = (int)rt::cdiv(sc.Wo, rt::S3RBSCfg::SW);
+                dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, rt::S3RBSCfg::SEG)), 1u, (unsigned)batch);
+                if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rbs grid %u x %u\n", sgrid.x, sgrid.z);
+                hipLaunchKernelGGL(rt::conv_s3rbs_kernel, sgrid, dim3(512), 0, S(s), ra);      // ELU / ELU, as in every tower block
+                RT_LAUNCH_CHECK("conv_s3rbs_kernel");
+                continue;
+            }
             dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
             if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
             if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(256), 0, S(s), ra);

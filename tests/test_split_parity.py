@@ -203,6 +203,13 @@ RB_CASES = [
     (13, 9, 5, 9, 3, 0, (0, 0)),          # odd channel counts, image smaller than a tile
     (8, 8, 3, 5, 1, 32, (1, 1)),
     (4, 4, 1, 1, 2, 0, (0, 0)),           # single pixel
+    # 32 -> 32 -> 32 on interleaved tensors: the streaming kernel (conv_rbs.hip.h), strips of 30 columns x segments of 16 rows
+    (32, 32, 16, 30, 1, 32, (1, 1)),      # exactly one strip and one segment
+    (32, 32, 17, 31, 1, 0, (1, 1)),       # one row / one column past them, dense odd rows
+    (32, 32, 37, 61, 2, 64, (1, 1)),      # three segments (16 + 16 + 5), three strips (30 + 30 + 1), two images
+    (32, 32, 5, 100, 1, 128, (1, 1)),     # shorter than a segment
+    (32, 32, 1, 1, 1, 0, (1, 1)),         # single pixel
+    (32, 32, 33, 7, 1, 32, (1, 1)),       # narrower than a strip
 ]
 
 

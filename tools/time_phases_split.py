@@ -14,7 +14,8 @@ from redtail_amd import build, capi  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 general = os.environ.get("RT_S3P", "0") == "0"
-block = os.environ.get("RT_TIME_BLOCK", "0") != "0"      # the fused residual block (conv_s3rb_kernel)
+block = os.environ.get("RT_TIME_BLOCK", "0") != "0"      # the fused residual block (1: conv_s3rbs_kernel, streaming; with RT_RB_TILES=1 conv_s3rb_kernel)
+streaming = block and os.environ.get("RT_RB_TILES", "0") == "0"
 k = capi.KernelLib.__new__(capi.KernelLib)
 k.path = os.environ.get("RT_TIMING_LIB", os.path.join(build.ROOT, "tools", "build", "librt_stereo_hip_timing.so"))
 k.lib = ctypes.CDLL(k.path)
@@ -31,7 +32,7 @@ plan.set_pitch(640, 640)
 plan.set_layouts(1, 1, 1)
 x = torch.randn(b, 32, h, 640, device="cuda")
 y, r = torch.empty_like(x), (x if block else torch.randn_like(x))
-nwg = 47 * 20 * b if block else (47 * 20 * b if general else 256)
+nwg = 2 * 21 * 12 * b if streaming else 47 * 20 * b if block else (47 * 20 * b if general else 256)
 dbg = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda")
 for _ in range(3):
     plan.enqueue(x, y, r, b)
@@ -41,6 +42,21 @@ plan.enqueue(x, y, r, b)
 torch.cuda.synchronize()
 t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
 t = t[t[:, 0] > 0]
+if streaming:
+    for role, nm in ((0, "conv1 wave 0"), (1, "conv2 wave 4")):
+        tr = dbg.cpu().numpy().reshape(-1, 2, 16)[:, role].astype(np.float64)
+        tr = tr[(tr[:, 0] > 0) & (tr[:, 13] > 0)]            # full segments (6 steps)
+        names = ["start", "prologue loads issued", "prologue done (barrier)", "step 0 done", "s1 MFMAs issued", "s1 epilogue issued",
+                 "s1 next rows in LDS", "s1 barrier", "s2 MFMAs issued", "s2 epilogue issued", "s2 next rows in LDS", "s2 barrier",
+                 "step 3 done", "step 4 done", "end (step 5, stores acknowledged)"]
+        d = np.diff(tr[:, :15], axis=1)
+        print("streaming residual block, %s: phase durations in shader cycles (mean / p10 / p90 over %d workgroups)" % (nm, len(tr)))
+        for i in range(14):
+            print("  %-26s -> %-34s %9.1f %9.1f %9.1f" % (names[i], names[i + 1], d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+        life = tr[:, 14] - tr[:, 0]
+        print("  workgroup lifetime mean %.1f cycles; shader clock %.0f MHz; kernel span %.1f cycles" % (
+            life.mean(), life.sum() / tr[:, 15].sum() * 100.0, tr[:, 14].max() - tr[:, 0].min()))
+    sys.exit(0)
 if block:
     names = ["start", "gathers issued", "c0 in LDS", "conv1 c0 MFMAs", "c1 in LDS", "conv1 c1 MFMAs", "t written", "conv2 c0 MFMAs",
              "conv2 c1 MFMAs", "stores issued"]
