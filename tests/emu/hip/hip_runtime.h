@@ -185,6 +185,7 @@ static inline void hipemu_buffer_load_lds(const hipemu::buffer_rsrc& r, void* ld
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 
 // ---- runtime API subset used by rt_capi.hip ------------------------------------------------
