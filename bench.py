@@ -31,6 +31,7 @@ Extra objects on the JSON line:
                 on this host's cores on a bounded sample of the same workload.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -51,6 +52,26 @@ HALF_W, HALF_H = 629, 185
 DOMINANT_FLOPS = 2.0 * 32 * 32 * 9 * HALF_W * HALF_H      # one 3x3 32->32 conv at half resolution
 DOMINANT_BYTES = 4.0 * (3 * 32 * HALF_W * HALF_H + 32 * 32 * 9 + 32)     # x, residual, y, weights, bias
 NET_FLOPS = 91.87e9                    # whole network per pair at 1257x369, direct form
+
+
+def net_bytes_2d():
+    """ALGORITHMIC HBM bytes of one pair through the 48 launches of ResNet-18 2D at 1257x369, fp32: every launch reads its input
+    (+ skip tensor) and writes its output once (weights are noise: 2.9 MB in all)."""
+    px = lambda c, h, w: 4.0 * c * h * w
+    h2, w2, h4, w4, h8, w8, h16, w16 = HALF_H, HALF_W, 93, 315, 47, 158, 24, 79
+    t = px(32, h2, w2)
+    total = 2 * (px(3, H, W) + t)                              # conv1, left / right
+    total += 32 * 3 * t - 16 * t                               # 32 residual-block convolutions: x, y (+ skip on every second one)
+    total += 2 * 2 * t                                         # encoder2D_out x 2
+    total += 2 * t + px(1, h2, w2)                             # correlation + soft-argmax
+    total += px(33, h2, w2) + t + 2 * t                        # conv2D_1, conv2D_2
+    total += t + px(64, h4, w4) + 2 * 2 * px(64, h4, w4)       # conv2D_3ds, conv2D_4, conv2D_5
+    total += px(64, h4, w4) + px(128, h8, w8) + 2 * 2 * px(128, h8, w8)      # conv2D_6ds, conv2D_7, conv2D_8
+    total += px(128, h8, w8) + 2 * px(64, h4, w4)              # deconv2D_1 (+ skip)
+    total += px(64, h4, w4) + 2 * t                            # deconv2D_2 (+ skip)
+    total += t + px(1, H, W)                                   # deconv2D_3
+    return total
+
 
 
 def load_weights(half2):
@@ -153,6 +174,133 @@ def isolated_dominant(k, b, half2, launches=50, fused=False):
     return ms.value * 1e3 / launches
 
 
+
+# ---- the 3-D models (BASELINE configs C4 / C5): `--model nvsmall|resnet18|nvtiny [--half2] [--batch B]` --------------------------
+MODELS_3D = {"nvtiny": (513, 161, 24, "NVTINY_3D"), "nvsmall": (1025, 321, 48, "NVSMALL_3D"), "resnet18": (1025, 321, 68, "RESNET18_3D")}
+
+
+def trunk_bytes_3d(cfg, h, w, max_disp, es):
+    """ALGORITHMIC HBM bytes of the 3-D trunk per pair: every fused Conv3D / Conv3DTranspose launch reads its input (the first
+    one gathers the two 2-D feature maps instead of a cost volume), its skip tensor if it has one, and writes its output, each
+    once; `es` = bytes per element of the 4-D tensors (2 in half2 mode), the last layer's volume is fp32.  Returns (total,
+    {layer: bytes})."""
+    H, W, D = (h + 1) // 2, (w + 1) // 2, max_disp
+    dims = {}
+    per = {}
+    cur = None
+    half = lambda n: (n + 1) // 2
+    for i, (name, k, c, stride) in enumerate(cfg["conv3d"]):
+        if stride == 2:
+            D, H, W = half(D), half(H), half(W)
+        out = k * D * H * W
+        rd = (2 * cfg["feat"] * ((h + 1) // 2) * ((w + 1) // 2) * 4) if i == 0 else cur * es      # folded cost volume: two fp32 feature maps
+        per[name] = rd + out * es + 27 * k * c * 4
+        dims[name] = (k, D, H, W)
+        cur = out
+    n_dec = len(cfg["deconv3d"])
+    for i, (name, k, c, skip) in enumerate(cfg["deconv3d"]):
+        if skip:
+            kk, D, H, W = dims[skip]
+            out = c * D * H * W
+        else:                                                   # last layer: up to the image grid, one channel, fp32 volume
+            D, H, W = 2 * D, h, w
+            out = c * D * H * W
+        last = i == n_dec - 1
+        per[name] = cur * es + out * (4 if last else es) * (2 if skip else 1) + 27 * k * c * 4
+        cur = out
+    return float(sum(per.values())), per
+
+
+def main_3d(args, rank, world, local_rank, dev, distributed):
+    """One step = one IExecutionContext::enqueue of `--batch` stereo pairs through the whole 3-D network, inputs resident in HBM."""
+    w_img, h_img, max_disp, cfg_name = MODELS_3D[args.model]
+    cfg = getattr(synth, cfg_name)
+    weights = None
+    if rank == 0:
+        try:
+            path = model_files.weight_file(args.model, args.half2)
+            weights, desc = capi.read_weights(path, args.half2), "reference %s/TensorRT/%s" % (args.model, os.path.basename(path))
+        except FileNotFoundError as e:
+            print("bench.py: %s -- timing seeded synthetic weights instead" % e, file=sys.stderr)
+            weights, desc = synth.synth_weights_3d(cfg), "seeded He-normal (synthetic: the reference ships no such weight file)"
+        blob = capi.pack_weights(weights, fp16=args.half2)
+    if distributed:
+        import torch.distributed as dist
+        blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
+    lib = capi.NetLib()
+    lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
+    b = args.batch
+    nctx = max(1, min(args.contexts, 2))                      # the volumes are large: at most two contexts
+    nets = [lib.create(args.model, w_img, h_img, max_batch=b, weights=blob, fp16_weights=args.half2) for _ in range(nctx)]
+    ls, rs = zip(*(synth.synth_pair(h_img, w_img, 1234 + rank * 64 + i) for i in range(b)))
+    left, right = torch.from_numpy(np.stack(ls)).to(dev), torch.from_numpy(np.stack(rs)).to(dev)
+    disps = [torch.empty(b, 1, h_img, w_img, device=dev) for _ in nets]
+    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+
+    def step(i):
+        c = i % nctx
+        nets[c].execute(left, right, disps[c], b, stream=streams[c].cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+    for d in disps:
+        assert torch.isfinite(d).all(), "non-finite disparity"
+    if rank != 0:
+        return
+    es = 2 if args.half2 else 4
+    total, per = trunk_bytes_3d(cfg, h_img, w_img, max_disp, es)
+    prof = collections.defaultdict(list)
+    for _ in range(3):
+        for name, ms in nets[0].profile(left, right, disps[0], b):
+            prof[name].append(ms)
+    known = {n: sum(v) / len(v) for n, v in prof.items() if n in per}
+    dom = max(known, key=known.get)
+    dom_s = known[dom] * 1e-3
+    step_s = elapsed / args.steps
+    parity = None
+    if args.check:                                             # minutes of CPU at 1025 x 321; tests/test_net_parity.py does it in the GPU tier
+        from oracle import stereo_oracle as O
+        torch.set_num_threads(host_cores())
+        wref = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if args.half2 else v) for k, v in weights.items()}
+        with torch.no_grad():
+            ref = O.stereo3d(left[:1].cpu(), right[:1].cpu(), wref, cfg, max_disp)
+        parity = float((disps[0][:1].cpu() - ref).abs().max())
+    out = {
+        "metric": "stereo pairs/sec, %s 3D %dx%d" % (args.model, w_img, h_img), "value": world * args.steps * b / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "ms_per_pair": step_s / b * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 3-D tensors (f32 accumulate), f32 2-D towers" if args.half2 else "f32", "data": "synthetic",
+        "parity_max_abs_err": parity, "parity_note": "--check runs the CPU oracle at this size; tests/test_net_parity.py covers it in the GPU tier",
+        "config": {"workload": "%s 3-D Stereo DNN, %dx%d, max disparity %d, batch %d per step, %d context(s)" % (
+                       args.model, w_img, h_img, 2 * max_disp, b, nctx),
+                   "weights": desc, "launches_per_step": nets[0].num_launches(), "half2": bool(args.half2)},
+        "roofline": {"bound": "hbm", "kernel": "%s (conv_s3_kernel gather form / deconv3d kernels, DESIGN.md 4.1, 9)" % dom,
+                     "achieved": per[dom] * b / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom] * b / dom_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes": per[dom] * b, "avg_launch_us": dom_s * 1e6,
+                     "step_algorithmic_bytes": total * b, "step_gbs": total * b / step_s / 1e9,
+                     "frac_step": total * b / step_s / 1e9 / HBM_PEAK_GBS,
+                     "frac_step_note": "algorithmic bytes of the whole 3-D trunk (each tensor once per launch that touches it) / step time / 8 TB/s"},
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +313,9 @@ def main():
     ap.add_argument("--half2", action="store_true",
                     help="TensorRT half2 mode (BASELINE config C3): fp16 weight file, activations stored as fp16 between "
                          "launches, fp16 operands on the matrix cores with fp32 accumulation; the JSON line then says dtype f16")
+    ap.add_argument("--model", default="resnet18_2D", choices=["resnet18_2D"] + sorted(MODELS_3D),
+                    help="resnet18_2D (the headline) or one of the 3-D models (BASELINE configs C4 / C5): separate JSON line, HBM-priced roofline")
+    ap.add_argument("--check", action="store_true", help="3-D models: also run the CPU oracle at the timed size (minutes)")
     ap.add_argument("--from-host", action="store_true", help="also measure the PCIe-inclusive rate (extra JSON object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("RT_BENCH_SPINUP_MS", "80")),
@@ -200,6 +351,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.model != "resnet18_2D":
+        main_3d(args, rank, world, local_rank, dev, distributed)
+        if distributed:
+            torch.distributed.destroy_process_group()
+        return
 
     # ---- weights: rank 0 owns the file image, everyone else receives it over RCCL/xGMI ------------------
     weights, weights_desc = None, None
@@ -447,6 +603,11 @@ def main():
                     "frac_step_note": "91.87 GFLOP (direct form) per pair / ms_per_step / 157.3 TFLOP/s fp32 matrix peak; above 1 is "
                                       "possible because the split kernels run on the fp16 pipe",
                     "step_tflops": NET_FLOPS * b / step_s / 1e12,
+                    # ... and the whole step against the HBM roof: algorithmic bytes of all 48 launches (each tensor once per launch
+                    # that touches it; fp16 tensors in half2 mode) / step time -- what four overlapping contexts sustain
+                    "step_algorithmic_bytes": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b,
+                    "step_gbs": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b / step_s / 1e9,
+                    "frac_step_hbm": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b / step_s / 1e9 / HBM_PEAK_GBS,
                     # the same launch on round 1's scale (direct-form FLOPs / fp32 matrix peak, where the Winograd kernel had 0.63 / 0.69)
                     "direct_form_tflops": flops * b / avg_s / 1e12, "direct_form_tflops_isolated": flops * b / iso_us / 1e6,
                     "frac_of_fp32_mfma_peak": flops * b / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,

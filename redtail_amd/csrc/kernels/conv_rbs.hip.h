@@ -4,8 +4,8 @@
 //
 // (reference resnet18_2D_513x257_net.cpp:66-575: resblockN_conv1 -> ELU -> resblockN_conv2 -> add -> ELU, 8 blocks per
 // side = 32 of the network's 48 launches.)  Layer by layer the block moves x, t, t, x, y through HBM -- five tensor
-// passes, and with four contexts in flight the towers run at ~4.6 TB/s of such traffic, i.e. they are HBM-bound
-// (DESIGN.md 4.0).  Fused, the intermediate t never leaves the CU: two passes (+ halo).  conv_s3rb_kernel (conv_split.hip.h)
+// passes, and with four contexts in flight the towers run at ~3.8 TB/s of such traffic: memory-bound.
+// Fused, the intermediate t never leaves the CU: two passes (+ halo).  conv_s3rb_kernel (conv_split.hip.h)
 // does that per 4 x 32 tile and pays for it with a recomputed halo in BOTH directions, weights staged per tile and phases
 // that nothing overlaps; this kernel removes those three costs:
 //
