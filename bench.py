@@ -547,18 +547,17 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream ------
-        prof_runs, tot, cnt = 5, 0.0, 0
-        for _ in range(prof_runs):
-            for name, ms in net.profile(left, right, disp, b):
-                if dominant(name):
-                    tot += ms
-                    cnt += 1
+        prof_runs = 5
+        rows = [r for _ in range(prof_runs) for r in net.profile(left, right, disp, b)]
+        # residual blocks that run as ONE launch are named "<conv1>+<conv2>" by the executor (engine.cpp: fuseResBlocks)
+        fused = any(dominant(n) and "+" in n for n, _ in rows)
+        sel = [ms for n, ms in rows if dominant(n) and (("+" in n) == fused)]
+        tot, cnt = sum(sel), len(sel)
         avg_s = tot / cnt * 1e-3
         launches = cnt // prof_runs
         step_s = elapsed / args.steps
         traffic, traffic_src = measured_traffic(args.half2) if b == 1 else (None, None)
         exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
-        fused = launches == 16                                  # residual blocks run as one launch each (conv_s3rb_kernel)
         iso_us = isolated_dominant(lib.kernels, b, args.half2, fused=fused)
         flops = BLOCK_FLOPS if fused else DOMINANT_FLOPS
         if args.half2:
@@ -576,13 +575,29 @@ def main():
             # 16 x the fp32 rate -- 1/5 of the fp32 matrix time -- which leaves the layer bound by its fp32 traffic:
             # x + residual + y (+ weights, bias), every byte once
             nbytes = BLOCK_BYTES if fused else DOMINANT_BYTES
-            kernel = ("conv_s3rb_kernel<il,il>: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
-                      "intermediate in LDS; fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate" if fused else
+            kernel = ("conv_s3rbs_kernel: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
+                      "streaming down 30-column strips, intermediate rows in an LDS ring; fp32 tensors, 3-term fp16 split on "
+                      "v_mfma_f32_32x32x16_f16, fp32 accumulate" if fused else
                       "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate")
-            mfma_exec = 3.0 * flops * ((11.0 / 8.0 + 1.0) / 2.0 if fused else 1.0)     # conv1 is recomputed on the 10 x 34 halo region: 11 / 8
+            if fused:
+                # executed matrix work of the streaming kernel: 21 strips x segments, every step computes 4 rows x 32 columns of
+                # conv1 and of conv2 (halo rows / columns and the rows of the pipeline's fill and drain steps included)
+                seg = int(os.environ.get("RT_RBS_SEG", "0")) or 32
+                strips, rows_exec = -(-HALF_W // 30), 0
+                for y0 in range(0, HALF_H, seg):
+                    hseg = min(seg, HALF_H - y0)
+                    rows_exec += 4 * ((hseg + 1) // 4 + 1) + 4 * ((hseg + 1 + 4) // 4)          # conv1: steps 0..last1, conv2: steps 1..nstep-1
+                mfma_exec = 3.0 * strips * rows_exec * 2.0 * 32 * 32 * 32 * 9
+            else:
+                mfma_exec = 3.0 * flops
         if exact and not args.half2:
             achieved, peak, unit, bound = flops * b / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
             iso_frac = flops * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
+        elif fused and not args.half2:
+            # the fused block moves 2.8x fewer bytes than its two layers and is bound by matrix (+ vector) issue, not by HBM
+            # (DESIGN.md 4.4): priced in EXECUTED fp16 matrix FLOPs against the dense fp16 peak
+            achieved, peak, unit, bound = mfma_exec * b / avg_s / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            iso_frac = mfma_exec * b / iso_us / 1e6 / MFMA_F16_PEAK_TFLOPS
         else:
             achieved, peak, unit, bound = nbytes * b / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
             iso_frac = nbytes * b / iso_us / 1e3 / HBM_PEAK_GBS
@@ -615,7 +630,16 @@ def main():
                     "mfma_flops_executed": mfma_exec * b,
                     "mfma_util_executed": mfma_exec * b / iso_us / 1e6 / mfma_peak,
                     "mfma_util_note": "executed matrix FLOPs of one launch / isolated duration / %.0f TFLOP/s (%s pipe)" % (
-                        mfma_peak, "fp32" if (exact and not args.half2) else "fp16")}
+                        mfma_peak, "fp32" if (exact and not args.half2) else "fp16"),
+                    "hbm_gbs": nbytes * b / avg_s / 1e9, "frac_hbm": nbytes * b / avg_s / 1e9 / HBM_PEAK_GBS,
+                    "frac_hbm_note": "algorithmic bytes of the same launch / in-situ duration / 8 TB/s"}
+        if fused and not args.half2:
+            # continuity with the layer-by-layer kernel (the roofline object of earlier benches; still runs the other 18 convolutions)
+            g_us = isolated_dominant(lib.kernels, b, args.half2, fused=False)
+            roofline["layer_by_layer_kernel"] = {"kernel": "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU)", "bound": "hbm",
+                                                 "isolated_launch_us": g_us, "algorithmic_bytes": DOMINANT_BYTES * b,
+                                                 "achieved": DOMINANT_BYTES * b / g_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac_isolated": DOMINANT_BYTES * b / g_us / 1e3 / HBM_PEAK_GBS}
         out = {
             "metric": "stereo pairs/sec, ResNet18-2D 1257x369", "value": world * args.steps * b / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

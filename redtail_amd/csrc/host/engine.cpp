@@ -348,6 +348,7 @@ private:
     std::vector<void*> prof_events_;   // start/stop pair per launch (IProfiler)
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
+    void* ev_null_ = nullptr;
     std::map<std::pair<int, int>, std::pair<void*, size_t>> half_buf_;   // (op, slot) -> fp16 staging buffer of a kHALF plugin
     void* halfBuffer(int op, int slot, size_t bytes);
 };
@@ -929,11 +930,14 @@ void EngineImpl::planIssueOrder() {
 // tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  Not in half2 mode, where the two layers run on fp16
 // operands with fp16 tensors in between.
 void EngineImpl::fuseResBlocks() {
-    // Opt-in (RT_RB=1).  Measured on MI355X (profiles/README.md, round 2): the fused block takes 27.9 us alone against 2 x 14.1 us
-    // for its two layers -- one workgroup per CU (150 KB of LDS) runs gather, conv1, conv2 and the stores back to back with nothing
-    // to overlap them, and 11 column blocks of conv1 do not spread evenly over 8 waves -- and the network is slower with it
-    // (1934 vs 2069 pairs/s).  It needs a persistent, software-pipelined tile loop to pay; until then the layers stay separate.
-    if (!getenv("RT_RB") || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (half2_ && !getenv("RT_NO_F16"))) return;
+    // Default: the blocks the STREAMING kernel serves (conv_rbs.hip.h: 32 -> 32 -> 32 channels, ELU after both, interleaved
+    // tensors) on images large enough to fill the GPU with its strips x segments -- measured on MI355X, round 2, ResNet-18 2D at
+    // 1257x369 with four contexts: 2185 vs 2057 pairs/s, 2.8x less HBM traffic per block.  Everything else stays two launches: the
+    // per-tile form of the fused block (conv_s3rb_kernel) is slower than its two layers (1934 vs 2069 pairs/s).
+    // RT_RB=1 fuses every block rt_resblock_plan_create accepts (tests, A/B), RT_RB=0 / RT_NO_RB none.
+    const char* e = getenv("RT_RB");
+    const bool force = e && atoi(e) != 0;
+    if ((e && !force) || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (getenv("RT_CONV_EXACT_FP32") && atoi(getenv("RT_CONV_EXACT_FP32")) != 0) || (half2_ && !getenv("RT_NO_F16"))) return;
     int fused = 0;
     for (size_t ia = 0; ia < ops_.size(); ia++) {
         Op& a = ops_[ia];
@@ -964,6 +968,16 @@ void EngineImpl::fuseResBlocks() {
             return d;
         };
         const rtConv2dDesc d1 = desc(a, false), d2 = desc(b, true);
+        if (!force) {
+            bool ok = d1.Cin == 32 && d1.Cout == 32 && d2.Cout == 32 && a.act == RT_ACT_ELU && b.act == RT_ACT_ELU && d1.Cin % 4 == 0;
+            // enough strips (30 columns) x segments (16 rows) for every CU
+            ok = ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200;
+            // a block whose input is written straight into a concatenation (foldConcats) reads a planar tensor
+            for (const Op& o : ops_)
+                if (o.kind == OpKind::kConcat)
+                    for (int x : o.in) ok = ok && root(x) != root(a.in[0]);
+            if (!ok) continue;
+        }
         const LayerData *la = a.conv_layer, *lb = b.conv_layer;
         rtConvPlan* rb = nullptr;
         if (rt_resblock_plan_create(&rb, &d1, la->kernel.values, la->bias.count ? la->bias.values : nullptr, &d2, lb->kernel.values,
@@ -975,6 +989,7 @@ void EngineImpl::fuseResBlocks() {
         a.out = b.out;
         a.resid = b.resid;
         a.act = b.act;
+        a.name += "+" + b.name;                         // IProfiler rows name both layers
         ops_.erase(ops_.begin() + ib);
         fused++;
     }
@@ -1278,6 +1293,7 @@ ContextImpl::~ContextImpl() {
         if (ev) rt_event_destroy(ev);
     if (ev_fork_) rt_event_destroy(ev_fork_);
     if (ev_join_) rt_event_destroy(ev_join_);
+    if (ev_null_) rt_event_destroy(ev_null_);
     if (side_stream_) rt_stream_destroy(side_stream_);
     if (main_stream_) rt_stream_destroy(main_stream_);
 }
@@ -1344,9 +1360,11 @@ static void order_event(void** ev) {
 
 bool ContextImpl::execute(int batchSize, void** bindings) {
     if (!main_stream_ && rt_stream_create(&main_stream_) != 0) return false;
-    // execute() is the synchronous API: whatever the caller queued on the NULL stream (uploads, fills)
-    // must be complete before our own non-blocking streams touch the bindings
-    if (rt_stream_sync(nullptr) != 0) return false;
+    // execute() is the synchronous API: whatever the caller queued on the NULL stream (uploads, fills) must be complete before
+    // our own non-blocking streams touch the bindings -- ordered on the device (an event of the NULL stream), not by blocking
+    // the host before the first launch is issued
+    if (!ev_null_) order_event(&ev_null_);
+    if (rt_event_record(ev_null_, nullptr) != 0 || rt_stream_wait_event(main_stream_, ev_null_) != 0) return false;
     return run(batchSize, bindings, (cudaStream_t)main_stream_, true);
 }
 

@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
     }
     const int H = p.Hi, W = p.Wi;                       // stride 1, same padding: the three grids coincide
     const int c0 = (tile % p.tiles_x) * Cfg::SW;        // first output column of the strip
-    const int y0 = (tile / p.tiles_x) * Cfg::SEG;       // first output row of the segment
-    const int y1 = y0 + Cfg::SEG < H ? y0 + Cfg::SEG : H;
+    const int y0 = (tile / p.tiles_x) * a.seg;          // first output row of the segment (a.seg rows, a multiple of 4)
+    const int y1 = y0 + a.seg < H ? y0 + a.seg : H;
     const int t0 = y0 - 1;                              // first intermediate row
     const int n = blockIdx.z;
     // step s: conv1 rows t0 + 4s .. + 3 (needed up to row y1), conv2 rows t0 + 4s - 5 .. - 2 (valid in [y0, y1))
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
     const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
     const unsigned cs_x = (unsigned)p.x_cstride, rowb_x = (unsigned)p.x_pitch * 16u;
     // per gather slot: byte offset of (group, first row of batch 0, column) -- a batch adds a scalar row offset --, and packed:
-    // LDS offset inside a ring row << 5 | (last batch in which the slot's row is needed + 1) << 2 | row of the batch
+    // LDS offset inside a ring row << 8 | (last batch in which the slot's row is needed + 1) << 2 | row of the batch
     unsigned xbase[NKX];
     int xmeta[NKX];
     const int row_hi = (y1 + 1 < H - 1 ? y1 + 1 : H - 1);          // last input row the segment needs
@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
         const bool valid = idx < Cfg::NSLOT;
         // batch b holds rows t0 + 4b + 1 + row: needed while that is <= row_hi
         const int d = row_hi - (t0 + 1 + row);
-        const int bmax = d < 0 ? -1 : (d >> 2);                    // <= 5
+        const int bmax = d < 0 ? -1 : (d >> 2);                    // <= 62: segments of up to 248 rows
         xbase[k] = (valid && ix >= 0 && ix < W) ? (unsigned)g * cs_x * 16u + (unsigned)ix * 16u + (unsigned)(t0 + 1 + row) * rowb_x : kBufOOB;
-        xmeta[k] = valid ? ((((g >> 2) * XCOL + px) * PXB + (g & 3) * 8) << 5) | ((bmax + 1) << 2) | row : -1;
+        xmeta[k] = valid ? ((((g >> 2) * XCOL + px) * PXB + (g & 3) * 8) << 8) | ((bmax + 1) << 2) | row : -1;
     }
     f32x4 rin[NKX];
     // batches b >= 0 (rows >= y0 >= 0): one compare + select per slot, the batch's row offset is a scalar
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
         const unsigned so = (unsigned)(4 * b) * rowb_x;
 #pragma unroll
         for (int k = 0; k < NKX; k++) {
-            const bool ok = b < ((xmeta[k] >> 2) & 7);             // b <= bmax (xmeta = -1: xbase is kBufOOB anyway)
+            const bool ok = b < ((xmeta[k] >> 2) & 63);             // b <= bmax (xmeta = -1: xbase is kBufOOB anyway)
             r[k] = buf_load4(rs_x, ok ? xbase[k] : kBufOOB, so);
         }
     };
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
             int slot = sb + (xmeta[k] & 3);
             slot = slot >= RING ? slot - RING : slot;
             const S3Split sp = s3_split(r[k]);
-            char* dst = sX + slot * ROWB + (xmeta[k] >> 5);
+            char* dst = sX + slot * ROWB + (xmeta[k] >> 8);
             *reinterpret_cast<f16x4*>(dst) = sp.hi;
             *reinterpret_cast<f16x4*>(dst + 32) = sp.lo;
         }
@@ -138,22 +138,25 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
         rin0[k] = buf_load4(rs_x, ok ? xbase[k] - 4u * rowb_x : kBufOOB, 0u);
     }
     load_batch(0, rin);
-    f16x8 wh[18];                                       // [chunk * 9 + tap]: high parts of this wave's A operands
+    // weights: each convolution's split weights are fetched ONCE per workgroup (its four waves would otherwise fetch the same
+    // 18 KB of high parts each): low parts into sWl for good, high parts through the (still unused) t ring into registers
     {
         // slab order of the split weights (rt_capi.hip: pack_into): [chunk][tap][hi/lo][k-group][co][8 halfs], 16-byte slots
         const buf_rsrc rs_w = make_buf(is1 ? a.w1 : p.w);
+        f32x4 rw[2 * Cfg::NK_WL];
 #pragma unroll
-        for (int t = 0; t < 18; t++) wh[t] = __builtin_bit_cast(f16x8, buf_load4(rs_w, (unsigned)lane * 16u, (unsigned)(t * 128) * 16u));
-        f32x4 rwl[Cfg::NK_WL];
-#pragma unroll
-        for (int k = 0; k < Cfg::NK_WL; k++) {
-            const int idx = (tid & 255) + 256 * k;      // [tap-chunk][lane]
-            rwl[k] = buf_load4(rs_w, idx < Cfg::WL_SLOTS ? (unsigned)((idx >> 6) * 128 + 64 + (idx & 63)) * 16u : kBufOOB, 0u);
+        for (int k = 0; k < 2 * Cfg::NK_WL; k++) {
+            const int idx = (tid & 255) + 256 * k;      // [tap-chunk][hi/lo][lane]: the slab itself
+            rw[k] = buf_load4(rs_w, idx < 2 * Cfg::WL_SLOTS ? (unsigned)idx * 16u : kBufOOB, 0u);
         }
+        f32x4* whs = reinterpret_cast<f32x4*>(sT) + (is1 ? 0 : Cfg::WL_SLOTS);
 #pragma unroll
-        for (int k = 0; k < Cfg::NK_WL; k++) {
+        for (int k = 0; k < 2 * Cfg::NK_WL; k++) {
             const int idx = (tid & 255) + 256 * k;
-            if (idx < Cfg::WL_SLOTS) sWl[(is1 ? 0 : Cfg::WL_SLOTS) + idx] = rwl[k];
+            if (idx >= 2 * Cfg::WL_SLOTS) continue;
+            const int tt = idx >> 7, hl = (idx >> 6) & 1, ln = idx & 63;
+            if (hl) sWl[(is1 ? 0 : Cfg::WL_SLOTS) + tt * 64 + ln] = rw[k];
+            else whs[tt * 64 + ln] = rw[k];
         }
     }
     RBS_STAMP(1);                                       // prologue loads issued
@@ -161,6 +164,13 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
     store_batch(-1, rin0);
     store_batch(0, rin);
     __syncthreads();
+    f16x8 wh[18];                                       // [chunk * 9 + tap]: high parts of this wave's A operands
+    {
+        const f32x4* whs = reinterpret_cast<const f32x4*>(sT) + (is1 ? 0 : Cfg::WL_SLOTS) + lane;
+#pragma unroll
+        for (int t = 0; t < 18; t++) wh[t] = __builtin_bit_cast(f16x8, whs[t * 64]);
+    }
+    __syncthreads();                                    // the t ring is free for conv1's first rows
     RBS_STAMP(2);                                       // first rows and low weight parts in LDS, high parts in registers
 
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride + p.y_off, 4));

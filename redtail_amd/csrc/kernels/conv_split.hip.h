@@ -691,6 +691,7 @@ struct RBArgs {
     const float* bias1;    // padded to 64
     int act1;
     int cmid;              // channels of the intermediate (conv1's outputs = conv2's inputs)
+    int seg;               // conv_s3rbs_kernel: output rows per workgroup (a multiple of 4)
 };
 
 template <bool XIL, bool YIL>

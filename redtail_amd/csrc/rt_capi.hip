@@ -1747,13 +1747,21 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             ra.c = a;
             ra.c.resid = static_cast<const float*>(x);          // the block's input is its skip connection
             ra.c.r_cstride = a.x_cstride; ra.c.r_bstride = plan->x_bstride; ra.c.r_il8 = sc.x_il8;
-            ra.w1 = plan->rb_w1_dev; ra.bias1 = plan->rb_bias1_dev; ra.act1 = plan->rb_act1; ra.cmid = plan->rb_cmid;
+            ra.w1 = plan->rb_w1_dev; ra.bias1 = plan->rb_bias1_dev; ra.act1 = plan->rb_act1; ra.cmid = plan->rb_cmid; ra.seg = 0;
             // 32 -> 32 -> 32 channels, ELU after both, on interleaved tensors (the feature towers): the streaming form, strips of 30 columns x
             // segments of 16 rows (conv_rbs.hip.h); everything else: one 4 x 32 tile per workgroup
             if (sc.x_il8 && sc.y_il8 && plan->cin == 32 && plan->rb_cmid == 32 && sc.Cout == 32 && plan->rb_act1 == 1 && plan->act == 1 &&
                 env_int("RT_RB_TILES", 0) == 0) {
                 ra.c.tiles_x = (int)rt::cdiv(sc.Wo, rt::S3RBSCfg::SW);
-                dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, rt::S3RBSCfg::SEG)), 1u, (unsigned)batch);
+                // rows per workgroup: the pipeline's fill and drain steps and the prologue are paid per segment, so longer segments
+                // cost fewer CU-cycles per row; shorter ones fill more CUs of an otherwise idle GPU (RT_RBS_SEG, default: see DESIGN.md 4.4)
+                // Measured in the running network (ResNet-18 2D, 1257x369, four contexts): 16 rows 2129, 24: 2178, 32: 2185, 48: 2067,
+                // 64: 1957 pairs/s (two launches of the layer-by-layer kernels: 2057); alone 16 rows are fastest (24.5 vs 32.4 us).
+                int seg = env_int("RT_RBS_SEG", 0);
+                if (seg <= 0) seg = ra.c.tiles_x * (int)rt::cdiv(sc.Ho, 32) * batch >= 120 ? 32 : rt::S3RBSCfg::SEG;
+                seg = seg < 4 ? 4 : (seg > 240 ? 240 : (seg + 3) / 4 * 4);
+                ra.seg = seg;
+                dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, seg)), 1u, (unsigned)batch);
                 if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rbs grid %u x %u\n", sgrid.x, sgrid.z);
                 hipLaunchKernelGGL(rt::conv_s3rbs_kernel, sgrid, dim3(512), 0, S(s), ra);      // ELU / ELU, as in every tower block
                 RT_LAUNCH_CHECK("conv_s3rbs_kernel");

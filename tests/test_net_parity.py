@@ -79,6 +79,25 @@ def test_resnet18_2d_tiny(rt):
     assert layers > 100 and launches < layers / 2     # conv+add+ELU, corr+softargmax fused
 
 
+def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
+    """RT_RB=1: every residual block of the two towers as ONE launch (streaming kernel where the tensors are interleaved, per-tile
+    kernel for the left tower's first block, whose input is written straight into a concatenation); 73 x 41 image = two strips
+    and two segments at half resolution (37 x 21) with 16-row segments, one with 32.  Same numbers as layer by layer."""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 41, 73)
+    base, (_, launches0) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    monkeypatch.setenv("RT_RB", "1")
+    for seg in ("16", "32"):
+        monkeypatch.setenv("RT_RBS_SEG", seg)
+        out, (layers, launches) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+        assert launches == launches0 - 16                  # 16 blocks, two launches -> one
+        assert not np.isnan(out).any()
+        assert np.abs(out - base).max() <= 2e-5, np.abs(out - base).max()
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w, max_disp=8).numpy()
+    assert np.abs(out - ref).max() <= 2e-4
+
+
 def test_resnet18_2d_unfused_equals_fused(rt, monkeypatch):
     """RT_NO_FUSION runs every plugin through its own enqueue(), i.e. the reference's layer-by-layer order"""
     w = O.synth_weights_resnet18_2d()
@@ -229,8 +248,10 @@ def test_resnet18_2d_full_size(w, h, batch):
     with torch.no_grad():
         ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), weights)
     err = (out.cpu() - ref).abs().max().item()
-    print("ResNet-18 2D %dx%d batch %d, real weights: max |disp - oracle| = %.3g" % (w, h, batch, err))
+    print("ResNet-18 2D %dx%d batch %d, real weights: max |disp - oracle| = %.3g, %d launches" % (w, h, batch, err, net.num_launches))
     assert err <= 1e-3, err
+    # at 1257x369 the executor runs 15 of the 16 residual blocks as one (streaming) launch each; at 513x257 none (too few strips)
+    assert net.num_launches == (33 if w == 1257 else 48), net.num_launches
     net.destroy()
 
 

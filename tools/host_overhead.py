@@ -20,6 +20,10 @@ for _ in range(200):
 print("host time per enqueue (GPU idle at call): median %.0f us  min %.0f us" % (np.median(ts) * 1e6, min(ts) * 1e6))
 print("synchronous loop (the reference's: execute, wait, next; sample_app/main.cpp:303-309): median %.0f us per pair = %.0f pairs/s" % (
     np.median(lat[50:]) * 1e6, 1.0 / np.median(lat[50:])))
+lat = []
+for _ in range(200):
+    t0 = time.perf_counter(); net.execute(L, R, out, 1); lat.append(time.perf_counter() - t0)
+print("IExecutionContext::execute() in a loop: median %.0f us per pair = %.0f pairs/s" % (np.median(lat[50:]) * 1e6, 1.0 / np.median(lat[50:])))
 # the same calls back to back (the bench loop): does the host run ahead of the GPU, or does a call block until the previous step
 # has drained?  host time per call and the time of the whole loop (GPU-bound if the host is ahead)
 ts = []

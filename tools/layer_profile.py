@@ -32,7 +32,7 @@ groups = {}
 for name in order:
     key = name.replace("left_", "L/R ").replace("right_", "L/R ")
     if "resblock" in key:
-        key = "L/R resblock*_conv*"
+        key = "L/R resblock* (block = one launch)" if "+" in name else "L/R resblock*_conv*"
     groups.setdefault(key, [0, 0.0])
     groups[key][0] += 1
     groups[key][1] += acc[name] / runs * 1e3

@@ -17,11 +17,14 @@ import os
 import shutil
 import sys
 
-DOMINANT = "conv_s3_kernel<3, 3, 1, ...>"      # every tensor-layout variant of the split-fp16 3x3 stride-1 kernel
+# Dominant kernel of the run: the streaming residual block (conv_rbs.hip.h) when the executor fuses the tower blocks (default since
+# the end of round 2), else every tensor-layout variant of the split-fp16 3x3 stride-1 kernel.  FUSED is set in main().
+FUSED = False
+DOMINANT = "conv_s3_kernel<3, 3, 1, ...>"
 
 
 def is_dom(name):
-    return name.startswith("conv_s3_kernel<3, 3, 1,")
+    return name.startswith("conv_s3rbs_kernel") if FUSED else name.startswith("conv_s3_kernel<3, 3, 1,")
 
 DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (the kernel also runs the low-resolution layers)
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
@@ -38,7 +41,14 @@ def short(name):
 
 
 def main():
+    global FUSED, DOMINANT, DOMINANT_GRID, ALGO_READ, ALGO_WRITE
     run, tag = sys.argv[1], sys.argv[2]
+    stats = open(os.path.join(run, "trace", "bench_kernel_stats.csv")).read()
+    if "conv_s3rbs_kernel" in stats:
+        FUSED, DOMINANT = True, "conv_s3rbs_kernel"
+        DOMINANT_GRID = 21 * 6 * 512                               # 21 strips x 6 segments of 32 rows, 8 waves
+        ALGO_READ = 4.0 * (32 * 185 * 629 + 2 * (32 * 32 * 9 + 32))   # x + both layers' weights and biases
+        ALGO_WRITE = 4.0 * 32 * 185 * 629
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
