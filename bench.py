@@ -94,7 +94,7 @@ BLOCK_FLOPS = 2.0 * DOMINANT_FLOPS
 BLOCK_BYTES = 4.0 * (2 * 32 * HALF_W * HALF_H + 2 * (32 * 32 * 9 + 32))
 
 
-def measured_traffic(half2=False):
+def measured_traffic(half2=False, fused=None):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/rNN_traffic.json,
     written by tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this
     command; counters cannot be read from inside the timed process).  None when no such file is present."""
@@ -103,6 +103,8 @@ def measured_traffic(half2=False):
     if not files:
         return None, None
     t = json.load(open(files[-1]))
+    if fused is not None and ("conv_s3rbs" in t.get("kernel", "")) != fused:
+        return None, None                                   # the PMC pass was taken with the other kernel as the dominant one
     return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
@@ -290,7 +292,7 @@ def main_3d(args, rank, world, local_rank, dev, distributed):
         "parity_max_abs_err": parity, "parity_note": "--check runs the CPU oracle at this size; tests/test_net_parity.py covers it in the GPU tier",
         "config": {"workload": "%s 3-D Stereo DNN, %dx%d, max disparity %d, batch %d per step, %d context(s)" % (
                        args.model, w_img, h_img, 2 * max_disp, b, nctx),
-                   "weights": desc, "launches_per_step": nets[0].num_launches(), "half2": bool(args.half2)},
+                   "weights": desc, "launches_per_step": nets[0].num_launches, "half2": bool(args.half2)},
         "roofline": {"bound": "hbm", "kernel": "%s (conv_s3_kernel gather form / deconv3d kernels, DESIGN.md 4.1, 9)" % dom,
                      "achieved": per[dom] * b / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom] * b / dom_s / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes": per[dom] * b, "avg_launch_us": dom_s * 1e6,
@@ -439,7 +441,9 @@ def main():
             nets[0].execute(left, right, disps[0], b)
         dt1 = time.perf_counter() - t1
         single["synchronous_execute"] = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3,
-                                         "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309)"}
+                                         "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309); execute() orders itself "
+                                                 "after the legacy NULL stream, which this process pays for each of its other (blocking) streams: "
+                                                 "tools/host_overhead.py measures 606 us per pair with one"}
     # PCIe-inclusive rate (never `value`): the same K steps with each pair's two images copied host -> device and its
     # disparity device -> host, pinned buffers, copies on a per-context copy stream ordered by events so that they
     # overlap the convolutions of the other contexts (double-buffered H2D)
@@ -556,7 +560,7 @@ def main():
         avg_s = tot / cnt * 1e-3
         launches = cnt // prof_runs
         step_s = elapsed / args.steps
-        traffic, traffic_src = measured_traffic(args.half2) if b == 1 else (None, None)
+        traffic, traffic_src = measured_traffic(args.half2, None if args.half2 else fused) if b == 1 else (None, None)
         exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
         iso_us = isolated_dominant(lib.kernels, b, args.half2, fused=fused)
         flops = BLOCK_FLOPS if fused else DOMINANT_FLOPS
