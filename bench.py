@@ -135,8 +135,19 @@ def cpu_baseline(weights, budget_s=12.0):
             dt = time.perf_counter() - t0
             if dt >= budget_s or n >= 512:
                 break
-    return dict(value=n / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
+    out = dict(value=n / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+               sample="%d pairs of 1257x369 in %.1f s, torch %s CPU fp32 oracle" % (n, dt, torch.__version__))
+    # the same oracle on ONE core (what a scalar port would be measured as): a few pairs
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        n1, t1 = 0, time.perf_counter()
+        while n1 < 2 or time.perf_counter() - t1 < 4.0:
+            O.resnet18_2d(L, R, weights)
+            n1 += 1
+        d1 = time.perf_counter() - t1
+    torch.set_num_threads(host_cores())
+    out["one_core"] = dict(value=n1 / d1, unit="pairs/s", cores=1, sample="%d pairs in %.1f s" % (n1, d1))
+    return out
 
 
 def isolated_dominant(k, b, half2, launches=50, fused=False):
