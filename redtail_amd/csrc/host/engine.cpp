@@ -937,7 +937,7 @@ void EngineImpl::fuseResBlocks() {
     // RT_RB=1 fuses every block rt_resblock_plan_create accepts (tests, A/B), RT_RB=0 / RT_NO_RB none.
     const char* e = getenv("RT_RB");
     const bool force = e && atoi(e) != 0;
-    if ((e && !force) || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || (getenv("RT_CONV_EXACT_FP32") && atoi(getenv("RT_CONV_EXACT_FP32")) != 0) || (half2_ && !getenv("RT_NO_F16"))) return;
+    if ((e && !force) || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || getenv("RT_NO_S3") || (getenv("RT_CONV_EXACT_FP32") && atoi(getenv("RT_CONV_EXACT_FP32")) != 0) || (half2_ && !getenv("RT_NO_F16"))) return;
     int fused = 0;
     for (size_t ia = 0; ia < ops_.size(); ia++) {
         Op& a = ops_[ia];
