@@ -5,11 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
-network (48 fused launches) with the inputs already resident in HBM (the reference times
+network (33 launches at this size) with the inputs already resident in HBM (the reference times
 context->execute the same way, sample_app/main.cpp:303-309).  Steps are issued round-robin over
---contexts execution contexts of the same engine configuration, each on its own stream (default 4, the
-usual TensorRT throughput set-up): the serial low-resolution tail of one pair then overlaps the encoder
-of the next.  "single_context" on the JSON line is the same workload through one context.  Stereo pairs are independent, so ranks
+--contexts execution contexts of the same engine configuration, each on its own stream (default 6 with one
+HIP stream each, the TensorRT throughput set-up `trtexec --streams`): the serial low-resolution tail of one pair
+then overlaps the encoder of the next.  "single_context" on the JSON line is the same workload through one
+context with two streams (the latency set-up), "synchronous_execute" the reference's own loop.  Stereo pairs are independent, so ranks
 share nothing but the weights: rank 0 builds the weight-file image and broadcasts it over RCCL
 (torch.distributed backend "nccl"); there is no data-path collective and scaling is weak (each rank
 processes its own K pairs).
@@ -106,6 +107,19 @@ def measured_traffic(half2=False, fused=None):
     if fused is not None and ("conv_s3rbs" in t.get("kernel", "")) != fused:
         return None, None                                   # the PMC pass was taken with the other kernel as the dominant one
     return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
+def make_streams(klib, n, dev):
+    """n NON-BLOCKING HIP streams (rt_stream_create = hipStreamNonBlocking), wrapped for torch.  torch.cuda.Stream() makes blocking
+    streams, and every operation on the legacy NULL stream -- IExecutionContext::execute() orders itself after it -- then pays for
+    each of them (852 vs 606 us per pair in the synchronous loop with this process's eight streams)."""
+    import ctypes
+    out = []
+    for _ in range(n):
+        h = ctypes.c_void_p()
+        klib.check(klib.lib.rt_stream_create(ctypes.byref(h)), "rt_stream_create")
+        out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    return out
 
 
 def host_cores():
@@ -248,7 +262,7 @@ def main_3d(args, rank, world, local_rank, dev, distributed):
     ls, rs = zip(*(synth.synth_pair(h_img, w_img, 1234 + rank * 64 + i) for i in range(b)))
     left, right = torch.from_numpy(np.stack(ls)).to(dev), torch.from_numpy(np.stack(rs)).to(dev)
     disps = [torch.empty(b, 1, h_img, w_img, device=dev) for _ in nets]
-    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+    streams = make_streams(lib.kernels, len(nets), dev)
 
     def step(i):
         c = i % nctx
@@ -320,9 +334,15 @@ def main():
     ap.add_argument("--steps", type=int, default=200)       # the reference averages over 200 images
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "4")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "0")),
                     help="IExecutionContexts per GPU, each with its own stream; steps are issued round-robin "
-                         "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop")
+                         "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop; 0 (default) = 6 "
+                         "(fp32) / 4 (--half2), the best measured of 3..12")
+    ap.add_argument("--streams-per-context", type=int, default=0, choices=[0, 1, 2],
+                    help="HIP streams a context issues on (IExecutionContext::setExecutionStreams): 2 = right-image encoder on a second "
+                         "stream, 1 = everything on the context's stream; 0 (default) = 1 with several fp32 contexts, 2 with one or with --half2.  Measured "
+                         "(driver command, --steps 20 --warmup 5): six one-stream contexts 2270, four two-stream contexts 2100 pairs/s; "
+                         "one context: 1750-1880 with two streams, 1345 with one")
     ap.add_argument("--half2", action="store_true",
                     help="TensorRT half2 mode (BASELINE config C3): fp16 weight file, activations stored as fp16 between "
                          "launches, fp16 operands on the matrix cores with fp32 accumulation; the JSON line then says dtype f16")
@@ -336,6 +356,8 @@ def main():
                          "of an idle MI355X needs ~50 ms of load to reach its sustained value (measured: 20 timed steps give 1883 / "
                          "1948 / 2015 pairs/s after 5 / 20 / 100 warm-up steps).  0 = off; reported on the JSON line")
     args = ap.parse_args()
+    if args.contexts <= 0:
+        args.contexts = 4 if args.half2 else 6
 
     # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU through
     # torch.distributed.run on 127.0.0.1, exactly the command the driver uses -- instead of silently timing one GPU.
@@ -389,6 +411,9 @@ def main():
     nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob, fp16_weights=args.half2)
             for _ in range(args.contexts)]
     net = nets[0]
+    spc = args.streams_per_context or (1 if (args.contexts > 1 and not args.half2) else 2)      # half2: 3978 (4 x 2) vs 3881 (6 x 1) pairs/s at batch 8
+    for n_ in nets:
+        n_.set_streams(spc)
 
     b = args.batch
     ls, rs = zip(*(synth.synth_pair(H, W, 1234 + rank * 64 + i) for i in range(b)))
@@ -396,7 +421,7 @@ def main():
     right = torch.from_numpy(np.stack(rs)).to(dev)
     disps = [torch.empty(b, 1, H, W, device=dev) for _ in nets]
     disp = disps[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+    streams = make_streams(lib.kernels, len(nets), dev)
     nctx = len(nets)
 
     def step(i):
@@ -438,6 +463,7 @@ def main():
     # the reference's own loop for comparison (sample_app/main.cpp:303-309): one context, one pair in flight
     single = None
     if nctx > 1 and rank == 0:
+        nets[0].set_streams(2)                                 # the latency set-up: one context, right-image encoder on a second stream
         n1 = min(args.steps, 200)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -447,14 +473,16 @@ def main():
         dt1 = time.perf_counter() - t1
         single = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3, "steps": n1}
         # ... and literally: IExecutionContext::execute (returns when the disparity is there), one call after the other
-        t1 = time.perf_counter()
-        for _ in range(n1):
+        lat = []
+        for _ in range(max(n1, 50)):
+            t1 = time.perf_counter()
             nets[0].execute(left, right, disps[0], b)
-        dt1 = time.perf_counter() - t1
-        single["synchronous_execute"] = {"value": n1 * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / n1 / b * 1e3,
-                                         "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309); execute() orders itself "
-                                                 "after the legacy NULL stream, which this process pays for each of its other (blocking) streams: "
-                                                 "tools/host_overhead.py measures 606 us per pair with one"}
+            lat.append(time.perf_counter() - t1)
+        dt1 = float(np.median(lat[len(lat) // 4:]))             # per call: the first calls still create the context's own stream
+        single["synchronous_execute"] = {"value": b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / b * 1e3, "ms_per_pair_mean": float(np.mean(lat)) / b * 1e3,
+                                         "calls": len(lat),
+                                         "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309)"}
+        nets[0].set_streams(spc)
     # PCIe-inclusive rate (never `value`): the same K steps with each pair's two images copied host -> device and its
     # disparity device -> host, pinned buffers, copies on a per-context copy stream ordered by events so that they
     # overlap the convolutions of the other contexts (double-buffered H2D)
@@ -465,7 +493,7 @@ def main():
         NBUF = 2                                                      # input buffers per context: copy i+1 under compute i
         d_l = [[torch.empty_like(left) for _ in range(NBUF)] for _ in nets]
         d_r = [[torch.empty_like(right) for _ in range(NBUF)] for _ in nets]
-        copy_streams = [torch.cuda.Stream(device=dev) for _ in nets]
+        copy_streams = make_streams(lib.kernels, len(nets), dev)
         copied = [[torch.cuda.Event() for _ in range(NBUF)] for _ in nets]
         consumed = [[torch.cuda.Event() for _ in range(NBUF)] for _ in nets]
 
@@ -538,6 +566,11 @@ def main():
         pcie["u8_frames"] = {"value": args.steps * b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / args.steps / b * 1e3,
                              "mb_per_pair": mb8 / b,
                              "note": "u8 BGR frames in, 16-bit disparity out, pre/post-processing on the device"}
+        # the u8 pipeline left disparities of the QUANTISED frames in `disps`: one plain step per context again, so that what is
+        # checked below is what was timed above
+        for i in range(nctx):
+            step(i)
+        torch.cuda.synchronize(dev)
     ctx_diff = 0.0
     for d in disps:
         assert torch.isfinite(d).all(), "non-finite disparity"
@@ -619,9 +652,9 @@ def main():
         overlapped = launches * avg_s > step_s * b            # launches of several streams / contexts run concurrently
         mfma_peak = MFMA_F32_PEAK_TFLOPS if (exact and not args.half2) else MFMA_F16_PEAK_TFLOPS
         roofline = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                    "frac_note": ("in-situ launch duration (HIP events on the launch stream inside the running network); %d launches x "
-                                  "%.1f us %s one step of %.1f us, i.e. launches of the two streams / %d contexts overlap: use frac_isolated "
-                                  "and frac_step as throughput statements" % (launches, avg_s * 1e6, ">" if overlapped else "<=", step_s * 1e6, nctx)),
+                    "frac_note": ("launch duration by HIP events on the launch stream in profiled steps of one context (%d stream(s)); %d launches x "
+                                  "%.1f us %s one step of %.1f us: in the timed run the launches of %d contexts overlap -- frac_step* are the "
+                                  "throughput statements" % (spc, launches, avg_s * 1e6, ">" if overlapped else "<=", step_s * 1e6, nctx)),
                     "overlapped": bool(overlapped), "traffic": traffic,
                     "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
                     "algorithmic_bytes": nbytes * b, "flops_per_launch": flops * b,
@@ -649,6 +682,11 @@ def main():
                     "hbm_gbs": nbytes * b / avg_s / 1e9, "frac_hbm": nbytes * b / avg_s / 1e9 / HBM_PEAK_GBS,
                     "frac_hbm_note": "algorithmic bytes of the same launch / in-situ duration / 8 TB/s"}
         if fused and not args.half2:
+            roofline["bound_note"] = ("matrix and vector instructions share a SIMD's issue port on gfx950, also across waves (tools/micro/mfma_f16_valu.hip: "
+                                      "92 % of the sum): a 4-row step of this kernel needs 108 MFMAs x 32 = 3.5 k matrix cycles + ~2 k vector cycles per "
+                                      "SIMD and takes ~6 k (profiles/r02_phases.txt); the rest of `frac` is the 2.5 PFLOP/s peak assuming 2.4 GHz "
+                                      "(sustained here: 2.0-2.2), the prologue and the half-empty first / last pipeline step of a segment")
+        if fused and not args.half2:
             # continuity with the layer-by-layer kernel (the roofline object of earlier benches; still runs the other 18 convolutions)
             g_us = isolated_dominant(lib.kernels, b, args.half2, fused=False)
             roofline["layer_by_layer_kernel"] = {"kernel": "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU)", "bound": "hbm",
@@ -669,7 +707,7 @@ def main():
                            "on the fp16 matrix pipe; correlation, soft-argmax, activations in fp32 -- error vs fp64 in the fp32-roundoff class"),
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
-                       "pairs_per_step": b, "contexts": nctx, "launches_per_step": net.num_launches, "layers": net.num_layers,
+                       "pairs_per_step": b, "contexts": nctx, "streams_per_context": spc, "launches_per_step": net.num_launches, "layers": net.num_layers,
                        "weights": weights_desc, "parallelism": "pairs sharded over %d GPU(s)" % world},
             "parity_max_abs_err": parity, "contexts_max_abs_diff": ctx_diff,
             "parity_note": "max |disp - oracle| over the %d timed context(s), same pair(s), %s; budget %s" % (

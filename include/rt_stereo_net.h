@@ -51,6 +51,10 @@ int rt_net_serialize(rtStereoNet* net, void* buf, size_t buf_bytes, size_t* plan
  * (sample_app/main.cpp:198-220; lib/internal_utils.cpp:289-313). */
 int rt_net_create_from_plan(rtStereoNet** net, const void* plan, size_t plan_bytes);
 int rt_net_num_layers(const rtStereoNet* net);     /* layers of the network definition  */
+/* HIP streams the context issues its launches on: 2 (default) = the right-image encoder on a second stream, best for one
+ * context (latency); 1 = everything on the caller's stream, best when several handles are kept busy side by side
+ * (IExecutionContext::setExecutionStreams, an extension of the NvInfer.h subset; bench.py uses 1 with its six contexts). */
+int rt_net_set_streams(rtStereoNet* net, int streams);
 int rt_net_num_launches(const rtStereoNet* net);   /* kernel launches after fusion       */
 int rt_net_destroy(rtStereoNet* net);
 const char* rt_net_last_error(void);

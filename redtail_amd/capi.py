@@ -275,6 +275,7 @@ NET_SYMBOLS = {
     "rt_net_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_char_p, c_size_t]),
     "rt_net_num_layers": (c_int, [c_void_p]),
     "rt_net_num_launches": (c_int, [c_void_p]),
+    "rt_net_set_streams": (c_int, [c_void_p, c_int]),
     "rt_net_destroy": (c_int, [c_void_p]),
     "rt_net_last_error": (c_char_p, []),
 }
@@ -364,6 +365,10 @@ class StereoNet:
     def execute(self, left, right, disp, batch=1, stream=None):
         self.netlib.check(self.netlib.lib.rt_net_execute(self.handle, _ptr(left), _ptr(right), _ptr(disp), batch, stream),
                           "rt_net_execute")
+
+    def set_streams(self, n):
+        """1: all launches on the caller's stream (throughput with several contexts); 2: second stream for the right encoder"""
+        self.netlib.check(self.netlib.lib.rt_net_set_streams(self.handle, n), "rt_net_set_streams")
 
     def profile(self, left, right, disp, batch=1):
         buf = ctypes.create_string_buffer(1 << 16)

@@ -325,6 +325,8 @@ public:
     bool enqueue(int batchSize, void** bindings, cudaStream_t stream, cudaEvent_t* inputConsumed) override;
     void setDebugSync(bool s) override { debug_sync_ = s; }
     bool getDebugSync() const override { return debug_sync_; }
+    void setExecutionStreams(int n) override { streams_ = n < 2 ? 1 : 2; }
+    int getExecutionStreams() const override { return streams_; }
     void setProfiler(IProfiler* p) override { profiler_ = p; }
     IProfiler* getProfiler() const override { return profiler_; }
     const ICudaEngine& getEngine() const override;
@@ -338,6 +340,7 @@ private:
     EngineImpl& eng_;
     IProfiler* profiler_ = nullptr;
     bool debug_sync_ = false;
+    int streams_ = 2;
     int alloc_batch_ = 0;
     std::vector<void*> buffers_;       // per tensor id (owned)
     void* workspace_ = nullptr;
@@ -1382,7 +1385,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
     }
     if (!ensureBuffers(batch)) return false;
     const bool profile = profiler_ != nullptr;
-    const bool two = eng_.two_streams_;
+    const bool two = eng_.two_streams_ && streams_ > 1;
     rtStream main = stream;
     if (two) {
         if (!side_stream_ && rt_stream_create(&side_stream_) != 0) return false;

@@ -227,6 +227,13 @@ extern "C" int rt_net_profile(rtStereoNet* net, const void* left, const void* ri
     return 0;
 }
 
+extern "C" int rt_net_set_streams(rtStereoNet* net, int streams) {
+    if (!net || !net->context) return fail("rt_net_set_streams: null pointer");
+    if (streams < 1 || streams > 2) return fail("rt_net_set_streams: 1 or 2 streams");
+    net->context->setExecutionStreams(streams);
+    return 0;
+}
+
 extern "C" int rt_net_num_layers(const rtStereoNet* net) { return net ? net->layers : 0; }
 extern "C" int rt_net_num_launches(const rtStereoNet* net) { return net && net->engine ? net->engine->getNbLayers() : 0; }
 extern "C" int rt_net_destroy(rtStereoNet* net) {

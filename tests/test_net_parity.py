@@ -98,6 +98,25 @@ def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
     assert np.abs(out - ref).max() <= 2e-4
 
 
+def test_resnet18_2d_one_stream_per_context(rt):
+    """IExecutionContext::setExecutionStreams(1) (rt_net_set_streams): every launch on the caller's stream -- the throughput set-up of
+    bench.py -- gives the numbers of the default two-stream schedule bit for bit, and can be switched back"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 25, 41)
+    net = rt.lib.create("resnet18_2D", 41, 25, max_batch=1, weights=w, max_disp=8)
+    outs = []
+    for streams in (2, 1, 2):
+        net.set_streams(streams)
+        out = rt.empty(1, 1, 25, 41)
+        net.execute(rt.dev(l), rt.dev(r), out, 1)
+        outs.append(np.array(rt.host(out)))
+    with pytest.raises(capi.RtError):
+        net.set_streams(3)
+    net.destroy()
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_resnet18_2d_unfused_equals_fused(rt, monkeypatch):
     """RT_NO_FUSION runs every plugin through its own enqueue(), i.e. the reference's layer-by-layer order"""
     w = O.synth_weights_resnet18_2d()

@@ -35,3 +35,13 @@ torch.cuda.synchronize()
 t_all = time.perf_counter() - t_all
 print("pipelined: host time per enqueue median %.0f us, first ten %s; all 60 issued after %.1f ms, finished after %.1f ms" % (
     np.median(ts) * 1e6, " ".join("%.0f" % (t * 1e6) for t in ts[:10]), t_issue * 1e3, t_all * 1e3))
+# does execute()'s NULL-stream ordering get more expensive with more contexts alive in the process?
+extra = [lib.create("resnet18_2D", 1257, 369, max_batch=1, weights=synth.synth_weights_resnet18_2d()) for _ in range(3)]
+outs = [torch.empty_like(out) for _ in extra]
+for n2, o2 in zip(extra, outs):
+    n2.execute(L, R, o2, 1, stream=st.cuda_stream)
+torch.cuda.synchronize()
+lat = []
+for _ in range(200):
+    t0 = time.perf_counter(); net.execute(L, R, out, 1); lat.append(time.perf_counter() - t0)
+print("execute() loop with three more contexts alive: median %.0f us per pair" % (np.median(lat[50:]) * 1e6))
