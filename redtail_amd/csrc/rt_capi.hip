@@ -477,6 +477,10 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
 
 struct rtConvPlan {
     std::vector<SubConv> subs;
+    // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
+    // whole environment, and five look-ups per launch were a third of the host's time per launch
+    mutable bool env_read = false;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -1677,6 +1681,12 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             RT_LAUNCH_CHECK("deconv3d_s2_small_kernel");
             continue;
         }
+        if (!plan->env_read) {
+            plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
+            plan->opt_rb_tiles = env_int("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0);
+            plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
+            plan->env_read = true;
+        }
         rt::ConvArgs a;
         a.x = static_cast<const float*>(x);
         a.y = static_cast<float*>(y);
@@ -1698,7 +1708,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         a.pad_y = sc.pad_y; a.pad_x = sc.pad_x; a.nz = sc.nz;
         a.tiles_x = (int)rt::cdiv(sc.Wo, 32 * sc.TXW);
         a.act = plan->act;
-        a.xcd_order = env_int("RT_CONV_XCD", 1);
+        a.xcd_order = plan->opt_xcd;
         a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
         a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
@@ -1729,10 +1739,10 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
         if (sc.s3p) {
             // persistent: one 8-wave workgroup per CU walks a contiguous range of tiles (RT_S3P_GRID: test knob)
             const int64_t T = (int64_t)a.tiles_x * tiles_y * batch;
-            int64_t g = std::min<int64_t>(T, env_int("RT_S3P_GRID", device_cus()));
+            int64_t g = std::min<int64_t>(T, (plan->opt_s3p_grid > 0 ? plan->opt_s3p_grid : device_cus()));
             if (g >= 8) g -= g % 8;
             dim3 pgrid((unsigned)std::max<int64_t>(g, 1));
-            if (env_int("RT_CONV_TRACE", 0))
+            if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_s3p x%d y%d r%d tiles %lld grid %u\n", sc.x_il8, sc.y_il8, sc.r_il8, (long long)T, pgrid.x);
             if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3p_kernel<8, true, true>), pgrid, dim3(512), 0, S(s), a);
             else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3p_kernel<8, true, false>), pgrid, dim3(512), 0, S(s), a);
@@ -1751,24 +1761,24 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             // 32 -> 32 -> 32 channels, ELU after both, on interleaved tensors (the feature towers): the streaming form, strips of 30 columns x
             // segments of 16 rows (conv_rbs.hip.h); everything else: one 4 x 32 tile per workgroup
             if (sc.x_il8 && sc.y_il8 && plan->cin == 32 && plan->rb_cmid == 32 && sc.Cout == 32 && plan->rb_act1 == 1 && plan->act == 1 &&
-                env_int("RT_RB_TILES", 0) == 0) {
+                plan->opt_rb_tiles == 0) {
                 ra.c.tiles_x = (int)rt::cdiv(sc.Wo, rt::S3RBSCfg::SW);
                 // rows per workgroup: the pipeline's fill and drain steps and the prologue are paid per segment, so longer segments
                 // cost fewer CU-cycles per row; shorter ones fill more CUs of an otherwise idle GPU (RT_RBS_SEG, default: see DESIGN.md 4.4)
                 // Measured in the running network (ResNet-18 2D, 1257x369, four contexts): 16 rows 2129, 24: 2178, 32: 2185, 48: 2067,
                 // 64: 1957 pairs/s (two launches of the layer-by-layer kernels: 2057); alone 16 rows are fastest (24.5 vs 32.4 us).
-                int seg = env_int("RT_RBS_SEG", 0);
+                int seg = plan->opt_rbs_seg;
                 if (seg <= 0) seg = ra.c.tiles_x * (int)rt::cdiv(sc.Ho, 32) * batch >= 120 ? 32 : rt::S3RBSCfg::SEG;
                 seg = seg < 4 ? 4 : (seg > 240 ? 240 : (seg + 3) / 4 * 4);
                 ra.seg = seg;
                 dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, seg)), 1u, (unsigned)batch);
-                if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rbs grid %u x %u\n", sgrid.x, sgrid.z);
+                if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rbs grid %u x %u\n", sgrid.x, sgrid.z);
                 hipLaunchKernelGGL(rt::conv_s3rbs_kernel, sgrid, dim3(512), 0, S(s), ra);      // ELU / ELU, as in every tower block
                 RT_LAUNCH_CHECK("conv_s3rbs_kernel");
                 continue;
             }
             dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
-            if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
+            if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
             if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(256), 0, S(s), ra);
             else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, false>), rgrid, dim3(256), 0, S(s), ra);
             else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, true>), rgrid, dim3(256), 0, S(s), ra);
@@ -1783,7 +1793,7 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         if (sc.split3) {
-            if (env_int("RT_CONV_TRACE", 0))
+            if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             bool launched = false;
             if (sc.x_f16 || sc.y_f16) {                 // fp16 storage (3-D tensors of half2 mode): planar, 4-row tiles
@@ -1819,14 +1829,14 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             continue;
         }
         if (sc.f16first) {
-            if (env_int("RT_CONV_TRACE", 0)) fprintf(stderr, "[rt] conv_f16_first il8 y%d grid %u x %u x %u\n", sc.y_il8, grid.x, grid.y, grid.z);
+            if (plan->opt_trace) fprintf(stderr, "[rt] conv_f16_first il8 y%d grid %u x %u x %u\n", sc.y_il8, grid.x, grid.y, grid.z);
             if (sc.y_il8) hipLaunchKernelGGL((rt::conv_f16_first_kernel<true>), grid, dim3(256), 0, S(s), a, plan->cin);
             else hipLaunchKernelGGL((rt::conv_f16_first_kernel<false>), grid, dim3(256), 0, S(s), a, plan->cin);
             RT_LAUNCH_CHECK("conv_f16_first_kernel");
             continue;
         }
         if (sc.f16mma) {
-            if (env_int("RT_CONV_TRACE", 0))
+            if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_f16mma %dx%d s%d rows %d il8 x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.TY, sc.x_il8,
                         sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             if (sc.KH == 3 && sc.KW == 3 && sc.S == 1) {     // the tower layers: tensor layouts x rows per workgroup
