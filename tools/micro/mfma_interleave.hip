@@ -21,15 +21,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum Kind { FMA = 0, EXP, CVT, CMPSEL, PKFMA, DSR128, DSW64, VMEMLD, MIXLDS, FMAMIX, NKIND };
+enum Kind { FMA = 0, EXP, CVT, CMPSEL, PKFMA, DSR128, DSW64, VMEMLD, MIXLDS, FMAMIX, SALU, SNOP, DSW2, VMEMST, NKIND };
 static const char* kKindName[NKIND] = {"v_fma_f32", "v_exp_f32", "v_cvt_pk_f16_f32", "v_cmp+v_cndmask", "v_pk_fma_f32", "ds_read_b128",
-                                       "ds_write_b64", "global_load_dwordx4", "1 ds_read_b128 + (K-1) v_fma", "v_fma_mix_f32"};
+                                       "ds_write_b64", "global_load_dwordx4", "1 ds_read_b128 + (K-1) v_fma", "v_fma_mix_f32", "s_add_u32", "s_nop 0",
+                                       "ds_write2_b64", "global_store_dwordx4"};
 
 struct Regs {
     float x[8];
     f32x2 p[4];
     f32x4 q[4];
-    unsigned h[4];
+    unsigned h[5];
 };
 
 template <int KIND>
@@ -48,7 +49,11 @@ __device__ __forceinline__ void filler(int j, Regs& r, float m, float c, unsigne
     else if constexpr (KIND == MIXLDS) {
         if ((j & 7) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(r.q[i]) : "v"(lds_addr));
         else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r.x[j & 7]) : "v"(m), "v"(c));
-    } else if constexpr (KIND == FMAMIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,1]" : "+v"(r.x[j & 7]) : "v"(m), "v"(r.h[i]));
+    } else if constexpr (KIND == SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(r.h[4]) : : "scc");
+    else if constexpr (KIND == SNOP) asm volatile("s_nop 0");
+    else if constexpr (KIND == DSW2) asm volatile("ds_write2_b64 %0, %1, %2 offset1:4" : : "v"(lds_addr + 2048u * i), "v"(r.p[i]), "v"(r.p[(i + 1) & 3]) : "memory");
+    else if constexpr (KIND == VMEMST) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(gp + 64 * i), "v"(r.q[i]) : "memory");
+    else if constexpr (KIND == FMAMIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,1]" : "+v"(r.x[j & 7]) : "v"(m), "v"(r.h[i]));
 }
 
 // NW = waves per SIMD, MODE 0: every wave runs [MFMA, K fillers]; MODE 1: waves >= 4 run fillers only (FK per partner MFMA slot)
@@ -66,6 +71,7 @@ __global__ void __launch_bounds__(NW * 256) probe(unsigned long long* cyc, float
     Regs r;
     for (int j = 0; j < 8; j++) r.x[j] = 0.001f * (j + lane);
     for (int j = 0; j < 4; j++) { r.p[j] = f32x2{0.5f + j, 0.25f}; r.q[j] = f32x4{0.f, 0.f, 0.f, 0.f}; r.h[j] = 0x3c003c00u; }
+    r.h[4] = 0;
     const float m = 0.9999f, c = 1e-3f;
     const unsigned lds_addr = (unsigned)(size_t)lds + lane * 16u;     // conflict-free 16-byte lanes
     const f32x4* gp = g + (size_t)blockIdx.x * 1024 + threadIdx.x;
@@ -79,8 +85,8 @@ __global__ void __launch_bounds__(NW * 256) probe(unsigned long long* cyc, float
 #pragma unroll
                 for (int j = 0; j < K; j++) filler<KIND>(u * K + j, r, m, c, lds_addr, gp);
             }
-            if (KIND == DSR128 || KIND == MIXLDS || KIND == DSW64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (KIND == VMEMLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (KIND == DSR128 || KIND == MIXLDS || KIND == DSW64 || KIND == DSW2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (KIND == VMEMLD || KIND == VMEMST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     } else {
         for (int it = 0; it < iters; it++) {
@@ -89,8 +95,8 @@ __global__ void __launch_bounds__(NW * 256) probe(unsigned long long* cyc, float
 #pragma unroll
                 for (int j = 0; j < FK; j++) filler<KIND>(u * FK + j, r, m, c, lds_addr, gp);
             }
-            if (KIND == DSR128 || KIND == MIXLDS || KIND == DSW64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (KIND == VMEMLD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (KIND == DSR128 || KIND == MIXLDS || KIND == DSW64 || KIND == DSW2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (KIND == VMEMLD || KIND == VMEMST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -101,6 +107,7 @@ __global__ void __launch_bounds__(NW * 256) probe(unsigned long long* cyc, float
         for (int e = 0; e < 16; e++) s += acc[j][e];
     for (int j = 0; j < 8; j++) s += r.x[j];
     for (int j = 0; j < 4; j++) s += r.p[j][0] + r.p[j][1] + r.q[j][0] + r.q[j][3] + (float)r.h[j];
+    s += (float)r.h[4];
     if (s == 12345.f) out[threadIdx.x] = s;
 }
 
@@ -152,11 +159,25 @@ void sweep_pair() {
     run<KIND, 6, 2, 0, 0>(); run<KIND, 8, 2, 0, 0>();
 }
 
-int main() {
+template <int KIND>
+void sweep_asym() {
+    run<KIND, 0, 2, 1, 1>(); run<KIND, 0, 2, 1, 2>(); run<KIND, 0, 2, 1, 4>(); run<KIND, 0, 2, 1, 8>();
+    run<KIND, 4, 2, 1, 4>();     // MFMA + 4 of them in the MFMA wave, 4 per slot in the partner
+}
+int main(int argc, char** argv) {
     (void)hipMalloc(&d_cyc, kBlocks * 8 * 8);
     (void)hipMalloc(&d_out, 4096);
     (void)hipMalloc(&d_g, (size_t)kBlocks * 2048 * 16);
     (void)hipMemset(d_g, 0, (size_t)kBlocks * 2048 * 16);
+    if (argc > 1) {      // round 3, second question: do SALU / s_nop / LDS reads of EITHER wave cost the SIMD issue time next to MFMAs?
+        (void)hipMalloc(&d_cyc, kBlocks * 8 * 8); (void)hipMalloc(&d_out, 4096); (void)hipMalloc(&d_g, (size_t)kBlocks * 2048 * 16);
+        sweep_self<SALU>(); sweep_self<SNOP>(); sweep_self<DSW2>(); sweep_self<VMEMST>();
+        sweep_pair<SALU>(); sweep_pair<SNOP>(); sweep_pair<DSR128>();
+        sweep_asym<SALU>(); sweep_asym<SNOP>(); sweep_asym<DSR128>(); sweep_asym<FMA>(); sweep_asym<DSW2>(); sweep_asym<VMEMLD>(); sweep_asym<VMEMST>();
+        // mixed partner: MFMA + 4 v_fma in one wave, the other wave the same plus one LDS read (MIXLDS K = 5)
+        run<MIXLDS, 5, 2, 0, 0>(); run<MIXLDS, 6, 2, 0, 0>();
+        return 0;
+    }
     printf("[MFMA, K fillers] x 8 per iteration, %d iterations, %d workgroups (one per CU); v_mfma_f32_32x32x16_f16 = 32 cycles per SIMD\n", kIters, kBlocks);
     sweep_self<FMA>(); sweep_self<EXP>(); sweep_self<CVT>(); sweep_self<CMPSEL>(); sweep_self<PKFMA>(); sweep_self<FMAMIX>();
     sweep_self<DSR128>(); sweep_self<DSW64>(); sweep_self<VMEMLD>(); sweep_self<MIXLDS>();
