@@ -30,6 +30,12 @@ Extra objects on the JSON line:
                 and `frac_of_fp32_mfma_peak*` put the step and the launch on round 1's scale (direct-form FLOPs / 157.3 TFLOP/s).
   cpu_baseline  the oracle (torch CPU restatement of the reference graph, oracle/stereo_oracle.py) timed
                 on this host's cores on a bounded sample of the same workload.
+  latency_ms_per_pair   IExecutionContext::execute() in a loop, one context: the reference's own timing protocol (`ms_per_pair` is
+                1 / throughput with several pairs in flight)
+  value_200 / value_exact_fp32   the same set-up over 200 steps / with RT_CONV_EXACT_FP32=1 (fp32 fmaf-chain kernels, no fp16 split)
+  secondary     default run only (N = 1, no other flags): BASELINE configs C3, C5, C4, the reference's published 513x257 configuration and
+                NVTiny 513x161 (C1), each a bounded run with its own parity check against the oracle on one pair, outside the timed
+                region (--no-secondary skips them)
 """
 import argparse
 import collections
@@ -106,7 +112,19 @@ def measured_traffic(half2=False, fused=None):
     t = json.load(open(files[-1]))
     if fused is not None and ("conv_s3rbs" in t.get("kernel", "")) != fused:
         return None, None                                   # the PMC pass was taken with the other kernel as the dominant one
+    if t.get("sources_sha16") not in (None, kernel_sources_sha16()):
+        return None, "%s is stale: taken on kernel sources %s, these are %s" % (os.path.relpath(files[-1], ROOT), t.get("sources_sha16"), kernel_sources_sha16())
     return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
+def kernel_sources_sha16():
+    """Hash of the kernel sources the counters of profiles/rNN_traffic.json belong to (tools/summarize_profiles.py stamps the file)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "redtail_amd", "csrc", "kernels", "*.h"))) + [os.path.join(ROOT, "redtail_amd", "csrc", "rt_capi.hip")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_streams(klib, n, dev):
@@ -164,7 +182,7 @@ def cpu_baseline(weights, budget_s=12.0):
     return out
 
 
-def isolated_dominant(k, b, half2, launches=50, fused=False):
+def isolated_dominant(k, b, half2, launches=50, fused=False, hints=0):
     """The dominant layer (3x3 32->32 @629x185 + bias + residual + ELU, the executor's tensor layouts) launched
     back-to-back on one idle stream: microseconds per launch between two HIP events.  Reported next to the in-situ
     figure (`avg_launch_us`: event pairs inside the running network, other streams' kernels in flight)."""
@@ -187,11 +205,11 @@ def isolated_dominant(k, b, half2, launches=50, fused=False):
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
     for _ in range(5):
-        plan.enqueue(x, y, r, b)
+        plan.enqueue(x, y, r, b, hints=hints)
     torch.cuda.synchronize()
     k.lib.rt_event_record(e0, None)
     for _ in range(launches):
-        plan.enqueue(x, y, r, b)
+        plan.enqueue(x, y, r, b, hints=hints)
     k.lib.rt_event_record(e1, None)
     torch.cuda.synchronize()
     ms = ctypes.c_float()
@@ -204,6 +222,9 @@ def isolated_dominant(k, b, half2, launches=50, fused=False):
 
 # ---- the 3-D models (BASELINE configs C4 / C5): `--model nvsmall|resnet18|nvtiny [--half2] [--batch B]` --------------------------
 MODELS_3D = {"nvtiny": (513, 161, 24, "NVTINY_3D"), "nvsmall": (1025, 321, 48, "NVSMALL_3D"), "resnet18": (1025, 321, 68, "RESNET18_3D")}
+
+
+FLOPS_3D = {}          # filled by trunk_bytes_3d: direct-form FLOPs per pair and 3-D layer
 
 
 def trunk_bytes_3d(cfg, h, w, max_disp, es):
@@ -222,6 +243,7 @@ def trunk_bytes_3d(cfg, h, w, max_disp, es):
         out = k * D * H * W
         rd = (2 * cfg["feat"] * ((h + 1) // 2) * ((w + 1) // 2) * 4) if i == 0 else cur * es      # folded cost volume: two fp32 feature maps
         per[name] = rd + out * es + 27 * k * c * 4
+        FLOPS_3D[name] = 2.0 * 27 * c * out                      # direct form (stride-2 layers: out is the strided grid)
         dims[name] = (k, D, H, W)
         cur = out
     n_dec = len(cfg["deconv3d"])
@@ -234,31 +256,18 @@ def trunk_bytes_3d(cfg, h, w, max_disp, es):
             out = c * D * H * W
         last = i == n_dec - 1
         per[name] = cur * es + out * (4 if last else es) * (2 if skip else 1) + 27 * k * c * 4
+        FLOPS_3D[name] = 2.0 * 27 * k * out / 8.0                # transposed, stride 2: 27 / 8 taps per output
         cur = out
     return float(sum(per.values())), per
 
 
-def main_3d(args, rank, world, local_rank, dev, distributed):
-    """One step = one IExecutionContext::enqueue of `--batch` stereo pairs through the whole 3-D network, inputs resident in HBM."""
-    w_img, h_img, max_disp, cfg_name = MODELS_3D[args.model]
+def bench_3d(lib, dev, model, half2, b, steps, warmup, nctx, blob, weights, desc, world=1, distributed=False, rank=0, check=False):
+    """One step = one IExecutionContext::enqueue of `b` stereo pairs through the whole 3-D network, inputs resident in HBM.
+    Returns the JSON object (rank 0) or None."""
+    w_img, h_img, max_disp, cfg_name = MODELS_3D[model]
     cfg = getattr(synth, cfg_name)
-    weights = None
-    if rank == 0:
-        try:
-            path = model_files.weight_file(args.model, args.half2)
-            weights, desc = capi.read_weights(path, args.half2), "reference %s/TensorRT/%s" % (args.model, os.path.basename(path))
-        except FileNotFoundError as e:
-            print("bench.py: %s -- timing seeded synthetic weights instead" % e, file=sys.stderr)
-            weights, desc = synth.synth_weights_3d(cfg), "seeded He-normal (synthetic: the reference ships no such weight file)"
-        blob = capi.pack_weights(weights, fp16=args.half2)
-    if distributed:
-        import torch.distributed as dist
-        blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
-    lib = capi.NetLib()
-    lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
-    b = args.batch
-    nctx = max(1, min(args.contexts, 2))                      # the volumes are large: at most two contexts
-    nets = [lib.create(args.model, w_img, h_img, max_batch=b, weights=blob, fp16_weights=args.half2) for _ in range(nctx)]
+    nctx = max(1, min(nctx, 2))                               # the volumes are large: at most two contexts
+    nets = [lib.create(model, w_img, h_img, max_batch=b, weights=blob, fp16_weights=half2) for _ in range(nctx)]
     ls, rs = zip(*(synth.synth_pair(h_img, w_img, 1234 + rank * 64 + i) for i in range(b)))
     left, right = torch.from_numpy(np.stack(ls)).to(dev), torch.from_numpy(np.stack(rs)).to(dev)
     disps = [torch.empty(b, 1, h_img, w_img, device=dev) for _ in nets]
@@ -274,11 +283,11 @@ def main_3d(args, rank, world, local_rank, dev, distributed):
             torch.distributed.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -289,43 +298,231 @@ def main_3d(args, rank, world, local_rank, dev, distributed):
     barrier()
     for d in disps:
         assert torch.isfinite(d).all(), "non-finite disparity"
-    if rank != 0:
-        return
-    es = 2 if args.half2 else 4
-    total, per = trunk_bytes_3d(cfg, h_img, w_img, max_disp, es)
-    prof = collections.defaultdict(list)
-    for _ in range(3):
-        for name, ms in nets[0].profile(left, right, disps[0], b):
-            prof[name].append(ms)
-    known = {n: sum(v) / len(v) for n, v in prof.items() if n in per}
-    dom = max(known, key=known.get)
-    dom_s = known[dom] * 1e-3
-    step_s = elapsed / args.steps
-    parity = None
-    if args.check:                                             # minutes of CPU at 1025 x 321; tests/test_net_parity.py does it in the GPU tier
+    out = None
+    if rank == 0:
+        es = 2 if half2 else 4
+        total, per = trunk_bytes_3d(cfg, h_img, w_img, max_disp, es)
+        gflop = sum(FLOPS_3D[n] for n in per) / 1e9
+        prof = collections.defaultdict(list)
+        for _ in range(3):
+            for name, ms in nets[0].profile(left, right, disps[0], b):
+                prof[name].append(ms)
+        known = {n: sum(v) / len(v) for n, v in prof.items() if n in per}
+        dom = max(known, key=known.get)
+        dom_s = known[dom] * 1e-3
+        step_s = elapsed / steps
+        parity = None
+        if check:                                                  # ~10-30 s of CPU at 1025 x 321; tests/test_net_parity.py does it in the GPU tier too
+            from oracle import stereo_oracle as O
+            torch.set_num_threads(host_cores())
+            wref = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if half2 else v) for k, v in weights.items()}
+            with torch.no_grad():
+                ref = O.stereo3d(left[:1].cpu(), right[:1].cpu(), wref, cfg, max_disp)
+            parity = float((disps[0][:1].cpu() - ref).abs().max())
+        out = {
+            "metric": "stereo pairs/sec, %s 3D %dx%d" % (model, w_img, h_img), "value": world * steps * b / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "ms_per_pair": step_s / b * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 3-D tensors (f32 accumulate), f32 2-D towers" if half2 else "f32", "data": "synthetic",
+            "parity_max_abs_err": parity,
+            "parity_note": ("max |disp - oracle| in pixels on the first pair of the batch, %s; disparities reach ~%d px" % (
+                "oracle on the fp16-rounded weights with fp32 tensors" if half2 else "fp32 oracle", 2 * max_disp)) if check else
+                           "--check runs the CPU oracle at this size; tests/test_net_parity.py covers it in the GPU tier",
+            "config": {"workload": "%s 3-D Stereo DNN, %dx%d, max disparity %d, batch %d per step, %d context(s)" % (
+                           model, w_img, h_img, 2 * max_disp, b, nctx),
+                       "weights": desc, "launches_per_step": nets[0].num_launches, "half2": bool(half2)},
+            "roofline": {"bound": "hbm", "kernel": "%s (conv_s3_kernel gather form / deconv3d kernels, DESIGN.md 4.1, 9)" % dom,
+                         "achieved": per[dom] * b / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom] * b / dom_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": per[dom] * b, "avg_launch_us": dom_s * 1e6,
+                         "flops_per_launch": FLOPS_3D[dom] * b,
+                         "frac_mfma": FLOPS_3D[dom] * b / dom_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                         "frac_mfma_note": "direct-form FLOPs of the same launch / duration / 2.5 PFLOP/s dense fp16 (one MFMA per product with fp16 "
+                                           "operands and weights; fp32 tensors need up to three)",
+                         "step_algorithmic_bytes": total * b, "step_gbs": total * b / step_s / 1e9,
+                         "frac_step": total * b / step_s / 1e9 / HBM_PEAK_GBS,
+                         "frac_step_note": "algorithmic bytes of the whole 3-D trunk (each tensor once per launch that touches it) / step time / 8 TB/s",
+                         "step_gflop": gflop * b, "frac_step_mfma": gflop * b / step_s / 1e3 / MFMA_F16_PEAK_TFLOPS},
+        }
+    for n in nets:
+        n.destroy()
+    return out
+
+
+def weights_3d(model, half2):
+    """(weights dict, packed image, description) of a 3-D model: the reference's file where it ships one, seeded synthetic otherwise"""
+    cfg = getattr(synth, MODELS_3D[model][3])
+    try:
+        path = model_files.weight_file(model, half2)
+        weights, desc = capi.read_weights(path, half2), "reference %s/TensorRT/%s" % (model, os.path.basename(path))
+    except FileNotFoundError as e:
+        print("bench.py: %s -- timing seeded synthetic weights instead" % e, file=sys.stderr)
+        weights, desc = synth.synth_weights_3d(cfg), "seeded He-normal (synthetic: the reference ships no such weight file)"
+    return weights, capi.pack_weights(weights, fp16=half2), desc
+
+
+def main_3d(args, rank, world, local_rank, dev, distributed):
+    weights, blob, desc = (None, b"", None)
+    if rank == 0:
+        weights, blob, desc = weights_3d(args.model, args.half2)
+    if distributed:
+        import torch.distributed as dist
+        blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
+    lib = capi.NetLib()
+    lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
+    out = bench_3d(lib, dev, args.model, args.half2, args.batch, args.steps, args.warmup, args.contexts, blob, weights, desc,
+                   world=world, distributed=distributed, rank=rank, check=args.check)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def bench_2d_config(lib, dev, w, h, b, half2, nctx, spc, steps, warmup, sync):
+    """A ResNet-18 2D configuration other than the headline (secondary lines: BASELINE C3, the reference's 513x257): timed like the
+    headline (round-robin over nctx contexts) or, sync=True, as context->execute() calls one after the other; parity of the first
+    pair against the oracle outside the timed region; roofline of the dominant launches in algorithmic work."""
+    weights, desc = load_weights(half2)
+    blob = capi.pack_weights(weights, fp16=half2)
+    nets = [lib.create("resnet18_2D", w, h, max_batch=b, weights=blob, fp16_weights=half2) for _ in range(nctx)]
+    for n_ in nets:
+        n_.set_streams(spc)
+    ls, rs = zip(*(synth.synth_pair(h, w, 4321 + i) for i in range(b)))
+    left, right = torch.from_numpy(np.stack(ls)).to(dev), torch.from_numpy(np.stack(rs)).to(dev)
+    disps = [torch.empty(b, 1, h, w, device=dev) for _ in nets]
+    streams = make_streams(lib.kernels, nctx, dev)
+    if sync:
+        for _ in range(warmup):
+            nets[0].execute(left, right, disps[0], b)
+        lat = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            nets[0].execute(left, right, disps[0], b)
+            lat.append(time.perf_counter() - t1)
+        per_step = float(np.median(lat))
+        protocol = "context->execute() one call after the other (sample_app/main.cpp:303-309), median of %d calls" % steps
+    else:
+        for i in range(warmup):
+            nets[i % nctx].execute(left, right, disps[i % nctx], b, stream=streams[i % nctx].cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            nets[i % nctx].execute(left, right, disps[i % nctx], b, stream=streams[i % nctx].cuda_stream)
+        torch.cuda.synchronize(dev)
+        per_step = (time.perf_counter() - t1) / steps
+        protocol = "%d steps round-robin over %d contexts with %d stream(s) each" % (steps, nctx, spc)
+    from oracle import stereo_oracle as O
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        ref = O.resnet18_2d(left[:1].cpu(), right[:1].cpu(), {k: (np.asarray(v).astype(np.float16).astype(np.float32) if half2 else v)
+                                                              for k, v in weights.items()})
+    parity = max(float((d[:1].cpu() - ref).abs().max()) for d in (disps[:1] if sync else disps[:min(nctx, steps)]))
+    # dominant launches: the tower blocks (fused: one launch per block; merged: both towers per launch)
+    h2, w2 = (h + 1) // 2, (w + 1) // 2
+    rows = [r for _ in range(3) for r in nets[0].profile(left, right, disps[0], b)]
+    fused = any(dominant(n) and "+" in n for n, _ in rows)
+    sel = [(n, ms) for n, ms in rows if dominant(n) and (("+" in n) == fused)]
+    tot_s = sum(ms for _, ms in sel) * 1e-3
+    tot_imgs = sum(b * (2 if " | " in n else 1) for n, _ in sel)
+    layer_flops = 2.0 * 32 * 32 * 9 * h2 * w2
+    if half2:
+        unit_work, peak, unit, bound = 2.0 * (3 * 32 * h2 * w2 + 32 * 32 * 9) + 4.0 * 32, HBM_PEAK_GBS, "GB/s", "hbm"
+        kernel = "conv_f16mma_kernel<3,3,1> 3x3 32->32 @%dx%d (+bias,+residual,+ELU), fp16 tensors and operands, fp32 accumulate" % (w2, h2)
+    elif fused:
+        unit_work, peak, unit, bound = 3.0 * 2.0 * layer_flops, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+        kernel = "conv_s3rbs_kernel: residual block @%dx%d in one launch (3 fp16 MFMA products per multiply)" % (w2, h2)
+    else:
+        unit_work, peak, unit, bound = 4.0 * (3 * 32 * h2 * w2 + 32 * 32 * 9 + 32), HBM_PEAK_GBS, "GB/s", "hbm"
+        kernel = "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @%dx%d (+bias,+residual,+ELU), fp32 tensors, 3-term fp16 split" % (w2, h2)
+    achieved = unit_work * tot_imgs / tot_s / (1e12 if bound == "mfma" else 1e9)
+    out = {"value": b / per_step, "unit": "pairs/s", "ms_per_step": per_step * 1e3, "ms_per_pair": per_step / b * 1e3, "steps": steps, "warmup": warmup,
+           "dtype": "f16 (f32 accumulate)" if half2 else "f32", "data": "synthetic", "protocol": protocol,
+           "config": {"workload": "ResNet-18 2D Stereo DNN %s, %dx%d, batch=%d per step" % ("half2 mode" if half2 else "fp32", w, h, b),
+                      "contexts": nctx, "streams_per_context": spc, "launches_per_step": nets[0].num_launches, "weights": desc},
+           "parity_max_abs_err": parity,
+           "parity_note": "max |disp - oracle| on the first pair, %s; budget %s" % (
+               "oracle on the fp16-rounded weights" if half2 else "fp32 oracle", "1e-2" if half2 else "1e-3"),
+           "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                        "avg_launch_us": tot_s / len(sel) * 1e6, "images_per_launch": tot_imgs / len(sel), "traffic": None,
+                        "frac_note": "algorithmic work of the dominant launches / their durations (HIP events on the launch stream, profiled steps of one context)"}}
+    assert parity <= (1e-2 if half2 else 1e-3), "secondary config differs from the oracle by %.3g" % parity
+    for n_ in nets:
+        n_.destroy()
+    return out
+
+
+def secondary_lines(lib, dev):
+    """BASELINE's other configurations, bounded (default run only): each entry is a bench line of its own (value, ms_per_pair, dtype,
+    config.workload, parity_max_abs_err against the oracle on one pair, roofline in algorithmic work)."""
+    out = []
+
+    def add(tag, fn):
+        t0 = time.perf_counter()
+        try:
+            line = fn()
+        except Exception as e:                                  # a secondary line must never take the headline down
+            line = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["id"] = tag
+        line["wall_s"] = time.perf_counter() - t0
+        out.append(line)
+
+    add("C3: ResNet-18 2D half2, 1257x369, batch 8", lambda: bench_2d_config(lib, dev, W, H, 8, True, 4, 2, 32, 8, False))
+    add("ref513: ResNet-18 2D fp32, 513x257, batch 1, one context, synchronous (the reference's published configuration: stereoDNN/README.md:31)",
+        lambda: bench_2d_config(lib, dev, 513, 257, 1, False, 1, 2, 100, 20, True))
+
+    def three_d(model, half2, b, steps, warmup):
+        weights, blob, desc = weights_3d(model, half2)
+        return bench_3d(lib, dev, model, half2, b, steps, warmup, 2, blob, weights, desc, check=True)
+
+    add("C5: NVSmall half2, 1025x321, batch 8", lambda: three_d("nvsmall", True, 8, 6, 2))
+    add("C4: ResNet-18 3D fp32, 1025x321, batch 4 (one GPU's shard of batch 32 over 8)", lambda: three_d("resnet18", False, 4, 6, 2))
+
+    def nvtiny():
+        line = three_d("nvtiny", False, 1, 100, 20)
+        # C1 is the reference's CPU-runnable case: the oracle on this host's cores beside it
         from oracle import stereo_oracle as O
+        w_img, h_img, max_disp, cfg_name = MODELS_3D["nvtiny"]
+        weights, _, _ = weights_3d("nvtiny", False)
+        l, r = synth.synth_pair(h_img, w_img, 1234)
+        L, R = torch.from_numpy(l)[None], torch.from_numpy(r)[None]
         torch.set_num_threads(host_cores())
-        wref = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if args.half2 else v) for k, v in weights.items()}
         with torch.no_grad():
-            ref = O.stereo3d(left[:1].cpu(), right[:1].cpu(), wref, cfg, max_disp)
-        parity = float((disps[0][:1].cpu() - ref).abs().max())
-    out = {
-        "metric": "stereo pairs/sec, %s 3D %dx%d" % (args.model, w_img, h_img), "value": world * args.steps * b / elapsed, "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "ms_per_pair": step_s / b * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 3-D tensors (f32 accumulate), f32 2-D towers" if args.half2 else "f32", "data": "synthetic",
-        "parity_max_abs_err": parity, "parity_note": "--check runs the CPU oracle at this size; tests/test_net_parity.py covers it in the GPU tier",
-        "config": {"workload": "%s 3-D Stereo DNN, %dx%d, max disparity %d, batch %d per step, %d context(s)" % (
-                       args.model, w_img, h_img, 2 * max_disp, b, nctx),
-                   "weights": desc, "launches_per_step": nets[0].num_launches, "half2": bool(args.half2)},
-        "roofline": {"bound": "hbm", "kernel": "%s (conv_s3_kernel gather form / deconv3d kernels, DESIGN.md 4.1, 9)" % dom,
-                     "achieved": per[dom] * b / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom] * b / dom_s / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes": per[dom] * b, "avg_launch_us": dom_s * 1e6,
-                     "step_algorithmic_bytes": total * b, "step_gbs": total * b / step_s / 1e9,
-                     "frac_step": total * b / step_s / 1e9 / HBM_PEAK_GBS,
-                     "frac_step_note": "algorithmic bytes of the whole 3-D trunk (each tensor once per launch that touches it) / step time / 8 TB/s"},
-    }
-    print(json.dumps(out))
+            O.stereo3d(L, R, weights, getattr(synth, cfg_name), max_disp)
+            n, t0 = 0, time.perf_counter()
+            while n < 2 or time.perf_counter() - t0 < 4.0:
+                O.stereo3d(L, R, weights, getattr(synth, cfg_name), max_disp)
+                n += 1
+            dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": "%d pairs of 513x161 in %.1f s, torch CPU fp32 oracle" % (n, dt)}
+        return line
+
+    add("C1: NVTiny fp32, 513x161, batch 1 (plumbing case)", nvtiny)
+    return out
+
+
+def exact_fp32_value(lib, dev, blob, b, nctx, spc, left, right, ref, steps=60):
+    """The headline set-up with RT_CONV_EXACT_FP32=1: every convolution on the fp32 fmaf-chain kernels of round 1 (no fp16 split)."""
+    os.environ["RT_CONV_EXACT_FP32"] = "1"
+    try:
+        nets = [lib.create("resnet18_2D", W, H, max_batch=b, weights=blob) for _ in range(nctx)]
+    finally:
+        del os.environ["RT_CONV_EXACT_FP32"]
+    for n_ in nets:
+        n_.set_streams(spc)
+    disps = [torch.empty(b, 1, H, W, device=dev) for _ in nets]
+    streams = make_streams(lib.kernels, nctx, dev)
+    for i in range(2 * nctx):
+        nets[i % nctx].execute(left, right, disps[i % nctx], b, stream=streams[i % nctx].cuda_stream)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(steps):
+        nets[i % nctx].execute(left, right, disps[i % nctx], b, stream=streams[i % nctx].cuda_stream)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t1
+    parity = max(float((d.cpu() - ref).abs().max()) for d in disps)
+    launches = nets[0].num_launches
+    for n_ in nets:
+        n_.destroy()
+    return {"value": steps * b / dt, "unit": "pairs/s", "steps": steps, "launches_per_step": launches, "parity_max_abs_err": parity,
+            "note": "RT_CONV_EXACT_FP32=1: fp32 fmaf chains on the fp32 matrix pipe / Winograd F(2x2,3x3), same contexts and streams"}
 
 
 def main():
@@ -351,6 +548,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="3-D models: also run the CPU oracle at the timed size (minutes)")
     ap.add_argument("--from-host", action="store_true", help="also measure the PCIe-inclusive rate (extra JSON object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary lines (BASELINE C3 / C5 / C4, 513x257, NVTiny), value_200 and value_exact_fp32 of the default run")
     ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("RT_BENCH_SPINUP_MS", "80")),
                     help="keep the GPU busy with (untimed, uncounted) steps for this long before the W warm-up steps: the shader clock "
                          "of an idle MI355X needs ~50 ms of load to reach its sustained value (measured: 20 timed steps give 1883 / "
@@ -393,23 +592,46 @@ def main():
         return
 
     # ---- weights: rank 0 owns the file image, everyone else receives it over RCCL/xGMI ------------------
+    # Through the NATIVE entry (include/rt_stereo.h: rt_comm_*, rt_stereo_net.h: rt_net_create_broadcast -> ncclBroadcast from librccl,
+    # no torch in the path; torch.distributed only carries the communicator's 128-byte unique id).  If that entry fails on this node the
+    # image goes through torch.distributed's broadcast instead -- loudly, and the JSON line says which transport was used.
     weights, weights_desc = None, None
+    blob = None
     if rank == 0:
         weights, weights_desc = load_weights(args.half2)
         blob = capi.pack_weights(weights, fp16=args.half2)
-    if distributed:
-        import torch.distributed as dist
-        blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
     import zlib
-    blob_crc = zlib.crc32(blob) & 0xffffffff
-    if distributed:
-        print("bench.py: rank %d/%d (RCCL world size %d) on cuda:%d, weight image %d bytes crc32 %08x" % (
-            rank, world, torch.distributed.get_world_size(), local_rank, len(blob), blob_crc), file=sys.stderr, flush=True)
-
     lib = capi.NetLib()
     lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")
-    nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob, fp16_weights=args.half2)
-            for _ in range(args.contexts)]
+    transport, nets = "none (one rank)", None
+    if distributed:
+        import torch.distributed as dist
+        try:
+            nets, blob_crc = parallel.create_nets_native(lib, "resnet18_2D", W, H, args.contexts, blob, rank, world, dist, max_batch=args.batch,
+                                                         fp16_weights=args.half2)
+            transport = "rccl-native (rt_net_create_broadcast)"
+        except Exception as e:                                  # noqa: BLE001 -- any failure of the native entry must not cost the scaling run
+            print("bench.py: rank %d: native RCCL entry failed (%s: %s) -- broadcasting the weight image through torch.distributed instead" % (
+                rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            nets = None
+        ok = torch.tensor([1 if nets is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)               # all ranks on the same transport
+        if int(ok.item()) == 0:
+            if nets is not None:
+                for n_ in nets:
+                    n_.destroy()
+            blob = parallel.broadcast_blob(blob if rank == 0 else b"", rank, dev, dist)
+            nets, transport = None, "torch.distributed broadcast (fallback)"
+    if nets is None:
+        blob_crc = zlib.crc32(blob) & 0xffffffff
+        nets = [lib.create("resnet18_2D", W, H, max_batch=args.batch, weights=blob, fp16_weights=args.half2)
+                for _ in range(args.contexts)]
+    if distributed:
+        print("bench.py: rank %d/%d (RCCL world size %d) on cuda:%d, weight image crc32 %08x via %s" % (
+            rank, world, torch.distributed.get_world_size(), local_rank, blob_crc, transport), file=sys.stderr, flush=True)
+        if rank != 0:
+            blob = nets[0].weights_image()                      # (value_exact_fp32 etc. only run on one rank; kept for symmetry)
+
     net = nets[0]
     spc = args.streams_per_context or (1 if (args.contexts > 1 and not args.half2) else 2)      # half2: 3978 (4 x 2) vs 3881 (6 x 1) pairs/s at batch 8
     for n_ in nets:
@@ -460,6 +682,16 @@ def main():
         rank_rows = gathered
         elapsed = float(t.item())
     barrier()
+    default_run = (world == 1 and not args.half2 and b == 1 and not args.from_host and not args.no_secondary and
+                   os.environ.get("RT_CONV_EXACT_FP32", "0") == "0")
+    value_200 = None
+    if default_run and args.steps < 200:                       # the driver's K = 20 is 9 ms of timed region: the same contexts over 200 steps
+        t1 = time.perf_counter()
+        for i in range(200):
+            step(i)
+        torch.cuda.synchronize(dev)
+        value_200 = {"value": 200 * b / (time.perf_counter() - t1), "unit": "pairs/s", "steps": 200,
+                     "note": "same contexts, right after the contracted K steps"}
     # the reference's own loop for comparison (sample_app/main.cpp:303-309): one context, one pair in flight
     single = None
     if nctx > 1 and rank == 0:
@@ -592,22 +824,32 @@ def main():
         parity = max(float((d.cpu() - ref).abs().max()) for d in disps)
         budget = 1e-2 if args.half2 else 1e-3
         assert parity <= budget, "disparity differs from the oracle by %.3g (budget %.0e)" % (parity, budget)
+    value_exact, secondary = None, None
+    if default_run and rank == 0:
+        value_exact = exact_fp32_value(lib, dev, blob, b, nctx, spc, left, right, ref)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream ------
         prof_runs = 5
         rows = [r for _ in range(prof_runs) for r in net.profile(left, right, disp, b)]
-        # residual blocks that run as ONE launch are named "<conv1>+<conv2>" by the executor (engine.cpp: fuseResBlocks)
+        # residual blocks that run as ONE launch are named "<conv1>+<conv2>" by the executor (engine.cpp: fuseResBlocks); a launch that
+        # covers the twin layers of both towers (mergeSiamese) "<left> | <right>": it processes 2 b images
         fused = any(dominant(n) and "+" in n for n, _ in rows)
-        sel = [ms for n, ms in rows if dominant(n) and (("+" in n) == fused)]
-        tot, cnt = sum(sel), len(sel)
-        avg_s = tot / cnt * 1e-3
+        sel = [(n, ms) for n, ms in rows if dominant(n) and (("+" in n) == fused)]
+        imgs = lambda n: b * (2 if " | " in n else 1)
+        tot_s = sum(ms for _, ms in sel) * 1e-3
+        tot_imgs = sum(imgs(n) for n, _ in sel)
+        cnt = len(sel)
+        avg_s = tot_s / cnt
+        avg_imgs = tot_imgs / cnt                                  # images per launch, averaged over the dominant launches
         launches = cnt // prof_runs
         step_s = elapsed / args.steps
         traffic, traffic_src = measured_traffic(args.half2, None if args.half2 else fused) if b == 1 else (None, None)
         exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
-        iso_us = isolated_dominant(lib.kernels, b, args.half2, fused=fused)
-        flops = BLOCK_FLOPS if fused else DOMINANT_FLOPS
+        b_iso = int(round(avg_imgs)) if avg_imgs > 1.5 * b else b  # the typical dominant launch: both towers when they are merged
+        hints = capi.RT_HINT_THROUGHPUT if spc == 1 else 0
+        iso_us = isolated_dominant(lib.kernels, b_iso, args.half2, fused=fused, hints=hints)
+        flops = BLOCK_FLOPS if fused else DOMINANT_FLOPS           # per image
         if args.half2:
             # fp16 operands on the matrix cores: 2.5 PFLOP/s makes the layer HBM-bound, so it is priced in
             # bytes: x, residual, y as fp16 + fp16 weights + fp32 bias
@@ -619,18 +861,15 @@ def main():
             kernel = "conv_wino_f32_kernel<4,float,float,il,il> (RT_CONV_EXACT_FP32=1: Winograd F(2x2,3x3) on the fp32 matrix pipe)"
             mfma_exec = DOMINANT_FLOPS * 16.0 / 36.0
         else:
-            # fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (conv_split.hip.h): 3 x the direct-form multiplies at
-            # 16 x the fp32 rate -- 1/5 of the fp32 matrix time -- which leaves the layer bound by its fp32 traffic:
-            # x + residual + y (+ weights, bias), every byte once
             nbytes = BLOCK_BYTES if fused else DOMINANT_BYTES
             kernel = ("conv_s3rbs_kernel: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
                       "streaming down 30-column strips, intermediate rows in an LDS ring; fp32 tensors, 3-term fp16 split on "
                       "v_mfma_f32_32x32x16_f16, fp32 accumulate" if fused else
                       "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate")
             if fused:
-                # executed matrix work of the streaming kernel: 21 strips x segments, every step computes 4 rows x 32 columns of
-                # conv1 and of conv2 (halo rows / columns and the rows of the pipeline's fill and drain steps included)
-                seg = int(os.environ.get("RT_RBS_SEG", "0")) or 32
+                # executed matrix work of the streaming kernel per image: 21 strips x segments, every step computes 4 rows x 32 columns
+                # of conv1 and of conv2 (halo rows / columns and the rows of the pipeline's fill and drain steps included)
+                seg = int(os.environ.get("RT_RBS_SEG", "0")) or (64 if hints else 32)
                 strips, rows_exec = -(-HALF_W // 30), 0
                 for y0 in range(0, HALF_H, seg):
                     hseg = min(seg, HALF_H - y0)
@@ -638,56 +877,73 @@ def main():
                 mfma_exec = 3.0 * strips * rows_exec * 2.0 * 32 * 32 * 32 * 9
             else:
                 mfma_exec = 3.0 * flops
+        frac_executed = None
         if exact and not args.half2:
-            achieved, peak, unit, bound = flops * b / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
-            iso_frac = flops * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
+            achieved, peak, unit, bound = flops * tot_imgs / tot_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            iso_frac = flops * b_iso / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS
         elif fused and not args.half2:
-            # the fused block moves 2.8x fewer bytes than its two layers and is bound by matrix (+ vector) issue, not by HBM
-            # (DESIGN.md 4.4): priced in EXECUTED fp16 matrix FLOPs against the dense fp16 peak
-            achieved, peak, unit, bound = mfma_exec * b / avg_s / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
-            iso_frac = mfma_exec * b / iso_us / 1e6 / MFMA_F16_PEAK_TFLOPS
+            # the fused block moves 2.8x fewer bytes than its two layers and is bound by the SIMD's vector issue port (MFMA issue +
+            # VALU, tools/dev/README.md), not by HBM: priced in ALGORITHMIC matrix work -- 3 fp16 MFMA products per direct-form
+            # multiply, the minimum of the split scheme -- against the dense fp16 peak; the executed work (halo, fill / drain
+            # rows) is `frac_executed`
+            achieved, peak, unit, bound = 3.0 * flops * tot_imgs / tot_s / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            iso_frac = 3.0 * flops * b_iso / iso_us / 1e6 / MFMA_F16_PEAK_TFLOPS
+            frac_executed = mfma_exec * tot_imgs / tot_s / 1e12 / MFMA_F16_PEAK_TFLOPS
         else:
-            achieved, peak, unit, bound = nbytes * b / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-            iso_frac = nbytes * b / iso_us / 1e3 / HBM_PEAK_GBS
+            achieved, peak, unit, bound = nbytes * tot_imgs / tot_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+            iso_frac = nbytes * b_iso / iso_us / 1e3 / HBM_PEAK_GBS
         overlapped = launches * avg_s > step_s * b            # launches of several streams / contexts run concurrently
         mfma_peak = MFMA_F32_PEAK_TFLOPS if (exact and not args.half2) else MFMA_F16_PEAK_TFLOPS
+        # share of the GPU's time the dominant launches take in the TIMED run (several contexts in flight): their profiled durations
+        # overlap with other contexts' launches there, so the throughput statement is work / (share x step time)
+        dom_share = sum(ms for n, ms in rows if dominant(n) and (("+" in n) == fused)) / max(sum(ms for _, ms in rows), 1e-9)
+        dom_work_step = (3.0 * flops if (fused and not args.half2 and not exact) else flops) * (tot_imgs / prof_runs)
         roofline = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                    "frac_note": ("launch duration by HIP events on the launch stream in profiled steps of one context (%d stream(s)); %d launches x "
-                                  "%.1f us %s one step of %.1f us: in the timed run the launches of %d contexts overlap -- frac_step* are the "
-                                  "throughput statements" % (spc, launches, avg_s * 1e6, ">" if overlapped else "<=", step_s * 1e6, nctx)),
+                    "frac_note": ("ALGORITHMIC work of the dominant launches (SURVEY.md 8d x images per launch%s) / their durations by HIP events on the launch "
+                                  "stream in profiled steps of one context (%d stream(s)); %d launches x %.1f us %s one step of %.1f us: in the timed run the "
+                                  "launches of %d contexts overlap -- frac_throughput / frac_step* are the throughput statements" % (
+                                      "; x 3 fp16 MFMA products per multiply" if bound == "mfma" and not exact else "", spc, launches, avg_s * 1e6,
+                                      ">" if overlapped else "<=", step_s * 1e6, nctx)),
+                    "frac_executed": frac_executed,
+                    "frac_throughput": dom_work_step / (dom_share * step_s) / (1e12 if bound == "mfma" else 1e9) / peak if bound == "mfma" else None,
+                    "frac_throughput_note": "algorithmic work of one step's dominant launches / (their share of the profiled launch time x ms_per_step) / peak",
+                    "dominant_share_of_launch_time": dom_share,
                     "overlapped": bool(overlapped), "traffic": traffic,
                     "traffic_unit": "bytes/launch (PMC pass %s)" % traffic_src,
-                    "algorithmic_bytes": nbytes * b, "flops_per_launch": flops * b,
+                    "images_per_launch": avg_imgs,
+                    "algorithmic_bytes": nbytes * avg_imgs, "flops_per_launch": flops * avg_imgs,
                     "avg_launch_us": avg_s * 1e6, "launches_per_step": launches,
-                    "isolated_launch_us": iso_us, "frac_isolated": iso_frac,
+                    "isolated_launch_us": iso_us, "isolated_images_per_launch": b_iso, "frac_isolated": iso_frac,
                     # whole step against the roofs: direct-form FLOPs of the network / fp32 matrix peak, and the minimum
                     # (perfectly fused) activation traffic of SURVEY.md 8d / HBM peak
                     "frac_step": NET_FLOPS * b / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
                     "frac_step_note": "91.87 GFLOP (direct form) per pair / ms_per_step / 157.3 TFLOP/s fp32 matrix peak; above 1 is "
                                       "possible because the split kernels run on the fp16 pipe",
+                    "frac_step_f16_split": 3.0 * NET_FLOPS * b / step_s / 1e12 / MFMA_F16_PEAK_TFLOPS,
                     "step_tflops": NET_FLOPS * b / step_s / 1e12,
-                    # ... and the whole step against the HBM roof: algorithmic bytes of all 48 launches (each tensor once per launch
-                    # that touches it; fp16 tensors in half2 mode) / step time -- what four overlapping contexts sustain
+                    # ... and the whole step against the HBM roof: algorithmic bytes of all launches layer by layer (each tensor once per
+                    # launch that touches it; fp16 tensors in half2 mode) / step time -- what the overlapping contexts sustain
                     "step_algorithmic_bytes": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b,
                     "step_gbs": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b / step_s / 1e9,
                     "frac_step_hbm": net_bytes_2d() * (0.5 if args.half2 else 1.0) * b / step_s / 1e9 / HBM_PEAK_GBS,
                     # the same launch on round 1's scale (direct-form FLOPs / fp32 matrix peak, where the Winograd kernel had 0.63 / 0.69)
-                    "direct_form_tflops": flops * b / avg_s / 1e12, "direct_form_tflops_isolated": flops * b / iso_us / 1e6,
-                    "frac_of_fp32_mfma_peak": flops * b / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                    "frac_of_fp32_mfma_peak_isolated": flops * b / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                    "mfma_flops_executed": mfma_exec * b,
-                    "mfma_util_executed": mfma_exec * b / iso_us / 1e6 / mfma_peak,
+                    "direct_form_tflops": flops * tot_imgs / tot_s / 1e12, "direct_form_tflops_isolated": flops * b_iso / iso_us / 1e6,
+                    "frac_of_fp32_mfma_peak": flops * tot_imgs / tot_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "frac_of_fp32_mfma_peak_isolated": flops * b_iso / iso_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                    "mfma_flops_executed": mfma_exec * avg_imgs,
+                    "mfma_util_executed": mfma_exec * b_iso / iso_us / 1e6 / mfma_peak,
                     "mfma_util_note": "executed matrix FLOPs of one launch / isolated duration / %.0f TFLOP/s (%s pipe)" % (
                         mfma_peak, "fp32" if (exact and not args.half2) else "fp16"),
-                    "hbm_gbs": nbytes * b / avg_s / 1e9, "frac_hbm": nbytes * b / avg_s / 1e9 / HBM_PEAK_GBS,
-                    "frac_hbm_note": "algorithmic bytes of the same launch / in-situ duration / 8 TB/s"}
+                    "hbm_gbs": nbytes * tot_imgs / tot_s / 1e9, "frac_hbm": nbytes * tot_imgs / tot_s / 1e9 / HBM_PEAK_GBS,
+                    "frac_hbm_note": "algorithmic bytes of the same launches / in-situ duration / 8 TB/s"}
         if fused and not args.half2:
-            roofline["bound_note"] = ("matrix and vector instructions share a SIMD's issue port on gfx950, also across waves (tools/micro/mfma_f16_valu.hip: "
-                                      "92 % of the sum): a 4-row step of this kernel needs 108 MFMAs x 32 = 3.5 k matrix cycles + ~2 k vector cycles per "
-                                      "SIMD and takes ~6 k (profiles/r02_phases.txt); the rest of `frac` is the 2.5 PFLOP/s peak assuming 2.4 GHz "
-                                      "(sustained here: 2.0-2.2), the prologue and the half-empty first / last pipeline step of a segment")
+            roofline["bound_note"] = ("bound by the SIMD's vector issue port: a v_mfma_f32_32x32x16_f16 holds it ~14.6 of its 32 cycles, the VALU work of a 4-row "
+                                      "step (ELU, fp16 splits, addressing: ~1.5 k cycles per SIMD) needs the rest, and two in-order waves per SIMD reach 66-73 % "
+                                      "of it (tools/micro/mfma_interleave.hip, tools/dev/README.md: a rebuild with every wave's vector work sliced into "
+                                      "its own MFMA stream measured 4.7 k instead of 5.0 k cycles per step, one step more per segment, no gain); the rest "
+                                      "of `frac` is the 2.5 PFLOP/s peak assuming 2.4 GHz (sustained: 2.0-2.2), the prologue and the pipeline's fill / drain steps")
         if fused and not args.half2:
-            # continuity with the layer-by-layer kernel (the roofline object of earlier benches; still runs the other 18 convolutions)
+            # continuity with the layer-by-layer kernel (the roofline object of earlier benches; still runs the other convolutions)
             g_us = isolated_dominant(lib.kernels, b, args.half2, fused=False)
             roofline["layer_by_layer_kernel"] = {"kernel": "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU)", "bound": "hbm",
                                                  "isolated_launch_us": g_us, "algorithmic_bytes": DOMINANT_BYTES * b,
@@ -699,6 +955,9 @@ def main():
             "spinup": {"ms": args.spinup_ms, "untimed_steps": spun,
                        "why": "clock governor: the timed K steps follow W warm-up steps as contracted; before those the GPU is kept busy this long"},
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_pair": elapsed / args.steps / b * 1e3,
+            "ms_per_pair_note": "1 / throughput with %d pairs in flight; latency_ms_per_pair is one pair through one context, synchronously" % nctx,
+            "latency_ms_per_pair": single["synchronous_execute"]["ms_per_pair"] if single else None,
+            "value_200": value_200, "value_exact_fp32": value_exact,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 (f32 accumulate)" if args.half2 else "f32", "data": "synthetic",
             "arithmetic": ("fp16 operands, fp32 accumulate (TensorRT half2 mode)" if args.half2 else
@@ -708,7 +967,7 @@ def main():
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "streams_per_context": spc, "launches_per_step": net.num_launches, "layers": net.num_layers,
-                       "weights": weights_desc, "parallelism": "pairs sharded over %d GPU(s)" % world},
+                       "weights": weights_desc, "weights_transport": transport, "parallelism": "pairs sharded over %d GPU(s)" % world},
             "parity_max_abs_err": parity, "contexts_max_abs_diff": ctx_diff,
             "parity_note": "max |disp - oracle| over the %d timed context(s), same pair(s), %s; budget %s" % (
                 nctx, "oracle on the fp16-rounded weights" if args.half2 else "fp32 oracle", "1e-2" if args.half2 else "1e-3"),
@@ -721,6 +980,10 @@ def main():
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights)
+        if default_run:
+            secondary = secondary_lines(lib, dev)
+        if secondary is not None:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     for n in nets:
         n.destroy()

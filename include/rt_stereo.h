@@ -32,7 +32,7 @@ typedef void* rtStream;
 enum { RT_F32 = 0, RT_F16 = 1 };                     /* nvinfer1::DataType kFLOAT / kHALF            */
 enum { RT_NCHW = 0, RT_NC2HW2 = 1 };                 /* nvinfer1::PluginFormat                       */
 enum { RT_ACT_NONE = 0, RT_ACT_ELU = 1, RT_ACT_SIGMOID = 2 };
-enum { RT_E_BADARG = -1, RT_E_UNSUPPORTED = -2, RT_E_NODEVICE = -3, RT_E_NOMEM = -4 };
+enum { RT_E_BADARG = -1, RT_E_UNSUPPORTED = -2, RT_E_NODEVICE = -3, RT_E_NOMEM = -4, RT_E_RUNTIME = -5 };
 
 /* ---- library / device ------------------------------------------------------------------- */
 const char* rt_last_error_string(void);
@@ -248,7 +248,38 @@ int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]);
 /* Run: x, y (and residual, shaped like y, or NULL) are device pointers for `batch` samples. */
 int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                     rtStream stream);
+/* The same with launch hints (0 = rt_conv_enqueue).  RT_HINT_THROUGHPUT: the caller keeps several launches in flight on the device
+ * (execution contexts with one stream each, TensorRT's `trtexec --streams` set-up; IExecutionContext::setExecutionStreams(1)): kernels
+ * may then trade the duration of one launch for device time per result -- the streaming residual block walks 64-row instead of 32-row
+ * segments (fewer pipeline fill / drain steps per row, half the workgroups per launch).  Results do not depend on hints. */
+#define RT_HINT_THROUGHPUT 1
+int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
+                         rtStream stream, int hints);
 int rt_conv_plan_destroy(rtConvPlan* plan);
+
+/* ---- multi-GPU: RCCL communicator and byte broadcast ---------------------------------------------------------
+ * Stereo pairs are independent (the reference is single-GPU, batch 1: sample_app/main.cpp:260, 303-305), so ranks share
+ * nothing but the weight-file image: rank `root` reads trt_weights.bin, every other rank receives it over RCCL / xGMI
+ * (ncclBroadcast) at start-up, and no collective touches the data path.  librccl is loaded on first use (dlopen), so
+ * single-GPU users never pay for it.  One communicator per (process or thread, device): call rt_set_device first.
+ *   rank 0:  rt_comm_unique_id(id)  -> ship the 128 bytes to the other ranks by any means (file, socket, MPI, torchrun's store)
+ *   all:     rt_comm_init_rank(&comm, world, rank, id)          (ncclCommInitRank)
+ *   or:      rt_comm_adopt(&comm, existing ncclComm_t)           (a communicator the host application already has; not destroyed)
+ *   or:      rt_comm_init_all(comms, ndev, devices)              (one process driving several devices: ncclCommInitAll)
+ *   all:     rt_comm_broadcast(comm, host_buffer, bytes, root, stream)   blocking; bytes must agree on every rank
+ * Calls of one process that must progress together (several comms driven from one thread) go between
+ * rt_comm_group_start / rt_comm_group_end. */
+typedef struct rtComm rtComm;
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void* id_bytes);
+int rt_comm_init_rank(rtComm** comm, int world, int rank, const void* id_bytes);
+int rt_comm_init_all(rtComm** comms, int ndev, const int* devices);
+int rt_comm_adopt(rtComm** comm, void* nccl_comm);
+int rt_comm_info(const rtComm* comm, int* world, int* rank);
+int rt_comm_broadcast(rtComm* comm, void* host_buf, size_t bytes, int root, rtStream stream);
+int rt_comm_group_start(void);
+int rt_comm_group_end(void);
+int rt_comm_destroy(rtComm* comm);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,18 @@ int rt_net_create(rtStereoNet** net, int model, int width, int height, int max_b
 int rt_net_create_from_memory(rtStereoNet** net, int model, int width, int height, int max_batch, int weights_dtype,
                               int max_disp, const void* blob, size_t bytes);
 
+/* Multi-GPU start-up without Python: every rank of `comm` (rt_stereo.h: rt_comm_init_rank / rt_comm_adopt / rt_comm_init_all)
+ * calls this on its own device; rank `root` passes the weight-file image, the others pass NULL / 0 and receive it over RCCL
+ * (ncclBroadcast: first its size, then its bytes), then every rank builds the same engine.  What redtail_amd/parallel.py does
+ * through torch.distributed, for hosts that have no torch (apps/stereo_throughput.cpp).  comm == NULL: world of one rank. */
+int rt_net_create_broadcast(rtStereoNet** net, int model, int width, int height, int max_batch, int weights_dtype,
+                            int max_disp, const void* blob, size_t bytes, rtComm* comm, int root);
+/* crc32 (zlib polynomial) of the weight-file image the engine was built from: every rank prints it, they must agree */
+int rt_net_weights_crc32(const rtStereoNet* net, uint32_t* crc);
+/* The image itself (owned by the engine, valid until rt_net_destroy): a rank that received it by broadcast builds its further
+ * execution contexts from it (rt_net_create_from_memory). */
+int rt_net_weights_image(const rtStereoNet* net, const void** data, size_t* bytes);
+
 /* left/right: device (N,3,H,W) fp32 in [0,1]; disp: device (N,1,H,W) fp32 (ResNet-18 2D: disparity / width;
  * 3-D models: pixels).  stream == NULL: synchronous (IExecutionContext::execute); otherwise asynchronous on
  * that HIP stream (IExecutionContext::enqueue). */

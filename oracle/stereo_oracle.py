@@ -284,11 +284,30 @@ def resnet18_2d(left, right, w, max_disp=48, return_intermediates=False):
     return out
 
 
-def stereo3d(left, right, w, cfg, max_disp):
+def stereo3d(left, right, w, cfg, max_disp, plugin_fp16=False):
     """NVSmall / NVTiny / ResNet-18 (3-D) networks: sample_app/nvsmall_1025x321_net.cpp,
     nvtiny_513x161_net.cpp, resnet18_1025x321_net.cpp (scripts/model_nvsmall.py:18-73,
     scripts/model_resnet18.py:46-85).  max_disp is the half-resolution D of the cost volume.
-    Returns (N,1,H,W) disparity in pixels (softargmin)."""
+    Returns (N,1,H,W) disparity in pixels (softargmin).  float64 inputs evaluate the whole graph in fp64.
+
+    plugin_fp16=True restates what the reference's Conv3D / Conv3DTranspose plugins do when they are created with fp16 weights
+    (lib/conv3d_plugin.cpp:187-216, 247-274; lib/conv3d_transpose_plugin.cpp): the fp32 input is converted to fp16, cuDNN
+    convolves fp16 tensors (the output is an fp16 tensor), the bias is added to that fp16 tensor (cudnnAddTensor), and the
+    result is converted back to fp32 -- everything between the plugins (ELU, transform, slice, skip add, soft-argmin) stays fp32."""
+    r16 = lambda t: t.half().to(t.dtype)
+
+    def conv3d_p(x, kk, b, *a):
+        if not plugin_fp16:
+            return conv3d_tf(x, kk, b, *a)
+        y = r16(conv3d_tf(r16(x), kk, None, *a))                  # (N, K, D, H, W) fp16 tensor
+        return r16(y + b.view(1, -1, 1, 1, 1))
+
+    def deconv3d_p(y, kk, b, *a):
+        if not plugin_fp16:
+            return conv3d_transpose_tf(y, kk, b, *a)
+        x = r16(conv3d_transpose_tf(r16(y), kk, None, *a))        # (N, D, C, H, W)
+        return r16(x + b.view(1, 1, -1, 1, 1))
+
     def enc(x, side):
         if cfg["enc2d"] == "resnet":
             return _resnet_encoder(x, w, side)[0]
@@ -308,9 +327,9 @@ def stereo3d(left, right, w, cfg, max_disp):
             pd = tf_same_pad(cur.shape[1] - 1, 3, 2)
             ph = tf_same_pad(cur.shape[3], 3, 2)
             pw = tf_same_pad(cur.shape[4], 3, 2)
-            cur = conv3d_tf(cur, kk, b, (2, 2, 2), (pd[0], ph[0], pw[0]), (pd[1], ph[1], pw[1]))
+            cur = conv3d_p(cur, kk, b, (2, 2, 2), (pd[0], ph[0], pw[0]), (pd[1], ph[1], pw[1]))
         else:
-            cur = conv3d_tf(cur, kk, b, (1, 1, 1), (1, 1, 1), (1, 1, 1))
+            cur = conv3d_p(cur, kk, b, (1, 1, 1), (1, 1, 1), (1, 1, 1))
         if name != last:
             cur = transform(cur)                     # KDHW -> DKHW
         cur = elu(cur)
@@ -325,10 +344,10 @@ def stereo3d(left, right, w, cfg, max_disp):
             dx, hx, wx = 2 * dy, 2 * hy - 1, 2 * wy - 1
         pd = tf_same_pad(dx, 3, 2)
         if pd[0] != pd[1]:                           # tensorrt_model_builder.py:422-440
-            cur = conv3d_transpose_tf(cur, kk, b, (dx + 1, c, hx, wx), (2, 2, 2), (0, 1, 1), (0, 1, 1))
+            cur = deconv3d_p(cur, kk, b, (dx + 1, c, hx, wx), (2, 2, 2), (0, 1, 1), (0, 1, 1))
             cur = slice_d(cur, 0, dx)
         else:
-            cur = conv3d_transpose_tf(cur, kk, b, (dx, c, hx, wx), (2, 2, 2), (pd[0], 1, 1), (pd[1], 1, 1))
+            cur = deconv3d_p(cur, kk, b, (dx, c, hx, wx), (2, 2, 2), (pd[0], 1, 1), (pd[1], 1, 1))
         if skip is not None:
             cur = elu(cur + acts[skip])
             cur = transform(cur)                     # DKHW -> KDHW

@@ -195,6 +195,37 @@ def build_reference_tests(force=False, emu=False):
     return out
 
 
+def build_native_apps(force=False):
+    """apps/stereo_throughput.cpp: the native multi-GPU driver (one thread per device, RCCL weight broadcast through the C ABI)
+    -> redtail_amd/lib/stereo_throughput (git-ignored, travels to the GPU box)."""
+    src = os.path.join(ROOT, "apps", "stereo_throughput.cpp")
+    out = os.path.join(LIB, "stereo_throughput")
+    host, kern = build_host(), build_hip()
+    if force or _newer(out, [src, host, os.path.join(ROOT, "include")]):
+        _run([GXX, "-std=c++17", "-O2", "-g", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), src,
+              "-L", LIB, "-l:" + os.path.basename(host), "-l:" + os.path.basename(kern), "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
+def build_engine_tests(force=False, emu=False):
+    """Our own C++ test program for the executor's graph passes on graphs the four models do not contain
+    (tests/cpp/engine_graph_tests.cpp; driven by tests/test_engine_graphs.py).  Output: tools/build/engine_graph_tests
+    (git-ignored, travels to the GPU box) or, emu=True, tests/emu/build/engine_graph_tests_emu."""
+    src = os.path.join(ROOT, "tests", "cpp", "engine_graph_tests.cpp")
+    outdir = EMU_BUILD if emu else os.path.join(ROOT, "tools", "build")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "engine_graph_tests_emu" if emu else "engine_graph_tests")
+    host = build_host_emu() if emu else build_host()
+    kern = build_emu() if emu else build_hip()
+    if force or _newer(out, [src, host]):
+        libdir, libname = os.path.split(host)
+        _run([GXX, "-std=c++17", "-O1", "-g", "-Wall", "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(ROOT, "redtail_amd", "include"), src,
+              "-L", libdir, "-l:" + libname, "-l:" + os.path.basename(kern),
+              "-Wl,-rpath,$ORIGIN/../../redtail_amd/lib", "-Wl,-rpath," + libdir, "-o", out])
+    return out
+
+
 def main(argv):
     what = argv or ["hip", "host", "emu"]
     if "hip" in what:
@@ -204,6 +235,8 @@ def main(argv):
     if "apps" in what:
         build_sample_app()
         build_reference_tests()
+        build_engine_tests()
+        build_native_apps()
     if "emu" in what:
         build_emu()
         if os.path.exists(os.path.join(CSRC, "host", "engine.cpp")):

@@ -17,6 +17,9 @@ RT_NCHW, RT_NC2HW2 = 0, 1
 RT_ACT_NONE, RT_ACT_ELU, RT_ACT_SIGMOID = 0, 1, 2
 
 
+RT_HINT_THROUGHPUT = 1     # include/rt_stereo.h
+
+
 class RtError(RuntimeError):
     pass
 
@@ -84,8 +87,20 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_conv_enqueue_hint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "rt_conv_plan_destroy": (c_int, [c_void_p]),
+    # multi-GPU: RCCL communicator + byte broadcast (librccl is loaded on first use)
+    "rt_comm_unique_id": (c_int, [c_void_p]),
+    "rt_comm_init_rank": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "rt_comm_init_all": (c_int, [POINTER(c_void_p), c_int, POINTER(c_int)]),
+    "rt_comm_adopt": (c_int, [POINTER(c_void_p), c_void_p]),
+    "rt_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "rt_comm_broadcast": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "rt_comm_group_start": (c_int, []),
+    "rt_comm_group_end": (c_int, []),
+    "rt_comm_destroy": (c_int, [c_void_p]),
 }
+RT_COMM_ID_BYTES = 128
 
 
 def _ptr(x):
@@ -242,8 +257,8 @@ class ConvPlan:
         """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
         self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")
 
-    def enqueue(self, x, y, residual=None, batch=1, stream=None):
-        self.klib.check(self.klib.lib.rt_conv_enqueue(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream),
+    def enqueue(self, x, y, residual=None, batch=1, stream=None, hints=0):
+        self.klib.check(self.klib.lib.rt_conv_enqueue_hint(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream, hints),
                         "rt_conv_enqueue")
 
     def destroy(self):
@@ -276,6 +291,9 @@ NET_SYMBOLS = {
     "rt_net_num_layers": (c_int, [c_void_p]),
     "rt_net_num_launches": (c_int, [c_void_p]),
     "rt_net_set_streams": (c_int, [c_void_p, c_int]),
+    "rt_net_create_broadcast": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int]),
+    "rt_net_weights_crc32": (c_int, [c_void_p, POINTER(ctypes.c_uint32)]),
+    "rt_net_weights_image": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "rt_net_destroy": (c_int, [c_void_p]),
     "rt_net_last_error": (c_char_p, []),
 }
@@ -343,6 +361,31 @@ class NetLib:
         self.check(rc, "rt_net_create")
         return StereoNet(self, h, width, height)
 
+    # ---- multi-GPU start-up through the native RCCL entry (include/rt_stereo.h: rt_comm_*, rt_stereo_net.h: rt_net_create_broadcast)
+    def comm_unique_id(self):
+        """rank 0: the 128 bytes every other rank needs for comm_init_rank (ncclGetUniqueId)"""
+        buf = ctypes.create_string_buffer(RT_COMM_ID_BYTES)
+        self.kernels.check(self.kernels.lib.rt_comm_unique_id(buf), "rt_comm_unique_id")
+        return buf.raw
+
+    def comm_init_rank(self, world, rank, unique_id):
+        """ncclCommInitRank on the current device (rt_set_device first); returns an opaque handle"""
+        h = c_void_p()
+        self.kernels.check(self.kernels.lib.rt_comm_init_rank(ctypes.byref(h), world, rank, unique_id), "rt_comm_init_rank")
+        return h
+
+    def comm_destroy(self, comm):
+        self.kernels.check(self.kernels.lib.rt_comm_destroy(comm), "rt_comm_destroy")
+
+    def create_broadcast(self, model, width, height, comm, root=0, max_batch=1, blob=None, fp16_weights=False, max_disp=0):
+        """every rank calls this; rank `root` passes the weight-file image, the others receive it over RCCL (ncclBroadcast)"""
+        h = c_void_p()
+        dt = RT_F16 if fp16_weights else RT_F32
+        mid = MODEL_IDS[model] if isinstance(model, str) else model
+        rc = self.lib.rt_net_create_broadcast(ctypes.byref(h), mid, width, height, max_batch, dt, max_disp, blob, len(blob) if blob else 0, comm, root)
+        self.check(rc, "rt_net_create_broadcast")
+        return StereoNet(self, h, width, height)
+
     def create_from_plan(self, plan, width, height):
         """IRuntime::deserializeCudaEngine on bytes returned by StereoNet.serialize()"""
         h = c_void_p()
@@ -365,6 +408,18 @@ class StereoNet:
     def execute(self, left, right, disp, batch=1, stream=None):
         self.netlib.check(self.netlib.lib.rt_net_execute(self.handle, _ptr(left), _ptr(right), _ptr(disp), batch, stream),
                           "rt_net_execute")
+
+    def weights_crc32(self):
+        """crc32 of the weight-file image this engine was built from (== zlib.crc32 of the file)"""
+        c = ctypes.c_uint32()
+        self.netlib.check(self.netlib.lib.rt_net_weights_crc32(self.handle, ctypes.byref(c)), "rt_net_weights_crc32")
+        return c.value
+
+    def weights_image(self):
+        """bytes of the weight-file image the engine holds (what a non-root rank received by broadcast)"""
+        p, n = c_void_p(), c_size_t()
+        self.netlib.check(self.netlib.lib.rt_net_weights_image(self.handle, ctypes.byref(p), ctypes.byref(n)), "rt_net_weights_image")
+        return ctypes.string_at(p.value, n.value)
 
     def set_streams(self, n):
         """1: all launches on the caller's stream (throughput with several contexts); 2: second stream for the right encoder"""

@@ -60,6 +60,10 @@ struct TensorImpl : public ITensor {
     int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
     bool f16 = false;           // stored as fp16 (half2 mode); only tensors that only layout-aware launches touch
     bool il8 = false;           // fp16 and channel-interleaved, (C/8, H, pitch, 8): only fp16-arithmetic 3x3 plans touch it
+    // siamese towers (mergeSiamese): this right-tower tensor lives in the second half of its left-tower twin's buffer -- `batch`
+    // samples after the twin's first sample, so that one launch over 2 * batch samples serves both towers
+    int twin_of = -1;
+    bool has_twin = false;      // the left-tower tensor of such a pair: its buffer holds 2 * maxBatchSize samples
 
     void setName(const char* n) override { name = n ? n : ""; }
     const char* getName() const override { return name.c_str(); }
@@ -313,6 +317,11 @@ struct Op {
     int stream = 0;
     std::vector<int> wait_on;          // tensors produced on the other stream that this op consumes
     bool publish = false;              // another stream consumes the result: record an event after the launch
+    std::vector<int> lays;             // indices (layers_) of the layers this launch covers, in fusion order
+    // merged siamese launch (mergeSiamese): the right-tower op this launch also executes, as the second half of a 2 * batch launch
+    bool twin = false;
+    std::vector<int> twin_in;          // right-tower tensors it reads (inputs, residual): dependencies for the stream schedule
+    int twin_out = -1;                 // right-tower tensor it writes
 };
 
 class EngineImpl;
@@ -433,6 +442,7 @@ private:
     void foldCostVolumes();
     void assignHalf3D();
     void fuseResBlocks();
+    void mergeSiamese();
     bool ok_ = false;
     bool half2_ = false;
     std::vector<IPlugin*> half_plugins_;   // IPluginExt instances that only accept kHALF ...
@@ -484,11 +494,13 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
         }
     if (ok_) fuseResBlocks();
     if (ok_) assignPitch();
-    if (ok_) assignStreams();
+    if (ok_) assignStreams();           // preliminary: foldConcats wants to know which stream an op is on
     if (ok_) foldConcats();
     if (ok_) foldCostVolumes();
     if (ok_) assignHalf3D();
-    if (ok_) planIssueOrder();          // last: the passes above remove ops
+    if (ok_) mergeSiamese();
+    if (ok_) assignStreams();           // final: the passes above removed and merged ops (waits and publish flags are recomputed)
+    if (ok_) planIssueOrder();
 }
 
 EngineImpl::~EngineImpl() {
@@ -533,6 +545,7 @@ bool EngineImpl::lower() {
         done[li] = true;
         Op op;
         op.name = l->name;
+        op.lays.push_back((int)li);
         for (auto* t : l->in) op.in.push_back(t->id);
         op.out = l->out[0]->id;
 
@@ -569,18 +582,18 @@ bool EngineImpl::lower() {
                         if (other != cur && same_dims(other->dims, cur->dims) &&
                             (other->producer == nullptr || index_of(other->producer) < (int)li || done[index_of(other->producer)])) {
                             resid = other->id;
-                            done[index_of(nx)] = true;
+                            { done[index_of(nx)] = true; op.lays.push_back(index_of(nx)); }
                             cur = nx->out[0];
                             nx = soleConsumer(cur->id);
                         }
                     }
                     if (nx && isKind(nx, Kind::kElu)) {
                         act = RT_ACT_ELU;
-                        done[index_of(nx)] = true;
+                        { done[index_of(nx)] = true; op.lays.push_back(index_of(nx)); }
                         cur = nx->out[0];
                     } else if (nx && nx->type == LayerType::kACTIVATION && nx->act == ActivationType::kSIGMOID) {
                         act = RT_ACT_SIGMOID;
-                        done[index_of(nx)] = true;
+                        { done[index_of(nx)] = true; op.lays.push_back(index_of(nx)); }
                         cur = nx->out[0];
                     }
                 }
@@ -611,7 +624,7 @@ bool EngineImpl::lower() {
                 LayerData* nx = fuse ? soleConsumer(cur->id) : nullptr;
                 if (nx && isKind(nx, Kind::kElu)) {
                     op.act = RT_ACT_ELU;
-                    done[index_of(nx)] = true;
+                    { done[index_of(nx)] = true; op.lays.push_back(index_of(nx)); }
                     cur = nx->out[0];
                 }
                 op.out = cur->id;
@@ -641,7 +654,7 @@ bool EngineImpl::lower() {
                         op.max_disp = sp->maxDisparity();
                         op.is_min = stereo(nx)->softargmaxType() == SoftargmaxType::kMin;
                         op.out = nx->out[0]->id;
-                        done[index_of(nx)] = true;
+                        { done[index_of(nx)] = true; op.lays.push_back(index_of(nx)); }
                         ops_.push_back(op);
                         continue;
                     }
@@ -705,7 +718,7 @@ bool EngineImpl::lower() {
                         }
                     }
                     if ((f.act || f.out_dchw || f.residual || f.out_depth || f.in_pad_end) && sp->setFusion(f)) {
-                        for (int a : absorbed) done[a] = true;
+                        for (int a : absorbed) { done[a] = true; op.lays.push_back(a); }
                         if (f.in_pad_end) {                       // drop the Pad launch, consume its input
                             op.in[0] = ops_[folded_pad_op].in[0];
                             ops_.erase(ops_.begin() + folded_pad_op);
@@ -854,6 +867,10 @@ void EngineImpl::assignPitch() {
 }
 
 void EngineImpl::assignStreams() {
+    // (re)computed from scratch: the engine calls this once before the folding passes and once after them
+    two_streams_ = false;
+    for (auto& op : ops_) { op.stream = 0; op.wait_on.clear(); op.publish = false; }
+    for (auto& t : tensors_) t->stream = 0;
     if (getenv("RT_SINGLE_STREAM")) return;
     int n_inputs = 0;
     for (int b : bindings_)
@@ -869,11 +886,18 @@ void EngineImpl::assignStreams() {
         int d = 0;
         for (int i : op.in) d |= dep_of(i);
         if (op.resid >= 0) d |= dep_of(op.resid);
+        for (int i : op.twin_in) d |= dep_of(i);    // a merged siamese launch reads both towers
         dep[root(op.out)] |= d;
         dep[op.out] |= d;
         op.stream = d == 2 ? 1 : 0;
         tensors_[op.out]->stream = op.stream;
         tensors_[root(op.out)]->stream = op.stream;
+        if (op.twin_out >= 0) {
+            dep[root(op.twin_out)] |= d;
+            dep[op.twin_out] |= d;
+            tensors_[op.twin_out]->stream = op.stream;
+            tensors_[root(op.twin_out)]->stream = op.stream;
+        }
         side_ops += op.stream;
     }
     if (side_ops < 4) {          // not worth a second stream
@@ -889,10 +913,21 @@ void EngineImpl::assignStreams() {
         };
         for (int i : op.in) consider(i);
         if (op.resid >= 0) consider(op.resid);
+        for (int i : op.twin_in) consider(i);
     }
     for (auto& op : ops_)
         for (auto& o2 : ops_)
-            for (int w : o2.wait_on) op.publish |= (w == root(op.out));
+            for (int w : o2.wait_on) op.publish |= (w == root(op.out)) || (op.twin_out >= 0 && w == root(op.twin_out));
+    // every wait must have a launch that records the event it waits for (a pass that removes an op after this one would break that)
+    for (auto& op : ops_)
+        for (int w : op.wait_on) {
+            bool published = false;
+            for (auto& o2 : ops_) published = published || (o2.publish && (root(o2.out) == w || (o2.twin_out >= 0 && root(o2.twin_out) == w)));
+            if (!published) {
+                log_.log(ILogger::Severity::kERROR, ("engine: " + op.name + " waits for tensor '" + tensors_[w]->name + "' of the other stream, which no launch publishes").c_str());
+                ok_ = false;
+            }
+        }
 }
 
 void EngineImpl::planIssueOrder() {
@@ -922,6 +957,7 @@ void EngineImpl::planIssueOrder() {
             const size_t i = q[st][h[st]++];
             issue_sync_.push_back(i);
             for (int r = ops_[i].out; r >= 0; r = tensors_[r]->alias_of) produced[r] = 1;
+            for (int r = ops_[i].twin_out; r >= 0; r = tensors_[r]->alias_of) produced[r] = 1;
             turn = st ^ 1;
         }
         if (issue_sync_.size() != ops_.size()) issue_sync_.clear();
@@ -993,12 +1029,179 @@ void EngineImpl::fuseResBlocks() {
         a.resid = b.resid;
         a.act = b.act;
         a.name += "+" + b.name;                         // IProfiler rows name both layers
+        a.lays.insert(a.lays.end(), b.lays.begin(), b.lays.end());
         ops_.erase(ops_.begin() + ib);
         fused++;
     }
     if (fused)
         log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(fused) + " residual blocks fused into one launch each; " +
                                             std::to_string(ops_.size()) + " launches").c_str());
+}
+
+// Siamese towers in ONE launch per layer.  The two feature towers of every Stereo DNN share their weights (the reference exports
+// the TF variables once per side: left_* / right_* tensors of trt_weights.bin are byte-identical; resnet18_2D_513x257_net.cpp:48-575
+// builds the same layer sequence twice), so a left-tower launch and its right-tower twin differ only in the tensors they touch.
+// When the twin tensors of a pair are dense internal tensors of the same layout, the right one is PLACED `batch` samples behind the
+// left one in one buffer of 2 * maxBatchSize samples and the two launches become one launch over 2 * batch samples: twice the
+// workgroups per launch (the streaming residual block fills every CU: 252 instead of 126 workgroups at 1257x369), weights fetched
+// once, half the launches, and no second stream / cross-stream events for the towers.  The arithmetic per sample is untouched, so
+// results are bit-identical to the separate launches (tests/test_net_parity.py).
+void EngineImpl::mergeSiamese() {
+    if (getenv("RT_NO_SIAMESE") || getenv("RT_NO_FUSION")) return;
+    std::vector<int> ins;
+    for (int b : bindings_)
+        if (tensors_[b]->is_input) ins.push_back(b);
+    if (ins.size() != 2) return;
+    auto same_dims = [](const Dims& a, const Dims& b) {
+        if (a.nbDims != b.nbDims) return false;
+        for (int i = 0; i < a.nbDims; i++)
+            if (a.d[i] != b.d[i]) return false;
+        return true;
+    };
+    if (!same_dims(tensors_[ins[0]]->dims, tensors_[ins[1]]->dims)) return;
+    auto same_weights = [](const Weights& a, const Weights& b) {
+        if (a.count != b.count || a.type != b.type) return false;
+        if (a.count == 0) return true;
+        const size_t es = a.type == DataType::kHALF ? 2 : 4;
+        return a.values && b.values && (a.values == b.values || std::memcmp(a.values, b.values, (size_t)a.count * es) == 0);
+    };
+    // 1. twin layers: same type and parameters, byte-identical weights, input i of the right one is the twin of input i of the left one
+    std::vector<int> twin_t(tensors_.size(), -1), twin_l(layers_.size(), -1);
+    std::vector<char> is_right(layers_.size(), 0);
+    twin_t[ins[0]] = ins[1];
+    auto same_layer = [&](const LayerData& a, const LayerData& b) {
+        if (a.type != b.type || a.in.size() != b.in.size() || a.out.size() != b.out.size()) return false;
+        for (size_t i = 0; i < a.in.size(); i++)
+            if (twin_t[a.in[i]->id] != b.in[i]->id) return false;
+        for (size_t i = 0; i < a.out.size(); i++)
+            if (!same_dims(a.out[i]->dims, b.out[i]->dims)) return false;
+        switch (a.type) {
+            case LayerType::kCONVOLUTION:
+            case LayerType::kDECONVOLUTION:
+                return a.nb_maps == b.nb_maps && a.ksize.h() == b.ksize.h() && a.ksize.w() == b.ksize.w() && a.stride.h() == b.stride.h() &&
+                       a.stride.w() == b.stride.w() && a.padding.h() == b.padding.h() && a.padding.w() == b.padding.w() &&
+                       same_weights(a.kernel, b.kernel) && same_weights(a.bias, b.bias);
+            case LayerType::kSCALE: return isIdentityScale(a) && isIdentityScale(b);
+            case LayerType::kELEMENTWISE: return a.ew == b.ew;
+            case LayerType::kACTIVATION: return a.act == b.act;
+            case LayerType::kPLUGIN: {
+                IStereoPlugin *pa = a.plugin ? dynamic_cast<IStereoPlugin*>(a.plugin) : nullptr, *pb = b.plugin ? dynamic_cast<IStereoPlugin*>(b.plugin) : nullptr;
+                return pa && pb && pa->kind() == Kind::kElu && pb->kind() == Kind::kElu;
+            }
+            default: return false;
+        }
+    };
+    for (size_t ia = 0; ia < layers_.size(); ia++) {
+        const LayerData& a = *layers_[ia];
+        if (is_right[ia] || a.in.empty()) continue;
+        bool have = true;
+        for (auto* t : a.in) have = have && twin_t[t->id] >= 0;
+        if (!have) continue;
+        for (size_t ib = 0; ib < layers_.size(); ib++) {
+            if (ib == ia || is_right[ib] || twin_l[ib] >= 0 || !same_layer(a, *layers_[ib])) continue;
+            twin_l[ia] = (int)ib;
+            is_right[ib] = 1;
+            for (size_t i = 0; i < a.out.size(); i++) twin_t[a.out[i]->id] = layers_[ib]->out[i]->id;
+            break;
+        }
+    }
+    // 2. tensor pairs that can share a buffer [left samples | right samples]
+    auto plain = [&](const TensorImpl& t) { return !t.is_input && !t.is_output && t.alias_of < 0 && t.bstride == 0 && t.twin_of < 0 && !t.has_twin; };
+    auto pairable = [&](int l, int r) {
+        if (l < 0 || r < 0 || l == r) return false;
+        const TensorImpl &a = *tensors_[l], &b = *tensors_[r];
+        return plain(a) && plain(b) && same_dims(a.dims, b.dims) && a.pitch == b.pitch && a.f16 == b.f16 && a.il8 == b.il8;
+    };
+    // 3. op pairs: convolution plans covering twin layers, all of whose tensors pair up
+    int merged = 0;
+    for (size_t ia = 0; ia < ops_.size(); ia++) {
+        Op& a = ops_[ia];
+        if (a.kind != OpKind::kConv || a.twin || a.in.size() != 1 || a.lays.empty() || twin_l[a.lays[0]] < 0) continue;
+        int ib = -1;
+        for (size_t j = 0; j < ops_.size() && ib < 0; j++) {
+            const Op& b = ops_[j];
+            if (j == ia || b.kind != OpKind::kConv || b.twin || b.lays.size() != a.lays.size() || b.in.size() != 1 || b.act != a.act) continue;
+            bool eq = true;
+            for (size_t k = 0; k < a.lays.size(); k++) eq = eq && twin_l[a.lays[k]] == b.lays[k];
+            if (eq) ib = (int)j;
+        }
+        if (ib < 0) continue;
+        const Op& b = ops_[ib];
+        // the tensors as the ops see them (a tensor the op reads through an alias chain must be the plain buffer itself)
+        if (root(a.in[0]) != a.in[0] || root(b.in[0]) != b.in[0] || root(a.out) != a.out || root(b.out) != b.out) continue;
+        if ((a.resid >= 0) != (b.resid >= 0) || (a.resid >= 0 && (root(a.resid) != a.resid || root(b.resid) != b.resid))) continue;
+        auto ok_pair = [&](int l, int r) {       // already placed together, or can be
+            return l >= 0 && r >= 0 && ((tensors_[r]->twin_of == l && tensors_[l]->has_twin) || pairable(l, r));
+        };
+        if (!ok_pair(a.in[0], b.in[0]) || !ok_pair(a.out, b.out) || (a.resid >= 0 && !ok_pair(a.resid, b.resid))) continue;
+        auto place = [&](int l, int r) {
+            tensors_[r]->twin_of = l;
+            tensors_[l]->has_twin = true;
+        };
+        place(a.in[0], b.in[0]);
+        place(a.out, b.out);
+        if (a.resid >= 0) place(a.resid, b.resid);
+        a.twin = true;
+        a.twin_in.push_back(b.in[0]);
+        if (b.resid >= 0) a.twin_in.push_back(b.resid);
+        a.twin_out = b.out;
+        a.name += " | " + b.name;
+        rt_conv_plan_destroy(b.plan);
+        ops_.erase(ops_.begin() + ib);
+        if ((size_t)ib < ia) ia--;
+        merged++;
+    }
+    if (!merged) return;
+    // 4. a merged launch needs the right tower's earlier (unmerged) launches before it: stable topological order by buffer
+    {
+        const size_t n = ops_.size();
+        // tensors as the ops name them; two tensors are the same data when one is reached from the other along alias_of (a channel
+        // range of a folded concatenation and the whole buffer; an identity scale and its input) -- siblings of a concatenation are not
+        auto reads = [&](const Op& op) {
+            std::vector<int> r(op.in);
+            if (op.resid >= 0) r.push_back(op.resid);
+            r.insert(r.end(), op.twin_in.begin(), op.twin_in.end());
+            return r;
+        };
+        auto writes = [&](const Op& op) {
+            std::vector<int> w{op.out};
+            if (op.twin_out >= 0) w.push_back(op.twin_out);
+            return w;
+        };
+        auto above = [&](int a, int b) {         // a == b or a is reached from b along alias_of
+            for (int t = b; t >= 0; t = tensors_[t]->alias_of)
+                if (t == a) return true;
+            return false;
+        };
+        auto same_data = [&](int a, int b) { return above(a, b) || above(b, a); };
+        std::vector<std::vector<int>> rd(n), wr(n);
+        for (size_t i = 0; i < n; i++) { rd[i] = reads(ops_[i]); wr[i] = writes(ops_[i]); }
+        std::vector<char> placed(n, 0);
+        std::vector<Op> sorted;
+        for (size_t done = 0; done < n; done++) {
+            size_t pick = n;
+            for (size_t i = 0; i < n && pick == n; i++) {
+                if (placed[i]) continue;
+                bool ready = true;
+                for (size_t j = 0; j < n && ready; j++) {
+                    if (j == i || placed[j]) continue;
+                    for (int w : wr[j])
+                        for (int r : rd[i]) ready = ready && !same_data(w, r);
+                }
+                if (ready) pick = i;
+            }
+            if (pick == n) {        // a cycle cannot happen in a feed-forward graph; keep the original order if it does
+                log_.log(ILogger::Severity::kERROR, "engine: siamese merge produced a dependency cycle");
+                ok_ = false;
+                return;
+            }
+            placed[pick] = 1;
+            sorted.push_back(ops_[pick]);
+        }
+        ops_ = std::move(sorted);
+    }
+    log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(merged) + " left / right tower launches merged into one launch over both images each; " +
+                                        std::to_string(ops_.size()) + " launches").c_str());
 }
 
 // The default cost volume is never built (reference CostVolumePlugin kDefault, lib/kernels.cu:50-97: a (D, 2F, H, W) tensor
@@ -1322,7 +1525,7 @@ bool ContextImpl::ensureBuffers(int batch) {
         b = nullptr;
     }
     for (auto& t : eng_.tensors_) {
-        if (t->is_input || t->is_output || t->alias_of >= 0) continue;
+        if (t->is_input || t->is_output || t->alias_of >= 0 || t->twin_of >= 0) continue;     // a right-tower twin lives in its left twin's buffer
         bool used = false;
         for (auto& op : eng_.ops_) {
             used |= op.out == t->id || op.resid == t->id;
@@ -1330,7 +1533,7 @@ bool ContextImpl::ensureBuffers(int batch) {
         }
         if (!used) continue;
         const size_t elems = t->pitch ? (size_t)t->dims.d[0] * t->dims.d[1] * t->pitch : (size_t)volume(t->dims);
-        if (rt_malloc(&buffers_[t->id], elems * (t->f16 ? 2 : 4) * (size_t)batch) != 0) {
+        if (rt_malloc(&buffers_[t->id], elems * (t->f16 ? 2 : 4) * (size_t)batch * (t->has_twin ? 2 : 1)) != 0) {
             eng_.log_.log(ILogger::Severity::kERROR, (std::string("engine: device allocation failed: ") + rt_last_error_string()).c_str());
             return false;
         }
@@ -1343,10 +1546,15 @@ bool ContextImpl::ensureBuffers(int batch) {
     return true;
 }
 
-void* ContextImpl::addr(int tensor, int, void** bindings) const {
+void* ContextImpl::addr(int tensor, int batch, void** bindings) const {
     int t = tensor;
     int64_t off = 0;                   // element offset inside the buffer it aliases (folded concatenation)
     while (eng_.tensors_[t]->alias_of >= 0) { off += eng_.tensors_[t]->alias_off; t = eng_.tensors_[t]->alias_of; }
+    if (eng_.tensors_[t]->twin_of >= 0) {      // right-tower twin: `batch` samples behind the left tensor's first sample
+        const TensorImpl& r = *eng_.tensors_[t];
+        off += (int64_t)batch * (r.pitch ? (int64_t)r.dims.d[0] * r.dims.d[1] * r.pitch : (int64_t)volume(r.dims));
+        t = r.twin_of;
+    }
     const TensorImpl& ti = *eng_.tensors_[t];
     if (ti.is_input || ti.is_output) {
         for (size_t b = 0; b < eng_.bindings_.size(); b++)
@@ -1412,15 +1620,22 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         const Op& op = eng_.ops_[op_index];
         rtStream st = (two && op.stream == 1) ? side_stream_ : main;
         if (two)
-            for (int w : op.wait_on)
-                if (events_[w]) rt_stream_wait_event(st, events_[w]);
+            for (int w : op.wait_on) {
+                if (!events_[w]) {          // the producer on the other stream must have been issued (and its event recorded) before
+                    log.log(ILogger::Severity::kERROR, (op.name + ": cross-stream input '" + eng_.tensors_[w]->name + "' has no recorded event").c_str());
+                    return false;
+                }
+                rt_stream_wait_event(st, events_[w]);
+            }
         if (profile) rt_event_record(prof_events_[2 * op_index], st);
         const TensorImpl& out = *eng_.tensors_[op.out];
         void* y = addr(op.out, batch, bindings);
         int rc = 0;
         switch (op.kind) {
             case OpKind::kConv:
-                rc = rt_conv_enqueue(op.plan, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr, batch, st);
+                // a merged siamese launch covers the left samples and, right behind them, the right samples
+                rc = rt_conv_enqueue_hint(op.plan, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,
+                                          op.twin ? 2 * batch : batch, st, streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
                 break;
             case OpKind::kConv3D:
                 rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y,
@@ -1494,6 +1709,12 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             while (eng_.tensors_[r]->alias_of >= 0) r = eng_.tensors_[r]->alias_of;
             if (!events_[r]) order_event(&events_[r]);
             rt_event_record(events_[r], st);
+            if (op.twin_out >= 0) {
+                int r2 = op.twin_out;
+                while (eng_.tensors_[r2]->alias_of >= 0) r2 = eng_.tensors_[r2]->alias_of;
+                if (!events_[r2]) order_event(&events_[r2]);
+                rt_event_record(events_[r2], st);
+            }
         }
         if (debug_sync_) rt_stream_sync(st);
     }

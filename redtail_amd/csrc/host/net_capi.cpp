@@ -166,6 +166,40 @@ extern "C" int rt_net_create_from_memory(rtStereoNet** net, int model, int width
     return build(net, model, width, height, max_batch, dtype, max_disp, std::move(copy));
 }
 
+// Multi-GPU start-up (include/rt_stereo_net.h): the weight image travels root -> everyone over RCCL, then every rank builds its engine.
+extern "C" int rt_net_create_broadcast(rtStereoNet** net, int model, int width, int height, int max_batch, int dtype, int max_disp,
+                                       const void* blob, size_t bytes, rtComm* comm, int root) {
+    int world = 1, rank = 0;
+    if (comm && rt_comm_info(comm, &world, &rank) != 0) return fail(std::string("rt_net_create_broadcast: ") + rt_last_error_string());
+    if (root < 0 || root >= world) return fail("rt_net_create_broadcast: root is not a rank of the communicator");
+    if (rank == root && (!blob || !bytes)) return fail("rt_net_create_broadcast: the root rank has no weight image");
+    uint64_t n = rank == root ? (uint64_t)bytes : 0;
+    if (comm && rt_comm_broadcast(comm, &n, sizeof(n), root, nullptr) != 0) return fail(std::string("rt_net_create_broadcast: ") + rt_last_error_string());
+    if (n == 0 || n > ((uint64_t)1 << 32)) return fail("rt_net_create_broadcast: implausible weight image size received");
+    std::vector<char> image((size_t)n);
+    if (rank == root) memcpy(image.data(), blob, (size_t)n);
+    if (comm && rt_comm_broadcast(comm, image.data(), (size_t)n, root, nullptr) != 0) return fail(std::string("rt_net_create_broadcast: ") + rt_last_error_string());
+    return build(net, model, width, height, max_batch, dtype, max_disp, std::move(image));
+}
+
+extern "C" int rt_net_weights_crc32(const rtStereoNet* net, uint32_t* crc) {
+    if (!net || !crc) return fail("rt_net_weights_crc32: null pointer");
+    uint32_t c = 0xffffffffu;
+    for (unsigned char b : net->blob) {
+        c ^= b;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+    }
+    *crc = c ^ 0xffffffffu;
+    return 0;
+}
+
+extern "C" int rt_net_weights_image(const rtStereoNet* net, const void** data, size_t* bytes) {
+    if (!net || !data || !bytes) return fail("rt_net_weights_image: null pointer");
+    *data = net->blob.data();
+    *bytes = net->blob.size();
+    return 0;
+}
+
 // Engine plan = what ICudaEngine::serialize() returns (sample_app/main.cpp:269-275 caches it in a .plan file).
 // Call with buf == NULL to query the size.  Networks with non-serialisable plugins (the 3-D models) have no plan,
 // exactly as in the reference.

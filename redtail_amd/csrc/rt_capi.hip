@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_stereo.h"
@@ -479,7 +480,7 @@ struct rtConvPlan {
     std::vector<SubConv> subs;
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
-    mutable bool env_read = false;
+    mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
     mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
@@ -1647,6 +1648,11 @@ extern "C" int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]) {
 
 extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                                rtStream s) {
+    return rt_conv_enqueue_hint(plan, x, y, residual, batch, s, 0);
+}
+
+extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
+                                    rtStream s, int hints) {
     RT_REQUIRE(plan && x && y, "rt_conv_enqueue: null pointer");
     RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
     RT_REQUIRE(!plan->has_resid || residual || plan->rb_w1_dev, "rt_conv_enqueue: plan expects a residual tensor");
@@ -1681,12 +1687,11 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
             RT_LAUNCH_CHECK("deconv3d_s2_small_kernel");
             continue;
         }
-        if (!plan->env_read) {
+        std::call_once(plan->env_once, [&] {        // execution contexts of one engine share the plan and may launch it from different threads
             plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
             plan->opt_rb_tiles = env_int("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0);
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
-            plan->env_read = true;
-        }
+        });
         rt::ConvArgs a;
         a.x = static_cast<const float*>(x);
         a.y = static_cast<float*>(y);
@@ -1767,8 +1772,12 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
                 // cost fewer CU-cycles per row; shorter ones fill more CUs of an otherwise idle GPU (RT_RBS_SEG, default: see DESIGN.md 4.4)
                 // Measured in the running network (ResNet-18 2D, 1257x369, four contexts): 16 rows 2129, 24: 2178, 32: 2185, 48: 2067,
                 // 64: 1957 pairs/s (two launches of the layer-by-layer kernels: 2057); alone 16 rows are fastest (24.5 vs 32.4 us).
+                // Round 3, siamese batch-2 launches, six one-stream contexts: 32 rows 2315, 48: 2432, 64: 2457-2539, 96: 2441, 128: 2305 pairs/s;
+                // one context, synchronous execute(): 32 rows 0.60 ms per pair, 64: 0.74-0.76 ms.  So: throughput hint -> 64 rows while
+                // that leaves >= 120 workgroups; otherwise 32 rows while that leaves >= 120; otherwise 16.
                 int seg = plan->opt_rbs_seg;
-                if (seg <= 0) seg = ra.c.tiles_x * (int)rt::cdiv(sc.Ho, 32) * batch >= 120 ? 32 : rt::S3RBSCfg::SEG;
+                const auto wgs = [&](int rows) { return ra.c.tiles_x * (int)rt::cdiv(sc.Ho, rows) * batch; };
+                if (seg <= 0) seg = ((hints & RT_HINT_THROUGHPUT) && wgs(64) >= 120) ? 64 : (wgs(32) >= 120 ? 32 : rt::S3RBSCfg::SEG);
                 seg = seg < 4 ? 4 : (seg > 240 ? 240 : (seg + 3) / 4 * 4);
                 ra.seg = seg;
                 dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, seg)), 1u, (unsigned)batch);
@@ -1883,5 +1892,196 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
 
 extern "C" int rt_conv_plan_destroy(rtConvPlan* plan) {
     free_plan(plan);
+    return 0;
+}
+
+// ---- multi-GPU: RCCL communicator + byte broadcast (include/rt_stereo.h) ------------------------------------------------------
+struct rtComm {
+    void* nccl = nullptr;      // ncclComm_t
+    bool owned = false;
+    int world = 1, rank = 0, device = 0;
+};
+
+#ifndef HIPEMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// librccl is loaded on first use: a single-GPU process never maps it
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+#define RT_RCCL_SYM(n) api.n = reinterpret_cast<decltype(api.n)>(dlsym(api.lib, "nccl" #n))
+        RT_RCCL_SYM(GetUniqueId); RT_RCCL_SYM(CommInitRank); RT_RCCL_SYM(CommInitAll); RT_RCCL_SYM(CommDestroy); RT_RCCL_SYM(CommCount);
+        RT_RCCL_SYM(CommUserRank); RT_RCCL_SYM(CommCuDevice); RT_RCCL_SYM(Broadcast); RT_RCCL_SYM(GroupStart); RT_RCCL_SYM(GroupEnd);
+        RT_RCCL_SYM(GetErrorString);
+#undef RT_RCCL_SYM
+    });
+    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.CommCount && api.CommUserRank &&
+                    api.CommCuDevice && api.Broadcast && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    return ok ? &api : nullptr;
+}
+#define RT_RCCL(api, call, what)                                                                          \
+    do {                                                                                                  \
+        ncclResult_t r_ = (call);                                                                         \
+        if (r_ != ncclSuccess) return fail(RT_E_RUNTIME, "%s: RCCL: %s", what, (api)->GetErrorString(r_)); \
+    } while (0)
+#define RT_NEED_RCCL(api, what)   \
+    RcclApi* api = rccl();        \
+    if (!api) return fail(RT_E_UNSUPPORTED, "%s: librccl.so could not be loaded (%s)", what, dlerror() ? dlerror() : "symbols missing")
+}  // namespace
+
+extern "C" int rt_comm_unique_id(void* id_bytes) {
+    RT_REQUIRE(id_bytes, "rt_comm_unique_id: null pointer");
+    RT_NEED_RCCL(api, "rt_comm_unique_id");
+    ncclUniqueId id;
+    RT_RCCL(api, api->GetUniqueId(&id), "rt_comm_unique_id");
+    static_assert(sizeof(id) == RT_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return 0;
+}
+
+static int fill_comm(RcclApi* api, rtComm* c) {
+    RT_RCCL(api, api->CommCount(static_cast<ncclComm_t>(c->nccl), &c->world), "rt_comm");
+    RT_RCCL(api, api->CommUserRank(static_cast<ncclComm_t>(c->nccl), &c->rank), "rt_comm");
+    RT_RCCL(api, api->CommCuDevice(static_cast<ncclComm_t>(c->nccl), &c->device), "rt_comm");
+    return 0;
+}
+
+extern "C" int rt_comm_init_rank(rtComm** comm, int world, int rank, const void* id_bytes) {
+    RT_REQUIRE(comm && id_bytes && world >= 1 && rank >= 0 && rank < world, "rt_comm_init_rank: bad arguments");
+    RT_NEED_RCCL(api, "rt_comm_init_rank");
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    ncclComm_t c = nullptr;
+    RT_RCCL(api, api->CommInitRank(&c, world, id, rank), "rt_comm_init_rank");
+    auto* out = new rtComm();
+    out->nccl = c; out->owned = true;
+    if (int rc = fill_comm(api, out)) { api->CommDestroy(c); delete out; return rc; }
+    *comm = out;
+    return 0;
+}
+
+extern "C" int rt_comm_init_all(rtComm** comms, int ndev, const int* devices) {
+    RT_REQUIRE(comms && ndev >= 1 && ndev <= 64, "rt_comm_init_all: bad arguments");
+    RT_NEED_RCCL(api, "rt_comm_init_all");
+    std::vector<ncclComm_t> c((size_t)ndev, nullptr);
+    RT_RCCL(api, api->CommInitAll(c.data(), ndev, devices), "rt_comm_init_all");
+    for (int i = 0; i < ndev; i++) {
+        comms[i] = new rtComm();
+        comms[i]->nccl = c[i]; comms[i]->owned = true;
+        if (int rc = fill_comm(api, comms[i])) return rc;
+    }
+    return 0;
+}
+
+extern "C" int rt_comm_adopt(rtComm** comm, void* nccl_comm) {
+    RT_REQUIRE(comm && nccl_comm, "rt_comm_adopt: null pointer");
+    RT_NEED_RCCL(api, "rt_comm_adopt");
+    auto* out = new rtComm();
+    out->nccl = nccl_comm; out->owned = false;
+    if (int rc = fill_comm(api, out)) { delete out; return rc; }
+    *comm = out;
+    return 0;
+}
+
+extern "C" int rt_comm_broadcast(rtComm* comm, void* host_buf, size_t bytes, int root, rtStream s) {
+    RT_REQUIRE(comm && (host_buf || !bytes) && root >= 0 && root < comm->world, "rt_comm_broadcast: bad arguments");
+    if (!bytes) return 0;
+    RT_NEED_RCCL(api, "rt_comm_broadcast");
+    int prev = 0;
+    RT_HIP(hipGetDevice(&prev));
+    RT_HIP(hipSetDevice(comm->device));
+    void* dev = nullptr;
+    RT_HIP(hipMalloc(&dev, bytes));
+    int rc = 0;
+    if (comm->rank == root && hipMemcpyAsync(dev, host_buf, bytes, hipMemcpyHostToDevice, S(s)) != hipSuccess) rc = fail(RT_E_RUNTIME, "rt_comm_broadcast: upload failed");
+    if (!rc) {
+        ncclResult_t r = api->Broadcast(dev, dev, bytes, ncclUint8, root, static_cast<ncclComm_t>(comm->nccl), S(s));
+        if (r != ncclSuccess) rc = fail(RT_E_RUNTIME, "rt_comm_broadcast: RCCL: %s", api->GetErrorString(r));
+    }
+    if (!rc && comm->rank != root && hipMemcpyAsync(host_buf, dev, bytes, hipMemcpyDeviceToHost, S(s)) != hipSuccess) rc = fail(RT_E_RUNTIME, "rt_comm_broadcast: download failed");
+    if (hipStreamSynchronize(S(s)) != hipSuccess && !rc) rc = fail(RT_E_RUNTIME, "rt_comm_broadcast: stream synchronisation failed");
+    (void)hipFree(dev);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int rt_comm_group_start(void) {
+    RT_NEED_RCCL(api, "rt_comm_group_start");
+    RT_RCCL(api, api->GroupStart(), "rt_comm_group_start");
+    return 0;
+}
+
+extern "C" int rt_comm_group_end(void) {
+    RT_NEED_RCCL(api, "rt_comm_group_end");
+    RT_RCCL(api, api->GroupEnd(), "rt_comm_group_end");
+    return 0;
+}
+
+extern "C" int rt_comm_destroy(rtComm* comm) {
+    if (!comm) return 0;
+    int rc = 0;
+    if (comm->owned && comm->nccl) {
+        RcclApi* api = rccl();
+        if (api && api->CommDestroy(static_cast<ncclComm_t>(comm->nccl)) != ncclSuccess) rc = fail(RT_E_RUNTIME, "rt_comm_destroy: RCCL error");
+    }
+    delete comm;
+    return rc;
+}
+#else
+// SIMT-emulator build (CPU test tier): a world of one rank, so that the host-side flow (rt_net_create_broadcast) runs without RCCL
+extern "C" int rt_comm_unique_id(void* id_bytes) {
+    RT_REQUIRE(id_bytes, "rt_comm_unique_id: null pointer");
+    std::memset(id_bytes, 0x5a, RT_COMM_ID_BYTES);
+    return 0;
+}
+extern "C" int rt_comm_init_rank(rtComm** comm, int world, int rank, const void* id_bytes) {
+    RT_REQUIRE(comm && id_bytes && world == 1 && rank == 0, "rt_comm_init_rank: the emulator build has no RCCL (world size 1 only)");
+    *comm = new rtComm();
+    (*comm)->owned = true;
+    return 0;
+}
+extern "C" int rt_comm_init_all(rtComm** comms, int ndev, const int*) {
+    RT_REQUIRE(comms && ndev == 1, "rt_comm_init_all: the emulator build has no RCCL (one device only)");
+    comms[0] = new rtComm();
+    comms[0]->owned = true;
+    return 0;
+}
+extern "C" int rt_comm_adopt(rtComm**, void*) { return fail(RT_E_UNSUPPORTED, "rt_comm_adopt: the emulator build has no RCCL"); }
+extern "C" int rt_comm_broadcast(rtComm* comm, void* host_buf, size_t bytes, int root, rtStream) {
+    RT_REQUIRE(comm && (host_buf || !bytes) && root == 0, "rt_comm_broadcast: bad arguments");
+    return 0;
+}
+extern "C" int rt_comm_group_start(void) { return 0; }
+extern "C" int rt_comm_group_end(void) { return 0; }
+extern "C" int rt_comm_destroy(rtComm* comm) { delete comm; return 0; }
+#endif
+
+extern "C" int rt_comm_info(const rtComm* comm, int* world, int* rank) {
+    RT_REQUIRE(comm, "rt_comm_info: null pointer");
+    if (world) *world = comm->world;
+    if (rank) *rank = comm->rank;
     return 0;
 }

@@ -20,3 +20,29 @@ def shard(n_items, rank, world):
     base, extra = divmod(n_items, world)
     start = rank * base + min(rank, extra)
     return range(start, start + base + (1 if rank < extra else 0))
+
+
+def native_comm(lib, rank, world, dist=None):
+    """An RCCL communicator of our own through the C ABI (include/rt_stereo.h: rt_comm_unique_id / rt_comm_init_rank) -- what a host
+    without torch does.  The 128-byte unique id travels from rank 0 to the others through `dist` (any initialised torch.distributed
+    backend; its store, not a data path).  Call after rt_set_device."""
+    uid = [lib.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    return lib.comm_init_rank(world, rank, uid[0])
+
+
+def create_nets_native(lib, model, width, height, n_contexts, blob, rank, world, dist=None, max_batch=1, fp16_weights=False, max_disp=0):
+    """bench.py's multi-GPU start-up on the native entry: rank 0 passes the weight-file image, rt_net_create_broadcast ships it over
+    RCCL (ncclBroadcast) and builds the first engine of every rank; the rank's other contexts are built from the image that arrived.
+    Returns (nets, crc32 of the image on this rank)."""
+    comm = native_comm(lib, rank, world, dist)
+    try:
+        first = lib.create_broadcast(model, width, height, comm, 0, max_batch=max_batch, blob=blob if rank == 0 else None,
+                                     fp16_weights=fp16_weights, max_disp=max_disp)
+    finally:
+        lib.comm_destroy(comm)
+    image = first.weights_image()
+    nets = [first] + [lib.create(model, width, height, max_batch=max_batch, weights=image, fp16_weights=fp16_weights, max_disp=max_disp)
+                      for _ in range(n_contexts - 1)]
+    return nets, first.weights_crc32()

@@ -94,7 +94,7 @@ def pad1(backend, x):
 def test_conv3d_01_basic(backend, golden):                       # tests_main.cpp:362-389
     g = golden
     y = conv3d_run(backend, g["conv3d_01_x"], g["conv3d_01_w"], None, (1, 1, 1), (0, 0, 0), (0, 0, 0))
-    float_eq(transform(backend, y), g["conv3d_01_y"], ulps=16)
+    float_eq(transform(backend, y), g["conv3d_01_y"], ulps=4)           # EXPECT_FLOAT_EQ (tests_main.cpp:388); measured: oracle 1 ULP from the golden value
 
 
 def test_conv3d_02_hw_strides(backend, golden):                  # :391-420

@@ -68,7 +68,100 @@ def test_two_rank_broadcast_and_sharding(tmp_path):
     assert np.abs(out - ref).max() <= 1e-3
 
 
+def test_native_broadcast_entry_world_of_one_on_emulator():
+    """rt_comm_* / rt_net_create_broadcast / rt_net_weights_crc32 / rt_net_weights_image through ctypes on the emulator build (which has no
+    RCCL: a world of one rank): same engine, same crc32 as zlib, and the image comes back byte for byte"""
+    import zlib
+    from oracle import stereo_oracle as O
+    from redtail_amd import build, capi, synth
+    lib = capi.NetLib(build.build_host_emu(), build.build_emu())
+    weights = synth.synth_weights_resnet18_2d()
+    blob = capi.pack_weights(weights)
+    nets, crc = parallel.create_nets_native(lib, "resnet18_2D", 33, 17, 2, blob, 0, 1, max_disp=6)
+    assert crc == zlib.crc32(blob) & 0xffffffff
+    assert nets[0].weights_image() == blob
+    l, r = synth.synth_pair(17, 33, 7)
+    outs = []
+    for net in nets:
+        o = np.full((1, 1, 17, 33), np.nan, np.float32)
+        net.execute(l[None].copy(), r[None].copy(), o, 1)
+        outs.append(o)
+        net.destroy()
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l)[None], torch.from_numpy(r)[None], weights, max_disp=6).numpy()
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0] - ref).max() <= 1e-3
+    with pytest.raises(capi.RtError):
+        lib.comm_init_rank(2, 0, b"\0" * 128)            # the emulator build refuses a world it cannot serve
+
+
 # ---- GPU tier: the same code over RCCL (torch.distributed backend "nccl") ------------------------------------------------
+def _native_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # only carries the 128-byte unique id
+    from redtail_amd import capi, model_files, synth
+    lib = capi.NetLib()
+    lib.kernels.check(lib.kernels.lib.rt_set_device(rank), "rt_set_device")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    blob = open(model_files.weight_file("resnet18_2D"), "rb").read() if rank == 0 else None
+    w, h = 257, 129
+    nets, crc = parallel.create_nets_native(lib, "resnet18_2D", w, h, 2, blob, rank, world, dist)
+    l, r = synth.synth_pair(h, w, 1234 + rank)
+    out = torch.full((1, 1, h, w), float("nan"), device=dev)
+    nets[1].execute(torch.from_numpy(l)[None].to(dev), torch.from_numpy(r)[None].to(dev), out, 1)
+    torch.cuda.synchronize(dev)
+    np.save(os.path.join(tmp, "nout%d.npy" % rank), out.cpu().numpy())
+    np.save(os.path.join(tmp, "ncrc%d.npy" % rank), np.array([crc]))
+    for n in nets:
+        n.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_native_rccl_entry(tmp_path, world):
+    """The native multi-GPU entry (no torch in the data or weight path): rt_comm_unique_id -> rt_comm_init_rank (ncclCommInitRank) ->
+    rt_net_create_broadcast (ncclBroadcast of the image) on every rank; crc32 of what arrived == the file's; each rank's second context,
+    built from the received image, matches the oracle on the rank's own pair.  World 2 when two devices are visible."""
+    import zlib
+    from oracle import stereo_oracle as O
+    from redtail_amd import capi, model_files, synth
+    if torch.cuda.device_count() < world:
+        pytest.skip("%d visible device(s)" % torch.cuda.device_count())
+    mp.spawn(_native_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    path = model_files.weight_file("resnet18_2D")
+    want = zlib.crc32(open(path, "rb").read()) & 0xffffffff
+    weights = capi.read_weights(path)
+    for rank in range(world):
+        assert int(np.load(tmp_path / ("ncrc%d.npy" % rank))[0]) == want
+        l, r = synth.synth_pair(129, 257, 1234 + rank)
+        with torch.no_grad():
+            ref = O.resnet18_2d(torch.from_numpy(l)[None], torch.from_numpy(r)[None], weights).numpy()
+        assert np.abs(np.load(tmp_path / ("nout%d.npy" % rank)) - ref).max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_native_throughput_app():
+    """apps/stereo_throughput.cpp (one thread per device, rt_comm_init_all + rt_net_create_broadcast) on every visible device"""
+    import json
+    import subprocess
+    import zlib
+    from redtail_amd import model_files
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    app = os.path.join(ROOT, "redtail_amd", "lib", "stereo_throughput")
+    assert os.path.exists(app), "redtail_amd/lib/stereo_throughput not built (__graft_entry__.build())"
+    path = model_files.weight_file("resnet18_2D")
+    res = subprocess.run([app, "resnet18_2D", "513", "257", path, "--pairs", "48", "--contexts", "3", "--warmup", "6"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == torch.cuda.device_count() and line["value"] > 0
+    assert line["weights_crc32"] == "%08x" % (zlib.crc32(open(path, "rb").read()) & 0xffffffff)
+    assert all(r["weights_crc32"] == line["weights_crc32"] for r in line["ranks"])
+
+
+
 def _rccl_worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -86,16 +86,56 @@ def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
     w = O.synth_weights_resnet18_2d()
     l, r = pairs(2, 41, 73)
     base, (_, launches0) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
+    assert launches0 == 48 - 15                            # siamese merge: 14 block convolutions + encoder2D_out of the two towers pair up
     monkeypatch.setenv("RT_RB", "1")
     for seg in ("16", "32"):
         monkeypatch.setenv("RT_RBS_SEG", seg)
         out, (layers, launches) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-        assert launches == launches0 - 16                  # 16 blocks, two launches -> one
+        assert launches == 48 - 16 - 8                     # 16 blocks, two launches -> one; blocks 2-8 + encoder2D_out: two towers -> one
         assert not np.isnan(out).any()
         assert np.abs(out - base).max() <= 2e-5, np.abs(out - base).max()
     with torch.no_grad():
         ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w, max_disp=8).numpy()
     assert np.abs(out - ref).max() <= 2e-4
+
+
+def test_resnet18_2d_siamese_merge_is_bit_identical(rt, monkeypatch):
+    """The two feature towers share their weights (left_* == right_* in the reference's weight files): launches of twin layers whose
+    tensors are plain internal buffers run as ONE launch over [left samples | right samples] (EngineImpl::mergeSiamese).  Same bits
+    as the separate launches (RT_NO_SIAMESE=1), batch 1 and a batch below maxBatchSize, layer by layer and with fused blocks;
+    towers whose weights differ are not merged."""
+    w = O.synth_weights_resnet18_2d()
+    for n, maxb, env in ((1, 1, {}), (2, 3, {}), (2, 2, {"RT_RB": "1", "RT_RBS_SEG": "16"})):
+        l, r = pairs(n, 41, 73)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs, counts = [], []
+        for siamese in (True, False):
+            if siamese:
+                monkeypatch.delenv("RT_NO_SIAMESE", raising=False)
+            else:
+                monkeypatch.setenv("RT_NO_SIAMESE", "1")
+            net = rt.lib.create("resnet18_2D", 73, 41, max_batch=maxb, weights=w, max_disp=8)
+            out = rt.empty(n, 1, 41, 73)
+            net.execute(rt.dev(l), rt.dev(r), out, n)
+            outs.append(np.array(rt.host(out)))
+            counts.append(net.num_launches)
+            net.destroy()
+        monkeypatch.delenv("RT_NO_SIAMESE", raising=False)
+        assert counts[0] < counts[1], counts
+        assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+    # different weights on the two sides: nothing may be merged
+    w2 = dict(w)
+    k = "right_resblock3_conv1_k"
+    w2[k] = (np.asarray(w[k]) * 1.5).astype(np.float32)
+    l, r = pairs(1, 25, 41)
+    out, (_, launches) = run_net(rt, "resnet18_2D", w2, l, r, max_disp=8)
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w2, max_disp=8).numpy()
+    assert np.abs(out - ref).max() <= 2e-4
+    assert launches == 48 - 2                              # only block 2 (before the differing layer) pairs up: twins need twin inputs
 
 
 def test_resnet18_2d_one_stream_per_context(rt):
@@ -269,8 +309,10 @@ def test_resnet18_2d_full_size(w, h, batch):
     err = (out.cpu() - ref).abs().max().item()
     print("ResNet-18 2D %dx%d batch %d, real weights: max |disp - oracle| = %.3g, %d launches" % (w, h, batch, err, net.num_launches))
     assert err <= 1e-3, err
-    # at 1257x369 the executor runs 15 of the 16 residual blocks as one (streaming) launch each; at 513x257 none (too few strips)
-    assert net.num_launches == (33 if w >= 1241 else 48), net.num_launches
+    # at 1257x369 the executor runs 15 of the 16 residual blocks as one (streaming) launch each (48 -> 33) and blocks 2-8 + encoder2D_out of
+    # the two towers as one launch over both images (siamese merge: 33 -> 25); at 513x257 no block is fused (too few strips) and the 14
+    # block convolutions + encoder2D_out pair up (48 -> 33)
+    assert net.num_launches == (25 if w >= 1241 else 33), net.num_launches
     net.destroy()
 
 
@@ -362,9 +404,9 @@ def test_resnet18_2d_interleaved_contexts():
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,cfg,w,h,disp,tol", [("nvsmall", "NVSMALL_3D", 257, 129, 16, 1e-3), ("resnet18", "RESNET18_3D", 257, 129, 12, 1e-3),
                                                     ("nvsmall", "NVSMALL_3D", 1025, 321, 48, 1e-3),
-                                                    # 30 layers deep, disparities up to 136 px: the fp32 oracle itself is 2.2e-3 px away from an fp64
-                                                    # evaluation of the same graph, the GPU 2.4e-3 (direct form 3.5e-3) -- tools/precision_probe.py
-                                                    ("resnet18", "RESNET18_3D", 1025, 321, 68, 5e-3)])
+                                                    # 30 layers deep, disparities up to 136 px: fp32 roundoff alone exceeds 1e-3 px -- the test evaluates
+                                                    # the graph in fp64 and bounds the GPU's error by 1.5x the fp32 oracle's own (tol = None)
+                                                    ("resnet18", "RESNET18_3D", 1025, 321, 68, None)])
 def test_3d_models(model, cfg, w, h, disp, tol):
     """NVSmall / ResNet-18 3D (BASELINE configs C5 / C4 in fp32) at a quarter of their resolution and at full size
     (1025x321, D = 48 / 68 at half resolution): Winograd Conv3D, folded Pad, fused Conv3DTranspose decoder and the
@@ -379,8 +421,17 @@ def test_3d_models(model, cfg, w, h, disp, tol):
     with torch.no_grad():
         ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), weights, getattr(O, cfg), disp)
     err = (out.cpu() - ref).abs().max().item()
-    assert err <= tol, err
     net.destroy()
+    if tol is not None:
+        assert err <= tol, err
+        return
+    with torch.no_grad():                                     # fp64 evaluation of the same graph (about a minute of CPU)
+        ref64 = O.stereo3d(torch.from_numpy(l).double(), torch.from_numpy(r).double(), weights, getattr(O, cfg), disp)
+    e_gpu = (out.cpu().double() - ref64).abs().max().item()
+    e_oracle = (ref.double() - ref64).abs().max().item()
+    print("%s %dx%d: |GPU - fp64| = %.3g px, |fp32 oracle - fp64| = %.3g px, |GPU - fp32 oracle| = %.3g px" % (model, w, h, e_gpu, e_oracle, err))
+    assert e_gpu <= max(1.5 * e_oracle, 1e-3), (e_gpu, e_oracle)
+    assert err <= e_gpu + e_oracle + 1e-6                      # triangle inequality: nothing else hides in the fp32 comparison
 
 
 @pytest.mark.gpu
@@ -418,9 +469,21 @@ def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
     print("NVSmall 1025x321, real fp16 weights, half2 mode (fp16 3-D tensors): max |disp - oracle| = %.3g px, mean %.3g px, disparities up to %.1f px"
           % (err.max().item(), err.mean().item(), ref.max().item()))
     assert not torch.isnan(out).any()
-    # fp16 storage of 11 stacked 3-D layers on disparities up to ~100 px: asserted against a quarter of a pixel at worst and 2e-3 px
-    # on average (measured 0.11 / 3e-4 px; the reference's accuracy metric D1 counts errors above 3 px); with fp32 tensors (RT_NO_F16_3D) the same weights give < 1e-3 px, below
-    assert err.max().item() <= 0.25 and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    # fp16 storage of 11 stacked 3-D layers on disparities up to ~100 px: measured 0.11 px at worst / 3e-4 px on average against the
+    # fp32-tensor oracle, asserted at 1.3x that (the reference's accuracy metric D1 counts errors above 3 px); with fp32 tensors
+    # (RT_NO_F16_3D) the same weights give < 1e-3 px, below
+    assert err.max().item() <= 0.15 and err.mean().item() <= 4e-4, (err.max().item(), err.mean().item())
+    # ... and it is the error class of the REFERENCE's own fp16 mode: its Conv3D / Conv3DTranspose plugins convert to fp16 before cuDNN,
+    # get an fp16 tensor back, add the bias to it and convert to fp32 (lib/conv3d_plugin.cpp:187-216, 247-274).  The oracle restates
+    # that (plugin_fp16=True); our half2 output must be no further from it than twice its own distance from the fp32-tensor oracle.
+    with torch.no_grad():
+        ref16 = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), weights, O.NVSMALL_3D, 48, plugin_fp16=True)
+    d_ref = (ref16 - ref).abs()
+    d_hip = (out.cpu() - ref16).abs()
+    print("reference-style fp16 plugins (oracle): max |disp - fp32-tensor oracle| = %.3g px, mean %.3g px; ours against that: max %.3g px, mean %.3g px"
+          % (d_ref.max().item(), d_ref.mean().item(), d_hip.max().item(), d_hip.mean().item()))
+    assert d_hip.max().item() <= 2 * d_ref.max().item() and d_hip.mean().item() <= 2 * d_ref.mean().item(), (d_hip.max().item(), d_ref.max().item())
+    assert err.max().item() <= 2 * d_ref.max().item() and err.mean().item() <= 2 * d_ref.mean().item()      # no worse than the reference's mode
     net.destroy()
     monkeypatch.setenv("RT_NO_F16_3D", "1")
     net = lib.create("nvsmall", 1025, 321, weights_path=model_files.weight_file("nvsmall", True), fp16_weights=True)
@@ -438,7 +501,9 @@ def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
                                                           ("nvsmall", "NVSMALL_3D", 257, 129, 16, 8, 1e-3), ("resnet18", "RESNET18_3D", 257, 129, 12, 8, 1e-3)])
 def test_3d_models_batched(model, cfg, w, h, disp, batch, tol):
     """per-GPU shards of BASELINE configs C5 / C4 (64 / 32 pairs over 8 GPUs = 8 / 4 per GPU): batch 4 at full size,
-    batch 8 at a quarter of the resolution, every pair against the oracle"""
+    batch 8 at a quarter of the resolution, every pair against the oracle.  (ResNet-18 3D at full size: 5e-3 px against the fp32
+    oracle, whose own distance from an fp64 evaluation is 2.2e-3 px -- test_3d_models does that comparison in fp64 for one pair;
+    here the first pair must also equal the batch-1 engine's result bit for bit, so the batch adds nothing to that error.)"""
     lib = netlib("gpu")
     weights = O.synth_weights_3d(getattr(O, cfg))
     l, r = pairs(batch, h, w)
@@ -448,6 +513,13 @@ def test_3d_models_batched(model, cfg, w, h, disp, batch, tol):
     torch.cuda.synchronize()
     out = out.cpu()
     net.destroy()
+    if tol > 1e-3:                                            # the loose case: tie it to the single-pair engine, which test_3d_models bounds in fp64
+        net1 = lib.create(model, w, h, max_batch=1, weights=weights, max_disp=disp)
+        out1 = torch.full((1, 1, h, w), float("nan"), device="cuda")
+        net1.execute(torch.from_numpy(l[:1]).cuda(), torch.from_numpy(r[:1]).cuda(), out1, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(out1.cpu(), out[:1]), (out1.cpu() - out[:1]).abs().max().item()
+        net1.destroy()
     with torch.no_grad():
         for i in range(batch):
             ref = O.stereo3d(torch.from_numpy(l[i:i + 1]), torch.from_numpy(r[i:i + 1]), weights, getattr(O, cfg), disp)

@@ -46,7 +46,7 @@ def run_conv3d(g, idx, stride, pad_start, pad_end, pad_input_d=False, bias=None)
 
 
 def test_conv3d_01_basic(golden):                       # :362-389
-    assert_float_eq(run_conv3d(golden, "01", (1, 1, 1), (0, 0, 0), (0, 0, 0)), golden["conv3d_01_y"], ulps=16)
+    assert_float_eq(run_conv3d(golden, "01", (1, 1, 1), (0, 0, 0), (0, 0, 0)), golden["conv3d_01_y"], ulps=4)      # EXPECT_FLOAT_EQ = 4 ULP; measured 1 ULP (the golden value itself is 0.94 ULP from fp64)
 
 
 def test_conv3d_02_hw_strides(golden):                  # :391-420

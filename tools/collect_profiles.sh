@@ -5,12 +5,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-prof}
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> /dev/null
-RT_RB=0 python $R/bench.py --no-cpu-baseline > $O/bench_layer_by_layer.json 2> /dev/null      # the tower blocks as two launches each
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/trace.log 2>&1
+RT_RB=0 python $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_layer_by_layer.json 2> /dev/null      # the tower blocks as two launches each
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $O/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --steps 10 --warmup 2 --contexts 1 --spinup-ms 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --steps 10 --warmup 2 --contexts 1 --streams-per-context 1 --spinup-ms 0 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 10 --warmup 2 --contexts 1 --spinup-ms 0 --no-cpu-baseline > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 10 --warmup 2 --contexts 1 --streams-per-context 1 --spinup-ms 0 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1
 python $R/bench.py --half2 --batch 1 --no-cpu-baseline > $O/bench_half2_b1.json 2> /dev/null
 python $R/bench.py --half2 --batch 8 --no-cpu-baseline > $O/bench_half2_b8.json 2> /dev/null
 python $R/bench.py --model nvsmall --half2 --batch 8 --steps 20 --warmup 3 > $O/bench_nvsmall_half2_b8.json 2> /dev/null

@@ -26,6 +26,16 @@ DOMINANT = "conv_s3_kernel<3, 3, 1, ...>"
 def is_dom(name):
     return name.startswith("conv_s3rbs_kernel") if FUSED else name.startswith("conv_s3_kernel<3, 3, 1,")
 
+
+def kernel_sources_sha16(root):
+    """the stamp bench.py compares with (bench.py: kernel_sources_sha16)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "redtail_amd", "csrc", "kernels", "*.h"))) + [os.path.join(root, "redtail_amd", "csrc", "rt_capi.hip")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (the kernel also runs the low-resolution layers)
 # gfx950: TCC_EA read counters behind FETCH_SIZE report half of the bytes for coalesced streams (calibrated
 # with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
@@ -46,9 +56,17 @@ def main():
     stats = open(os.path.join(run, "trace", "bench_kernel_stats.csv")).read()
     if "conv_s3rbs_kernel" in stats:
         FUSED, DOMINANT = True, "conv_s3rbs_kernel"
-        DOMINANT_GRID = 21 * 6 * 512                               # 21 strips x 6 segments of 32 rows, 8 waves
-        ALGO_READ = 4.0 * (32 * 185 * 629 + 2 * (32 * 32 * 9 + 32))   # x + both layers' weights and biases
-        ALGO_WRITE = 4.0 * 32 * 185 * 629
+        # the dominant launches are the largest grids of that kernel in the run: since round 3 a launch covers both towers (siamese
+        # merge: grid z = 2) and walks 64-row segments in one-stream contexts, 32-row segments otherwise
+        import re
+        grids = collections.Counter()
+        for r in csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))):
+            if short(r["Kernel_Name"]).startswith("conv_s3rbs_kernel"):
+                grids[int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])] += 1
+        DOMINANT_GRID = max(grids)
+        images = 2 if DOMINANT_GRID in (21 * 3 * 512 * 2, 21 * 6 * 512 * 2, 21 * 4 * 512 * 2, 21 * 2 * 512 * 2) else 1
+        ALGO_READ = images * 4.0 * (32 * 185 * 629) + 4.0 * 2 * (32 * 32 * 9 + 32)   # x of every image + both layers' weights and biases
+        ALGO_WRITE = images * 4.0 * 32 * 185 * 629
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
@@ -83,14 +101,15 @@ def main():
     # ---- durations of the dominant kernel from the trace ----------------------------------------------
     rows = list(csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows
-            if is_dom(short(r["Kernel_Name"])) and int(r["Grid_Size_X"]) == DOMINANT_GRID]
+            if is_dom(short(r["Kernel_Name"])) and int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) == DOMINANT_GRID]
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
     t1 = max(int(r["End_Timestamp"]) for r in rows)
     traffic = dict(kernel=DOMINANT, launches_counted=len(dom["FETCH_SIZE"]),
                    fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
                    algorithmic_read_bytes=ALGO_READ, algorithmic_write_bytes=ALGO_WRITE,
                    fetch_scale=FETCH_SCALE, write_scale=WRITE_SCALE,
-                   rocprof_avg_launch_us=sum(durs) / len(durs) / 1e3, rocprof_launches=len(durs))
+                   rocprof_avg_launch_us=sum(durs) / len(durs) / 1e3, rocprof_launches=len(durs), dominant_grid_threads=DOMINANT_GRID,
+                   sources_sha16=kernel_sources_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     json.dump(traffic, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
 
     # ---- one steady-state step as a timeline (last full step of the trace) -----------------------------
