@@ -499,12 +499,8 @@ def secondary_lines(lib, dev):
 
 
 def exact_fp32_value(lib, dev, blob, b, nctx, spc, left, right, ref, steps=60):
-    """The headline set-up with RT_CONV_EXACT_FP32=1: every convolution on the fp32 fmaf-chain kernels of round 1 (no fp16 split)."""
-    os.environ["RT_CONV_EXACT_FP32"] = "1"
-    try:
-        nets = [lib.create("resnet18_2D", W, H, max_batch=b, weights=blob) for _ in range(nctx)]
-    finally:
-        del os.environ["RT_CONV_EXACT_FP32"]
+    """The headline set-up with the exact-fp32 option: every 2-D convolution on the fp32 fmaf-chain kernels of round 1 (no fp16 split)."""
+    nets = [lib.create("resnet18_2D", W, H, max_batch=b, weights=blob, flags=capi.RT_CONV_EXACT_FP32) for _ in range(nctx)]
     for n_ in nets:
         n_.set_streams(spc)
     disps = [torch.empty(b, 1, H, W, device=dev) for _ in nets]
@@ -522,7 +518,8 @@ def exact_fp32_value(lib, dev, blob, b, nctx, spc, left, right, ref, steps=60):
     for n_ in nets:
         n_.destroy()
     return {"value": steps * b / dt, "unit": "pairs/s", "steps": steps, "launches_per_step": launches, "parity_max_abs_err": parity,
-            "note": "RT_CONV_EXACT_FP32=1: fp32 fmaf chains on the fp32 matrix pipe / Winograd F(2x2,3x3), same contexts and streams"}
+            "note": "rtNetOptions.flags = RT_CONV_EXACT_FP32 (IBuilder::setExactFp32Mode): fp32 fmaf chains on the fp32 matrix pipe / Winograd F(2x2,3x3), "
+                    "same contexts and streams"}
 
 
 def main():

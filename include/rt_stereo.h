@@ -154,7 +154,13 @@ typedef struct rtConv2dDesc {
     int act;                /* RT_ACT_* fused after bias (+ residual)                            */
     int has_residual;       /* enqueue takes a residual tensor shaped like the output            */
     int dtype;              /* RT_F32 | RT_F16: storage type of activations AND weights          */
+    int flags;              /* RT_CONV_* option bits, 0 = defaults                               */
 } rtConv2dDesc;
+
+/* rtConv2dDesc::flags / rtConv3dDesc::flags.  RT_CONV_EXACT_FP32: keep the convolution on the fp32 fmaf-chain kernels (fp32 MFMA /
+ * Winograd F(2x2,3x3)) instead of the default 3-term fp16 split on the fp16 matrix pipe (22-bit operands, fp32 accumulation; domain
+ * |x| < 65504, see rt_check_range).  IBuilder::setExactFp32Mode / rtNetOptions::flags set it for a whole engine. */
+#define RT_CONV_EXACT_FP32 1
 
 /* 2-D convolution (cross-correlation), weights KCRS, bias K (may be NULL): TensorRT
  * addConvolution as called at sample_app/resnet18_2D_513x257_net.cpp:48-53 (no source in the
@@ -229,6 +235,7 @@ typedef struct rtConv3dDesc {
                             /* maps (C == 2F; CostVolumePlugin kDefault, lib/kernels.cu:50-97) that is never built:     */
                             /* x points to the (2F, H, W) tensor [left | right] and slice d of the volume is gathered   */
                             /* as cv[d, 0:F] = L, cv[d, F:2F, y, x] = R[:, y, x - d] (0 for x < d)                       */
+    int flags;              /* RT_CONV_* option bits (see rtConv2dDesc), 0 = defaults                               */
 } rtConv3dDesc;
 
 /* TensorFlow-compatible 3-D convolution.  x (N, D,C,H,W) , w (K,V,C,R,S) 3x3x3 -> y (N, K,Do,Ho,Wo).
@@ -242,6 +249,16 @@ int rt_conv3d_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const voi
  * in_dims = (Dy,Hy,Wy) of the input. */
 int rt_conv3d_transpose_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const int in_dims[3],
                                     const void* weights_host, const void* bias_host);
+
+/* The domain of a plan's arithmetic.  The default fp32 path multiplies 22-bit fp16 splits on the fp16 matrix pipe: an input value with
+ * |x| >= 65504 (or a non-finite one) becomes inf / NaN in the result -- loud, but far from its cause.  rt_conv_plan_input_limit gives the
+ * bound a plan needs (65504 for split / fp16-operand plans, +inf for RT_CONV_EXACT_FP32 and the small direct kernels);
+ * rt_check_range scans a device tensor of `rows` rows with `valid` leading elements out of `pitch` each (dense: rows = 1, valid = pitch = n):
+ * max |x| and the number of elements with |x| >= limit or non-finite.  Blocking.  IExecutionContext::setDebugSync(true) /
+ * rt_net_set_debug make the executor run it on the input of every such launch and fail the execute() with the layer's name. */
+int rt_conv_plan_input_limit(const rtConvPlan* plan, float* limit);
+int rt_check_range(const void* x, int64_t rows, int64_t valid, int64_t pitch, int dtype, float limit, float* max_abs, int64_t* violations,
+                   rtStream stream);
 
 /* Output dims of a plan: 2-D -> (Cout,Hout,Wout,1); 3-D -> 4 dims in the order they are written. */
 int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]);

@@ -46,6 +46,22 @@ int rt_net_weights_crc32(const rtStereoNet* net, uint32_t* crc);
  * execution contexts from it (rt_net_create_from_memory). */
 int rt_net_weights_image(const rtStereoNet* net, const void** data, size_t* bytes);
 
+/* Everything above in one call, options as a struct (zero-initialise, then set what is needed): weights from `weights_path` or from the
+ * image `blob` / `bytes` (the root rank's when `comm` is set, see rt_net_create_broadcast); flags: RT_CONV_EXACT_FP32 keeps every 2-D
+ * convolution on the fp32 fmaf-chain kernels (IBuilder::setExactFp32Mode). */
+typedef struct rtNetOptions {
+    int model, width, height, max_batch;
+    int weights_dtype;         /* RT_F32 / RT_F16 */
+    int max_disp;              /* <= 0: the model's default */
+    const char* weights_path;  /* or NULL */
+    const void* blob;          /* or NULL */
+    size_t bytes;
+    unsigned flags;            /* RT_CONV_EXACT_FP32 */
+    rtComm* comm;              /* or NULL: no broadcast */
+    int root;
+} rtNetOptions;
+int rt_net_create_opt(rtStereoNet** net, const rtNetOptions* options);
+
 /* left/right: device (N,3,H,W) fp32 in [0,1]; disp: device (N,1,H,W) fp32 (ResNet-18 2D: disparity / width;
  * 3-D models: pixels).  stream == NULL: synchronous (IExecutionContext::execute); otherwise asynchronous on
  * that HIP stream (IExecutionContext::enqueue). */
@@ -67,6 +83,9 @@ int rt_net_num_layers(const rtStereoNet* net);     /* layers of the network defi
  * context (latency); 1 = everything on the caller's stream, best when several handles are kept busy side by side
  * (IExecutionContext::setExecutionStreams, an extension of the NvInfer.h subset; bench.py uses 1 with its six contexts). */
 int rt_net_set_streams(rtStereoNet* net, int streams);
+/* Debug mode (IExecutionContext::setDebugSync): every launch is synchronised and the input of every fp16-pipe convolution is range-checked
+ * first (rt_check_range): an execute() whose activations leave the fp16-split domain fails with the layer's name in rt_net_last_error(). */
+int rt_net_set_debug(rtStereoNet* net, int on);
 int rt_net_num_launches(const rtStereoNet* net);   /* kernel launches after fusion       */
 int rt_net_destroy(rtStereoNet* net);
 const char* rt_net_last_error(void);

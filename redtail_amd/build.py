@@ -195,6 +195,18 @@ def build_reference_tests(force=False, emu=False):
     return out
 
 
+def build_oracle_c(force=False):
+    """oracle/corr_cpu.c -- the plain C restatement of the reference's correlation kernel (checker / CPU baseline, never the product)
+    -> oracle/_ref/libcorr_cpu.so (git-ignored, travels to the GPU box)."""
+    src = os.path.join(ROOT, "oracle", "corr_cpu.c")
+    outdir = os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "libcorr_cpu.so")
+    if force or _newer(out, [src]):
+        _run(["gcc", "-O2", "-shared", "-fPIC", src, "-o", out])
+    return out
+
+
 def build_native_apps(force=False):
     """apps/stereo_throughput.cpp: the native multi-GPU driver (one thread per device, RCCL weight broadcast through the C ABI)
     -> redtail_amd/lib/stereo_throughput (git-ignored, travels to the GPU box)."""

@@ -18,6 +18,7 @@ RT_ACT_NONE, RT_ACT_ELU, RT_ACT_SIGMOID = 0, 1, 2
 
 
 RT_HINT_THROUGHPUT = 1     # include/rt_stereo.h
+RT_CONV_EXACT_FP32 = 1     # rtConv2dDesc.flags / rtConv3dDesc.flags / rtNetOptions.flags
 
 
 class RtError(RuntimeError):
@@ -26,14 +27,14 @@ class RtError(RuntimeError):
 
 class Conv2dDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("Cin", "Cout", "Hin", "Win", "KH", "KW", "stride", "pad_h", "pad_w", "act",
-                                     "has_residual", "dtype")]
+                                     "has_residual", "dtype", "flags")]
 
 
 class Conv3dDesc(ctypes.Structure):
     _fields_ = [("C", c_int), ("K", c_int), ("D", c_int), ("H", c_int), ("W", c_int), ("kernel", c_int * 3),
                 ("stride", c_int * 3), ("pad_start", c_int * 3), ("pad_end", c_int * 3), ("act", c_int),
                 ("out_dchw", c_int), ("has_residual", c_int), ("dtype", c_int), ("out_depth", c_int),
-                ("in_pad_end", c_int), ("cv_fold", c_int)]
+                ("in_pad_end", c_int), ("cv_fold", c_int), ("flags", c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rt_stereo.h
@@ -80,6 +81,8 @@ KERNEL_SYMBOLS = {
                                                 c_void_p]),
     "rt_preprocess_bgr8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
+    "rt_conv_plan_input_limit": (c_int, [c_void_p, POINTER(c_float)]),
+    "rt_check_range": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_float, POINTER(c_float), POINTER(c_int64), c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_plan_set_batch_strides": (c_int, [c_void_p, c_int64, c_int64, c_int64]),
@@ -200,9 +203,15 @@ class KernelLib:
                    "rt_concat_channels")
 
     # -- convolution plans -------------------------------------------------------------------------
+    def check_range(self, x, rows, valid, pitch, dtype=RT_F32, limit=65504.0, stream=None):
+        """(max finite |x|, number of elements with |x| >= limit or non-finite) of a device tensor (rt_check_range)"""
+        mx, bad = c_float(), c_int64()
+        self.check(self.lib.rt_check_range(_ptr(x), rows, valid, pitch, dtype, limit, ctypes.byref(mx), ctypes.byref(bad), stream), "rt_check_range")
+        return mx.value, bad.value
+
     def conv2d_plan(self, w_host, b_host, Cin, Cout, Hin, Win, k, stride, pad, act=0, has_residual=False,
-                    dtype=RT_F32, transposed=False):
-        d = Conv2dDesc(Cin, Cout, Hin, Win, k, k, stride, pad, pad, act, int(has_residual), dtype)
+                    dtype=RT_F32, transposed=False, flags=0):
+        d = Conv2dDesc(Cin, Cout, Hin, Win, k, k, stride, pad, pad, act, int(has_residual), dtype, flags)
         plan = c_void_p()
         fn = self.lib.rt_deconv2d_plan_create if transposed else self.lib.rt_conv2d_plan_create
         self.check(fn(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host)), "conv2d plan")
@@ -245,6 +254,12 @@ class ConvPlan:
 
     def set_io_types(self, x_dtype, y_dtype):
         self.klib.check(self.klib.lib.rt_conv_plan_set_io_types(self.handle, x_dtype, y_dtype), "rt_conv_plan_set_io_types")
+
+    def input_limit(self):
+        """bound on |x| the plan's arithmetic needs (65504 for fp16-pipe plans, inf for exact fp32)"""
+        v = c_float()
+        self.klib.check(self.klib.lib.rt_conv_plan_input_limit(self.handle, ctypes.byref(v)), "rt_conv_plan_input_limit")
+        return v.value
 
     def supports_il8(self):
         return bool(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
@@ -294,9 +309,17 @@ NET_SYMBOLS = {
     "rt_net_create_broadcast": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int]),
     "rt_net_weights_crc32": (c_int, [c_void_p, POINTER(ctypes.c_uint32)]),
     "rt_net_weights_image": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    "rt_net_create_opt": (c_int, [POINTER(c_void_p), c_void_p]),
+    "rt_net_set_debug": (c_int, [c_void_p, c_int]),
     "rt_net_destroy": (c_int, [c_void_p]),
     "rt_net_last_error": (c_char_p, []),
 }
+
+
+class NetOptions(ctypes.Structure):
+    """rtNetOptions (include/rt_stereo_net.h)"""
+    _fields_ = [("model", c_int), ("width", c_int), ("height", c_int), ("max_batch", c_int), ("weights_dtype", c_int), ("max_disp", c_int),
+                ("weights_path", c_char_p), ("blob", c_void_p), ("bytes", c_size_t), ("flags", ctypes.c_uint), ("comm", c_void_p), ("root", c_int)]
 
 
 def pack_weights(weights, fp16=False):
@@ -347,10 +370,17 @@ class NetLib:
             raise RtError("%s failed (%d): %s" % (what, rc, self.lib.rt_net_last_error().decode()))
 
     def create(self, model, width, height, max_batch=1, weights=None, weights_path=None, fp16_weights=False,
-               max_disp=0):
+               max_disp=0, flags=0):
         h = c_void_p()
         dt = RT_F16 if fp16_weights else RT_F32
         mid = MODEL_IDS[model] if isinstance(model, str) else model
+        if flags:                                          # options beyond the plain entries: rt_net_create_opt
+            blob = None if weights_path is not None else (weights if isinstance(weights, (bytes, bytearray)) else pack_weights(weights, fp16_weights))
+            keep = ctypes.create_string_buffer(bytes(blob), len(blob)) if blob is not None else None
+            o = NetOptions(mid, width, height, max_batch, dt, max_disp, weights_path.encode() if weights_path else None,
+                           ctypes.cast(keep, c_void_p) if keep is not None else None, len(blob) if blob is not None else 0, flags, None, 0)
+            self.check(self.lib.rt_net_create_opt(ctypes.byref(h), ctypes.byref(o)), "rt_net_create_opt")
+            return StereoNet(self, h, width, height)
         if weights_path is not None:
             rc = self.lib.rt_net_create(ctypes.byref(h), mid, width, height, max_batch, dt, max_disp,
                                         weights_path.encode())
@@ -408,6 +438,10 @@ class StereoNet:
     def execute(self, left, right, disp, batch=1, stream=None):
         self.netlib.check(self.netlib.lib.rt_net_execute(self.handle, _ptr(left), _ptr(right), _ptr(disp), batch, stream),
                           "rt_net_execute")
+
+    def set_debug(self, on=True):
+        """IExecutionContext::setDebugSync: synchronise every launch and range-check the input of every fp16-pipe convolution"""
+        self.netlib.check(self.netlib.lib.rt_net_set_debug(self.handle, int(on)), "rt_net_set_debug")
 
     def weights_crc32(self):
         """crc32 of the weight-file image this engine was built from (== zlib.crc32 of the file)"""

@@ -29,6 +29,13 @@
 namespace nvinfer1 {
 namespace {
 
+// Development knobs (RT_* environment variables, the A/B switches of tests / tools / DESIGN.md's measurements) are honoured only in a
+// process that opts in with RT_DEV_KNOBS=1 (tests/conftest.py, tools/): ambient environment does not change what the library does.
+const char* knob(const char* name) {
+    static const bool on = [] { const char* e = std::getenv("RT_DEV_KNOBS"); return e && std::atoi(e) != 0; }();
+    return on ? std::getenv(name) : nullptr;
+}
+
 using redtail::tensorrt::CostVolumeType;
 using redtail::tensorrt::SoftargmaxType;
 using redtail::tensorrt::internal::ConvFusion;
@@ -343,6 +350,7 @@ public:
 
 private:
     bool run(int batch, void** bindings, cudaStream_t stream, bool sync);
+    bool checkInputRange(const Op& op, int batch, void** bindings, rtStream st);
     bool ensureBuffers(int batch);
     void* addr(int tensor, int batch, void** bindings) const;
 
@@ -376,7 +384,7 @@ public:
 
 class EngineImpl : public ICudaEngine {
 public:
-    EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log);
+    EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log, bool exact_fp32 = false);
     ~EngineImpl() override;
     bool ok() const { return ok_; }
 
@@ -445,6 +453,7 @@ private:
     void mergeSiamese();
     bool ok_ = false;
     bool half2_ = false;
+    bool exact_fp32_ = false;      // IBuilder::setExactFp32Mode: rtConv2dDesc::flags |= RT_CONV_EXACT_FP32 on every 2-D plan
     std::vector<IPlugin*> half_plugins_;   // IPluginExt instances that only accept kHALF ...
     std::vector<int> half_kinds_;          // ... and the format they were configured with (1 = NCHW, 2 = NC2HW2)
 public:
@@ -452,7 +461,8 @@ public:
 };
 
 // ---- building ------------------------------------------------------------------------------------------------
-EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log) : max_batch_(max_batch), log_(log), half2_(half2) {
+EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log, bool exact_fp32)
+    : max_batch_(max_batch), log_(log), half2_(half2), exact_fp32_(exact_fp32 || (knob("RT_CONV_EXACT_FP32") && atoi(knob("RT_CONV_EXACT_FP32")) != 0)) {
     tensors_ = std::move(net.tensors_);
     layers_ = std::move(net.layers_);
     for (auto* t : net.inputs_) bindings_.push_back(t->id);
@@ -492,8 +502,8 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
             auto it = std::find(half_plugins_.begin(), half_plugins_.end(), op.plugin);
             if (it != half_plugins_.end()) op.half_kind = half_kinds_[it - half_plugins_.begin()];
         }
-    if (ok_) fuseResBlocks();
     if (ok_) assignPitch();
+    if (ok_) fuseResBlocks();           // after the layouts are known: the streaming kernel serves interleaved tensors
     if (ok_) assignStreams();           // preliminary: foldConcats wants to know which stream an op is on
     if (ok_) foldConcats();
     if (ok_) foldCostVolumes();
@@ -537,7 +547,7 @@ bool EngineImpl::lower() {
         log_.log(ILogger::Severity::kERROR, msg.c_str());
         return false;
     };
-    const bool fuse = getenv("RT_NO_FUSION") == nullptr;
+    const bool fuse = knob("RT_NO_FUSION") == nullptr;
 
     for (size_t li = 0; li < layers_.size(); li++) {
         if (done[li]) continue;
@@ -603,6 +613,7 @@ bool EngineImpl::lower() {
                 d.pad_h = l->padding.h(); d.pad_w = l->padding.w();
                 d.act = act; d.has_residual = resid >= 0;
                 d.dtype = l->kernel.type == DataType::kHALF ? RT_F16 : RT_F32;
+                d.flags = exact_fp32_ ? RT_CONV_EXACT_FP32 : 0;
                 const int64_t expect = (int64_t)d.Cin * d.Cout * d.KH * d.KW;
                 if (l->kernel.count != expect) return fail(l->name + ": kernel weight count does not match the layer shape");
                 if (l->bias.count != 0 && l->bias.count != d.Cout) return fail(l->name + ": bias count does not match");
@@ -757,7 +768,7 @@ bool EngineImpl::lower() {
 // +6 % on the 3x3 layers with aligned rows).  Bindings and everything a generic plugin launch sees stay dense,
 // as TensorRT's plugin contract requires.
 void EngineImpl::assignPitch() {
-    if (getenv("RT_NO_PITCH")) return;
+    if (knob("RT_NO_PITCH")) return;
     std::vector<char> ok(tensors_.size(), 1);
     for (auto& t : tensors_) {
         if (t->is_input || t->is_output || t->alias_of >= 0 || t->dims.nbDims != 3 || t->bstride != 0) ok[t->id] = 0;
@@ -796,10 +807,10 @@ void EngineImpl::assignPitch() {
     // TensorRT keeps activations in fp16 between its own layers and hands plugins what they asked for; arithmetic
     // stays fp32 in the kernels.  Rows are then padded to 64 elements (128 bytes, and the even pitch the 2-pixel
     // stores need).
-    const bool f16 = half2_ && !getenv("RT_NO_F16");
+    const bool f16 = half2_ && !knob("RT_NO_F16");
     for (auto& t : tensors_) {
         if (!ok[t->id]) continue;
-        const char* ex = getenv("RT_PITCH_EXTRA");          // A/B knob: extra 128-byte lines per row
+        const char* ex = knob("RT_PITCH_EXTRA");          // A/B knob: extra 128-byte lines per row
         const int q = f16 ? 64 : 32;
         const int w = t->dims.d[2], pitch = (w + q - 1) / q * q + q * (ex ? atoi(ex) : 0);
         t->pitch = pitch == w ? 0 : pitch;
@@ -836,7 +847,7 @@ void EngineImpl::assignPitch() {
     auto corr_takes_il = [&](const Op& op) {        // fused correlation + soft-argmax on the matrix cores (corr_mfma.hip.h)
         const Dims& f = tensors_[op.in[0]]->dims;
         return op.kind == OpKind::kCorrSoftargmax && !f16 && f.d[0] % 4 == 0 && f.d[0] <= 32 && op.max_disp <= 64 &&
-               !getenv("RT_NO_CORR_MFMA") && !getenv("RT_NO_IL8");
+               !knob("RT_NO_CORR_MFMA") && !knob("RT_NO_IL8");
     };
     for (auto& op : ops_) {
         int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual
@@ -850,7 +861,7 @@ void EngineImpl::assignPitch() {
     for (auto& op : ops_) {
         if (op.kind != OpKind::kConv) continue;
         const int xi = il[root(op.in[0])], yi = il[root(op.out)], ri = op.resid >= 0 ? il[root(op.resid)] : 0;
-        if (getenv("RT_IL_TRACE")) fprintf(stderr, "[rt] %-28s x%d y%d r%d caps %d\n", op.name.c_str(), xi, yi, ri, rt_conv_plan_supports_il8(op.plan));
+        if (knob("RT_IL_TRACE")) fprintf(stderr, "[rt] %-28s x%d y%d r%d caps %d\n", op.name.c_str(), xi, yi, ri, rt_conv_plan_supports_il8(op.plan));
         if (!(xi || yi || ri)) continue;
         if (rt_conv_plan_set_layouts(op.plan, xi, yi, ri) != 0) {
             log_.log(ILogger::Severity::kERROR, rt_last_error_string());
@@ -871,7 +882,7 @@ void EngineImpl::assignStreams() {
     two_streams_ = false;
     for (auto& op : ops_) { op.stream = 0; op.wait_on.clear(); op.publish = false; }
     for (auto& t : tensors_) t->stream = 0;
-    if (getenv("RT_SINGLE_STREAM")) return;
+    if (knob("RT_SINGLE_STREAM")) return;
     int n_inputs = 0;
     for (int b : bindings_)
         if (tensors_[b]->is_input) n_inputs++;
@@ -969,14 +980,16 @@ void EngineImpl::planIssueOrder() {
 // tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  Not in half2 mode, where the two layers run on fp16
 // operands with fp16 tensors in between.
 void EngineImpl::fuseResBlocks() {
-    // Default: the blocks the STREAMING kernel serves (conv_rbs.hip.h: 32 -> 32 -> 32 channels, ELU after both, interleaved
+    // Default: the blocks the STREAMING kernel serves (conv_rbs.hip.h: 32 -> 32 -> 32 channels, ELU after both, channel-interleaved fp32
     // tensors) on images large enough to fill the GPU with its strips x segments -- measured on MI355X, round 2, ResNet-18 2D at
     // 1257x369 with four contexts: 2185 vs 2057 pairs/s, 2.8x less HBM traffic per block.  Everything else stays two launches: the
-    // per-tile form of the fused block (conv_s3rb_kernel) is slower than its two layers (1934 vs 2069 pairs/s).
-    // RT_RB=1 fuses every block rt_resblock_plan_create accepts (tests, A/B), RT_RB=0 / RT_NO_RB none.
-    const char* e = getenv("RT_RB");
+    // per-tile form of the fused block (conv_s3rb_kernel) is slower than its two layers (1934 vs 2069 pairs/s).  The pass runs AFTER
+    // assignPitch(), so it sees the layouts the tensors really have (a block whose input is written straight into a concatenation
+    // reads a planar tensor and is left alone).  Development knobs: RT_RB=1 fuses every block rt_resblock_plan_create accepts
+    // (tests, A/B), RT_RB=0 / RT_NO_RB none.
+    const char* e = knob("RT_RB");
     const bool force = e && atoi(e) != 0;
-    if ((e && !force) || getenv("RT_NO_FUSION") || getenv("RT_NO_RB") || getenv("RT_NO_S3") || (getenv("RT_CONV_EXACT_FP32") && atoi(getenv("RT_CONV_EXACT_FP32")) != 0) || (half2_ && !getenv("RT_NO_F16"))) return;
+    if ((e && !force) || knob("RT_NO_FUSION") || knob("RT_NO_RB") || knob("RT_NO_S3") || exact_fp32_ || (half2_ && !knob("RT_NO_F16"))) return;
     int fused = 0;
     for (size_t ia = 0; ia < ops_.size(); ia++) {
         Op& a = ops_[ia];
@@ -1007,14 +1020,11 @@ void EngineImpl::fuseResBlocks() {
             return d;
         };
         const rtConv2dDesc d1 = desc(a, false), d2 = desc(b, true);
+        const TensorImpl &x = *tensors_[root(a.in[0])], &y = *tensors_[root(b.out)];
         if (!force) {
-            bool ok = d1.Cin == 32 && d1.Cout == 32 && d2.Cout == 32 && a.act == RT_ACT_ELU && b.act == RT_ACT_ELU && d1.Cin % 4 == 0;
-            // enough strips (30 columns) x segments (16 rows) for every CU
-            ok = ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200;
-            // a block whose input is written straight into a concatenation (foldConcats) reads a planar tensor
-            for (const Op& o : ops_)
-                if (o.kind == OpKind::kConcat)
-                    for (int x : o.in) ok = ok && root(x) != root(a.in[0]);
+            bool ok = d1.Cin == 32 && d1.Cout == 32 && d2.Cout == 32 && a.act == RT_ACT_ELU && b.act == RT_ACT_ELU;
+            ok = ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200;       // enough strips (30 columns) x segments (16 rows) for every CU
+            ok = ok && x.il8 && y.il8 && !x.f16 && !y.f16;                        // what the streaming kernel reads and writes
             if (!ok) continue;
         }
         const LayerData *la = a.conv_layer, *lb = b.conv_layer;
@@ -1022,6 +1032,14 @@ void EngineImpl::fuseResBlocks() {
         if (rt_resblock_plan_create(&rb, &d1, la->kernel.values, la->bias.count ? la->bias.values : nullptr, &d2, lb->kernel.values,
                                     lb->bias.count ? lb->bias.values : nullptr) != 0)
             continue;                                   // not of that form: the two launches stay
+        // the tensors' properties, as assignPitch() gave them to the two plans this one replaces
+        bool cfg = (!(x.pitch || y.pitch) || rt_conv_plan_set_pitch(rb, x.pitch, y.pitch) == 0) &&
+                   rt_conv_plan_set_io_types(rb, x.f16 ? RT_F16 : RT_F32, y.f16 ? RT_F16 : RT_F32) == 0 &&
+                   (!(x.il8 || y.il8) || rt_conv_plan_set_layouts(rb, x.il8, y.il8, x.il8) == 0);
+        if (!cfg) {                                     // the fused plan cannot take these tensors: keep the two launches
+            rt_conv_plan_destroy(rb);
+            continue;
+        }
         rt_conv_plan_destroy(a.plan);
         rt_conv_plan_destroy(b.plan);
         a.plan = rb;
@@ -1047,7 +1065,7 @@ void EngineImpl::fuseResBlocks() {
 // once, half the launches, and no second stream / cross-stream events for the towers.  The arithmetic per sample is untouched, so
 // results are bit-identical to the separate launches (tests/test_net_parity.py).
 void EngineImpl::mergeSiamese() {
-    if (getenv("RT_NO_SIAMESE") || getenv("RT_NO_FUSION")) return;
+    if (knob("RT_NO_SIAMESE") || knob("RT_NO_FUSION")) return;
     std::vector<int> ins;
     for (int b : bindings_)
         if (tensors_[b]->is_input) ins.push_back(b);
@@ -1210,7 +1228,7 @@ void EngineImpl::mergeSiamese() {
 // convolution gathers slice d of the volume from it (rtConv3dDesc::cv_fold; the gather table's plane offsets + an x shift of
 // d for the right-image half).  The CostVolume launch disappears.
 void EngineImpl::foldCostVolumes() {
-    if (getenv("RT_NO_CV_FOLD") || getenv("RT_NO_FUSION")) return;
+    if (knob("RT_NO_CV_FOLD") || knob("RT_NO_FUSION")) return;
     for (size_t ci = 0; ci < ops_.size(); ci++) {
         const Op cv = ops_[ci];
         if (cv.kind != OpKind::kPlugin) continue;
@@ -1285,7 +1303,7 @@ void EngineImpl::foldCostVolumes() {
 // (conv_s3_kernel<.., TIN, TOUT>).  The 2-D feature towers keep fp32 activations; so do the volume the last layer writes
 // and the soft-argmin.
 void EngineImpl::assignHalf3D() {
-    if (!half2_ || getenv("RT_NO_F16") || getenv("RT_NO_F16_3D")) return;
+    if (!half2_ || knob("RT_NO_F16") || knob("RT_NO_F16_3D")) return;
     std::vector<char> h(tensors_.size(), 0);
     for (auto& t : tensors_) h[t->id] = !t->is_input && !t->is_output && t->alias_of < 0 && t->dims.nbDims == 4 && !t->f16;
     auto clear = [&](int t) { if (t >= 0) h[root(t)] = 0; };
@@ -1328,7 +1346,7 @@ void EngineImpl::assignHalf3D() {
 // convolution plans, the inputs BECOME channel ranges of the concatenated buffer -- same planar layout and row pitch, a
 // per-sample stride of the whole buffer -- and the copy launches disappear.
 void EngineImpl::foldConcats() {
-    if (getenv("RT_NO_CONCAT_FOLD") || getenv("RT_NO_FUSION")) return;
+    if (knob("RT_NO_CONCAT_FOLD") || knob("RT_NO_FUSION")) return;
     for (size_t ci = 0; ci < ops_.size(); ci++) {
         if (ops_[ci].kind != OpKind::kConcat) continue;
         const Op cat = ops_[ci];
@@ -1483,7 +1501,7 @@ IHostMemory* EngineImpl::serialize() const {
 ContextImpl::ContextImpl(EngineImpl& e) : eng_(e) {
     buffers_.assign(e.tensors_.size(), nullptr);
     events_.assign(e.tensors_.size(), nullptr);
-    debug_sync_ = getenv("RT_DEBUG_SYNC") != nullptr;      // serialise every launch (A/B measurements only)
+    debug_sync_ = knob("RT_DEBUG_SYNC") != nullptr;      // serialise every launch (A/B measurements only)
 }
 
 ContextImpl::~ContextImpl() {
@@ -1565,7 +1583,7 @@ void* ContextImpl::addr(int tensor, int batch, void** bindings) const {
 
 // events that only order streams carry no timestamps (RT_SYNC_EVENTS_TIMED=1: the round-1 behaviour, for A/B timing)
 static void order_event(void** ev) {
-    static const bool timed = getenv("RT_SYNC_EVENTS_TIMED") && atoi(getenv("RT_SYNC_EVENTS_TIMED")) != 0;
+    static const bool timed = knob("RT_SYNC_EVENTS_TIMED") && atoi(knob("RT_SYNC_EVENTS_TIMED")) != 0;
     if (timed) rt_event_create(ev); else rt_event_create_ordering(ev);
 }
 
@@ -1583,6 +1601,38 @@ bool ContextImpl::enqueue(int batchSize, void** bindings, cudaStream_t stream, c
     bool ok = run(batchSize, bindings, stream, false);
     if (ok && inputConsumed && *inputConsumed) ok = rt_event_record(*inputConsumed, stream) == 0;
     return ok;
+}
+
+// Debug mode (setDebugSync(true)): the input of every launch that multiplies on the fp16 matrix pipe is scanned for values outside the
+// domain of the fp16 split (|x| >= 65504, inf, NaN) BEFORE the launch, so that a violation is reported with the layer's name instead of
+// surfacing as a NaN disparity many layers later.  (The reference's cuDNN / TensorRT fp32 kernels have no such domain.)
+bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtStream st) {
+    if (op.kind != OpKind::kConv || !op.plan) return true;
+    float limit = 0.f;
+    if (rt_conv_plan_input_limit(op.plan, &limit) != 0 || !(limit < 3e38f)) return true;
+    std::vector<int> ins{op.in[0]};
+    if (op.twin) ins.push_back(op.twin_in[0]);
+    for (int tin : ins) {
+        int t = tin;
+        while (eng_.tensors_[t]->alias_of >= 0 && eng_.tensors_[t]->alias_off == 0 && eng_.tensors_[t]->bstride == 0) t = eng_.tensors_[t]->alias_of;
+        const TensorImpl& ti = *eng_.tensors_[t];
+        if (ti.alias_of >= 0 || ti.bstride != 0 || ti.dims.nbDims != 3) continue;       // a channel range of another buffer: checked where it is produced
+        const int C = ti.dims.d[0], H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W, G = ti.il8 ? (ti.f16 ? 8 : 4) : 1;
+        float mx = 0.f;
+        int64_t bad = 0;
+        if (rt_check_range(addr(tin, batch, bindings), (int64_t)batch * (C / G) * H, (int64_t)G * W, (int64_t)G * P, ti.f16 ? RT_F16 : RT_F32, limit, &mx, &bad, st) != 0) {
+            eng_.log_.log(ILogger::Severity::kERROR, (op.name + ": range check failed: " + rt_last_error_string()).c_str());
+            return false;
+        }
+        if (bad) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, ": input '%s' leaves the domain of the fp16-split convolution: %lld value(s) with |x| >= %.0f or non-finite, max finite |x| = %g "
+                          "(IBuilder::setExactFp32Mode keeps the engine on fp32 kernels)", ti.name.c_str(), (long long)bad, limit, mx);
+            eng_.log_.log(ILogger::Severity::kERROR, (op.name + msg).c_str());
+            return false;
+        }
+    }
+    return true;
 }
 
 bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync) {
@@ -1611,7 +1661,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         for (void*& e : prof_events_) rt_event_create(&e);
     }
     // issue order: see assignStreams(); event pairs and half buffers are indexed by the op's position in ops_
-    const int want = getenv("RT_INTERLEAVE") ? atoi(getenv("RT_INTERLEAVE")) : -1;     // A/B: 0 never, 1 always
+    const int want = knob("RT_INTERLEAVE") ? atoi(knob("RT_INTERLEAVE")) : -1;     // A/B: 0 never, 1 always
     const bool interleave = two && eng_.issue_sync_.size() == eng_.ops_.size() && (want < 0 ? sync : want != 0);
 
     bool ok = true;
@@ -1627,6 +1677,10 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
                 }
                 rt_stream_wait_event(st, events_[w]);
             }
+        if (debug_sync_ && !checkInputRange(op, batch, bindings, st)) {
+            ok = false;
+            break;
+        }
         if (profile) rt_event_record(prof_events_[2 * op_index], st);
         const TensorImpl& out = *eng_.tensors_[op.out];
         void* y = addr(op.out, batch, bindings);
@@ -1728,7 +1782,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
             float ms = 0.f;
             rt_event_elapsed_ms(prof_events_[2 * i], prof_events_[2 * i + 1], &ms);
             profiler_->reportLayerTime(eng_.ops_[i].name.c_str(), ms);
-            if (getenv("RT_PROFILE_TIMELINE")) {            // start/end of every launch relative to the first one
+            if (knob("RT_PROFILE_TIMELINE")) {            // start/end of every launch relative to the first one
                 float t0 = 0.f, t1 = 0.f;
                 rt_event_elapsed_ms(prof_events_[0], prof_events_[2 * i], &t0);
                 rt_event_elapsed_ms(prof_events_[0], prof_events_[2 * i + 1], &t1);
@@ -1750,6 +1804,8 @@ public:
     std::size_t getMaxWorkspaceSize() const override { return workspace_; }
     void setHalf2Mode(bool m) override { half2_ = m; }
     bool getHalf2Mode() const override { return half2_; }
+    void setExactFp32Mode(bool m) override { exact_fp32_ = m; }
+    bool getExactFp32Mode() const override { return exact_fp32_; }
     void setDebugSync(bool s) override { debug_sync_ = s; }
     bool getDebugSync() const override { return debug_sync_; }
     void setMinFindIterations(int v) override { min_find_ = v; }
@@ -1759,7 +1815,7 @@ public:
     bool platformHasFastFp16() const override { return true; }      // CDNA4: fp16 MFMA at 16x the fp32 rate
     bool platformHasFastInt8() const override { return true; }
     ICudaEngine* buildCudaEngine(INetworkDefinition& network) override {
-        auto* e = new EngineImpl(static_cast<NetworkImpl&>(network), max_batch_, half2_, log_);
+        auto* e = new EngineImpl(static_cast<NetworkImpl&>(network), max_batch_, half2_, log_, exact_fp32_);
         if (!e->ok()) {
             log_.log(ILogger::Severity::kERROR, "buildCudaEngine failed");
             delete e;
@@ -1773,7 +1829,7 @@ private:
     ILogger& log_;
     int max_batch_ = 1, min_find_ = 1, avg_find_ = 1;
     std::size_t workspace_ = 0;
-    bool half2_ = false, debug_sync_ = false;
+    bool half2_ = false, debug_sync_ = false, exact_fp32_ = false;
 };
 
 class RuntimeImpl : public IRuntime {

@@ -89,7 +89,7 @@ bool parseWeights(rtStereoNet& n, int dtype) {
 }
 
 int build(rtStereoNet** out, int model, int width, int height, int max_batch, int dtype, int max_disp,
-          std::vector<char>&& blob) {
+          std::vector<char>&& blob, unsigned flags = 0) {
     if (!out) return fail("rt_net_create: null out pointer");
     if (width < 17 || height < 17 || max_batch < 1) return fail("rt_net_create: bad dimensions");
     if (dtype != RT_F32 && dtype != RT_F16) return fail("rt_net_create: weights_dtype must be RT_F32 or RT_F16");
@@ -130,6 +130,7 @@ int build(rtStereoNet** out, int model, int width, int height, int max_batch, in
     n->layers = net->getNbLayers();
     builder->setMaxBatchSize(max_batch);
     builder->setHalf2Mode(dtype == RT_F16);        // fp16 weight file = fp16 inference, as in sample_app/main.cpp:256-262
+    builder->setExactFp32Mode((flags & RT_CONV_EXACT_FP32) != 0);
     builder->setMaxWorkspaceSize((size_t)1 << 30);
     n->engine = builder->buildCudaEngine(*net);
     net->destroy();
@@ -180,6 +181,39 @@ extern "C" int rt_net_create_broadcast(rtStereoNet** net, int model, int width, 
     if (rank == root) memcpy(image.data(), blob, (size_t)n);
     if (comm && rt_comm_broadcast(comm, image.data(), (size_t)n, root, nullptr) != 0) return fail(std::string("rt_net_create_broadcast: ") + rt_last_error_string());
     return build(net, model, width, height, max_batch, dtype, max_disp, std::move(image));
+}
+
+extern "C" int rt_net_create_opt(rtStereoNet** net, const rtNetOptions* o) {
+    if (!o) return fail("rt_net_create_opt: null options");
+    std::vector<char> image;
+    if (o->weights_path && !o->blob) {
+        std::ifstream f(o->weights_path, std::ios::binary | std::ios::ate);
+        if (!f.is_open()) return fail(std::string("rt_net_create_opt: cannot open ") + o->weights_path);
+        image.resize((size_t)f.tellg());
+        f.seekg(0);
+        f.read(image.data(), (std::streamsize)image.size());
+    } else if (o->blob && o->bytes) {
+        image.assign(static_cast<const char*>(o->blob), static_cast<const char*>(o->blob) + o->bytes);
+    }
+    if (o->comm) {
+        int world = 1, rank = 0;
+        if (rt_comm_info(o->comm, &world, &rank) != 0) return fail(std::string("rt_net_create_opt: ") + rt_last_error_string());
+        if (o->root < 0 || o->root >= world) return fail("rt_net_create_opt: root is not a rank of the communicator");
+        if (rank == o->root && image.empty()) return fail("rt_net_create_opt: the root rank has no weight image");
+        uint64_t n = rank == o->root ? (uint64_t)image.size() : 0;
+        if (rt_comm_broadcast(o->comm, &n, sizeof(n), o->root, nullptr) != 0) return fail(std::string("rt_net_create_opt: ") + rt_last_error_string());
+        if (n == 0 || n > ((uint64_t)1 << 32)) return fail("rt_net_create_opt: implausible weight image size received");
+        image.resize((size_t)n);
+        if (rt_comm_broadcast(o->comm, image.data(), (size_t)n, o->root, nullptr) != 0) return fail(std::string("rt_net_create_opt: ") + rt_last_error_string());
+    }
+    if (image.empty()) return fail("rt_net_create_opt: no weights (weights_path, blob or a broadcast)");
+    return build(net, o->model, o->width, o->height, o->max_batch, o->weights_dtype, o->max_disp, std::move(image), o->flags);
+}
+
+extern "C" int rt_net_set_debug(rtStereoNet* net, int on) {
+    if (!net || !net->context) return fail("rt_net_set_debug: null pointer");
+    net->context->setDebugSync(on != 0);
+    return 0;
 }
 
 extern "C" int rt_net_weights_crc32(const rtStereoNet* net, uint32_t* crc) {

@@ -43,6 +43,7 @@ struct ZSlice {
     int64_t y_off;         // replaces ConvArgs::y_off + zi * y_zstride
     int64_t w_off;         // element offset of this slice's packed weights
     int64_t r_off;         // like y_off, for the residual tensor (differs when the output layout is transposed)
+    int64_t r_off_il8;     // r_off for a channel-interleaved fp16 residual (C/8, H, W, 8): the pixel part of the offset counts 8 elements
 };
 
 struct ConvArgs {

@@ -304,9 +304,12 @@ struct S3Cfg {
 template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
     using Cfg = S3Cfg<KH, KW, S, NW>;
-    constexpr bool XF16 = std::is_same<TIN, _Float16>::value;
+    constexpr bool XF16 = std::is_same<TIN, _Float16>::value, YF16 = std::is_same<TOUT, _Float16>::value;
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
-    static_assert(!(XIL || YIL) || (!XF16 && std::is_same<TOUT, float>::value), "interleaved tensors are fp32");
+    // interleaved INPUT tensors are fp32 here (fp16 ones go through conv_f16mma_kernel); an interleaved OUTPUT may also be fp16,
+    // (K/8, H, W, 8): the first Conv3D of a 3-D model in half2 mode (fp32 feature maps in, fp16 volume out)
+    static_assert(!XIL || !XF16, "interleaved fp16 input: conv_f16mma_kernel");
+    static_assert(!(YIL && YF16) || !XIL, "fp16 interleaved output is built for planar input");
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
 
@@ -338,12 +341,12 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX);
     const int nchunks = p.CinPad / CC;
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
-    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off;
+    int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off, r_off_il8 = y_off;
     unsigned tap_mask = ~0u;
     if (p.zs) {
         const ZSlice z = p.zs[zi];
         pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
-        r_off = z.r_off;
+        r_off = z.r_off; r_off_il8 = z.r_off_il8;
         tap_mask = z.tap_mask;
     }
     const int act = p.act;
@@ -432,8 +435,18 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     if (p.resid != nullptr) {
         // interleaved tensors (2-D plans only): pixel offsets -- r_off / y_off of a transposed-convolution phase -- count
         // 16-byte slots, i.e. 4 elements
-        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + 4 * r_off : rbase, ESY));
-        if (r_il) {
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + (YF16 ? r_off_il8 : 4 * r_off) : rbase, ESY));
+        if (r_il && YF16) {
+            // fp16 residual, (C/8, H, W, 8): the lane's 4 consecutive channels of a pixel are 8 bytes (the skip tensor of a fused
+            // Conv3DTranspose + skip + ELU launch in half2 mode, written by conv_f16mma_kernel)
+            const unsigned vo = inb ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 8 + 4 * kg) * 2u : kBufOOB;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(rs_r, (cb + 8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q) * rs32) * 2u, 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) rr[q][e] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u[e >> 1] >> (16 * (e & 1))));
+            }
+        } else if (r_il) {
             const unsigned vo = inb ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * rs32) * 4u : kBufOOB;
 #pragma unroll
             for (int q = 0; q < 4; q++) rr[q] = buf_load4(rs_r, (cb + 8 * q + 4 * kg < p.Cout) ? vo : kBufOOB, (unsigned)((cb + 8 * q) * rs32) * 4u);
@@ -491,7 +504,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
-    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, YIL ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, ESY));
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (YIL && !YF16) ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, ESY));
     auto epilogue = [&](auto ACT) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -500,7 +513,15 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
-            if constexpr (YIL) {
+            if constexpr (YIL && YF16) {
+                // (K/8, H, W, 8) fp16: the lane's 4 consecutive channels of the pixel as one 8-byte store (y_off = depth-slice offset in elements)
+                const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 8 + 4 * kg) * 2u : kBufOOB;
+                u32x2_t w2;
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    w2[e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * e]) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * e + 1]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b64(w2, rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 2u, 0);
+            } else if constexpr (YIL) {
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 4 + 4 * kg * cs32) * 4u : kBufOOB;
                 buf_store4(o, rs_y, vo, (unsigned)((cb + 8 * q) * cs32) * 4u);
             } else {

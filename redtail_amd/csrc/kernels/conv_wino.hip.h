@@ -105,6 +105,9 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const int nchunks = p.CinPad / CC;
     const int Ho = p.Ho, Wo = p.Wo;
     const int64_t ybase = (int64_t)n * p.y_bstride + p.y_off + (int64_t)zi * p.y_zstride;
+    // the residual has its own per-sample stride: it may be a channel range of a concatenated buffer (engine.cpp: foldConcats) while the
+    // output is a dense tensor -- round 3: with the output's stride, sample 1 of a batch read the wrong rows (exact-fp32 engines only)
+    const int64_t rbase = (int64_t)n * p.r_bstride + p.y_off + (int64_t)zi * p.y_zstride;
     const int act = p.act;
 
     // ---- staging roles: wave w gathers channels w*CPW .. of each chunk (NW = 8: one channel per wave) ----------
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cbase);      // bias is padded to 64 channels
     float rr[4][2][2];
     if (r_il) {
-        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, ybase, ESY), p.resid != nullptr);
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, rbase, ESY), p.resid != nullptr);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
                 for (int i = 0; i < 4; i++) rr[i][a][b] = v[i];
             }
     } else {
-        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, ybase, ESY), p.resid != nullptr);
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, rbase, ESY), p.resid != nullptr);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const unsigned so = (unsigned)((nblk * 32 + i) * cs32) * ESY;

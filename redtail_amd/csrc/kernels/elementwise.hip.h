@@ -55,4 +55,24 @@ __global__ void __launch_bounds__(256) ew_f16_kernel(const _Float16* __restrict_
     }
 }
 
+// max |x| and the count of elements outside [-limit, limit) or non-finite, over `rows` rows of `valid` leading elements (row pitch
+// `pitch`): the debug range check of the fp16-split domain (rt_check_range).  out[0] = bit pattern of max |x| (non-negative floats
+// order like unsigned integers; NaN / inf count as violations and as 0x7f800000), out[1] = violations (low 32 bits), out[2] = high.
+template <typename T>
+__global__ void __launch_bounds__(256) range_check_kernel(const T* __restrict__ x, int64_t rows, int64_t valid, int64_t pitch, float limit, unsigned* out) {
+    const int64_t n = rows * valid;
+    unsigned mx = 0;
+    unsigned long long bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / valid, c = i - r * valid;
+        const float v = fabsf((float)x[r * pitch + c]);
+        const bool finite = v < __builtin_inff();                  // false for inf and NaN
+        if (!finite || v >= limit) bad++;
+        const unsigned bits = finite ? __builtin_bit_cast(unsigned, v) : 0x7f800000u;
+        mx = bits > mx ? bits : mx;
+    }
+    if (mx) atomicMax(out, mx);
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), bad);
+}
+
 }  // namespace rt

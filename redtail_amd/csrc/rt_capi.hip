@@ -658,10 +658,27 @@ bool window_supported(int KH, int KW, int S) {
 //   registers (5 waves/SIMD), twice the workgroups;  {2,1,2}: smallest, for layers that cannot fill 256 CUs.
 // Measured on MI355X (tools/layer_profile.py): the whole network is fastest with one wave-tile per wave,
 // RT_CONV_VARIANT / RT_CONV_NBW override the heuristic for A/B measurements.
+// Development knobs (RT_* environment variables: A/B switches of tests, tools and DESIGN.md's measurements) are honoured ONLY when the
+// process opts in with RT_DEV_KNOBS=1 -- tests/conftest.py, tools/ and the profile scripts do; a stray RT_NO_FUSION in a user's
+// environment does not change what the shipped library computes.  Options a user may want are API: rtConv2dDesc::flags,
+// rt_conv_enqueue_hint, IBuilder / IExecutionContext setters, rtNetOptions.
+bool dev_knobs() {
+    static const bool on = [] { const char* e = getenv("RT_DEV_KNOBS"); return e && atoi(e) != 0; }();
+    return on;
+}
 int env_int(const char* name, int dflt) {
+    if (!dev_knobs()) return dflt;
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+// RT_CONV_EXACT_FP32 as an API option: set from the descriptor's flags for the duration of one *_plan_create call
+thread_local int tl_exact_fp32 = 0;
+int exact_fp32() { return tl_exact_fp32 || env_int("RT_CONV_EXACT_FP32", 0) != 0; }
+struct ExactScope {
+    int prev;
+    explicit ExactScope(int flags) : prev(tl_exact_fp32) { tl_exact_fp32 = (flags & RT_CONV_EXACT_FP32) ? 1 : prev; }
+    ~ExactScope() { tl_exact_fp32 = prev; }
+};
 
 void set_tile(SubConv& sc, int variant) {
     switch (variant) {
@@ -705,7 +722,7 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     // fp32 tensors on the fp16 matrix pipe (3-term split, conv_split.hip.h) for every window that kernel is built for;
     // RT_CONV_EXACT_FP32=1 keeps the fp32 fmaf-chain kernels
     const bool s3_win = (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
-    sc.split3 = (!sc.direct && s3_win && env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3", 0) == 0) ? 1 : 0;
+    sc.split3 = (!sc.direct && s3_win && !exact_fp32() && env_int("RT_NO_S3", 0) == 0) ? 1 : 0;
     if (sc.split3) {
         sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4;
         // 3x3 stride 1: 8-row tiles (8 waves, weights staged once per 8 rows, less halo) are built and opt-in (RT_S3_ROWS=8):
@@ -719,7 +736,7 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
 // share a CU with the other stream's / other contexts' launches, so the network is slower with it (1830 vs 2081 pairs/s).
 bool s3p_eligible(const SubConv& sc, int cin) {
     return !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && cin <= 32 && sc.Cout <= 32 && sc.nz == 1 &&
-           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_S3P", 0) != 0;
+           !exact_fp32() && env_int("RT_S3P", 0) != 0;
 }
 
 // conv_s3p_kernel's LDS image of the layer's weights: [tap][chunk of 16 ci][hi / lo][k-group of 8][co % 32][8 halfs]
@@ -747,7 +764,7 @@ int upload_s3p(SubConv& sc, int cin_real, F wfun) {
 // conv_s3_first_kernel: per 32-channel block the 10 A operands [r][hi / lo][k-half][co][8 halfs], k = 3*s + c
 bool s3first_eligible(const SubConv& sc, int cin, int has_resid) {
     return !sc.direct && sc.KH == 5 && sc.KW == 5 && sc.S == 2 && cin <= 3 && !has_resid && sc.nz == 1 &&
-           env_int("RT_CONV_EXACT_FP32", 0) == 0 && env_int("RT_NO_S3", 0) == 0;
+           !exact_fp32() && env_int("RT_NO_S3", 0) == 0;
 }
 template <typename F>
 int upload_s3first(SubConv& sc, int cin_real, F wfun) {
@@ -860,6 +877,7 @@ void free_plan(rtConvPlan* p) {
 }  // namespace
 
 extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, const void* weights, const void* bias) {
+    ExactScope exact_scope(d ? d->flags : 0);
     RT_REQUIRE(out && d && weights, "rt_conv2d_plan_create: null pointer");
     RT_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "rt_conv2d_plan_create: bad dims");
     RT_REQUIRE(d->dtype == RT_F32 || d->dtype == RT_F16, "rt_conv2d_plan_create: bad dtype");
@@ -914,12 +932,13 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
 // RT_E_UNSUPPORTED when the pair is not of that form -- the caller then plans the layers separately.
 extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1, const void* w1, const void* b1,
                                        const rtConv2dDesc* d2, const void* w2, const void* b2) {
+    ExactScope exact_scope((d1 ? d1->flags : 0) | (d2 ? d2->flags : 0));
     RT_REQUIRE(out && d1 && d2 && w1 && w2, "rt_resblock_plan_create: null pointer");
     const bool form = d1->KH == 3 && d1->KW == 3 && d2->KH == 3 && d2->KW == 3 && d1->stride == 1 && d2->stride == 1 &&
                       d1->pad_h == 1 && d1->pad_w == 1 && d2->pad_h == 1 && d2->pad_w == 1 && !d1->has_residual && d2->has_residual &&
                       d1->Cout == d2->Cin && d2->Cout == d1->Cin && d1->Hin == d2->Hin && d1->Win == d2->Win &&
                       d1->Cin <= 32 && d1->Cout <= 32 && d1->Cin > 2 && d1->Hin > 0 && d1->Win > 0;
-    if (!form || env_int("RT_CONV_EXACT_FP32", 0) != 0 || env_int("RT_NO_RB", 0) != 0)
+    if (!form || exact_fp32() || env_int("RT_NO_RB", 0) != 0)
         return fail(RT_E_UNSUPPORTED, "rt_resblock_plan_create: not a 3x3 / 3x3 stride-1 residual block with <= 32 channels");
     RT_REQUIRE((d1->dtype == RT_F32 || d1->dtype == RT_F16) && d1->dtype == d2->dtype, "rt_resblock_plan_create: bad dtype");
     RT_REQUIRE((int64_t)d1->Cin * d1->Hin * d1->Win < (1ll << 29), "rt_resblock_plan_create: input sample exceeds 2 GB");
@@ -967,6 +986,7 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
 }
 
 extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, const void* weights, const void* bias) {
+    ExactScope exact_scope(d ? d->flags : 0);
     RT_REQUIRE(out && d && weights, "rt_deconv2d_plan_create: null pointer");
     RT_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "rt_deconv2d_plan_create: bad dims");
     RT_REQUIRE(d->dtype == RT_F32 || d->dtype == RT_F16, "rt_deconv2d_plan_create: bad dtype");
@@ -1109,6 +1129,7 @@ int check_conv3d_desc(const rtConv3dDesc* d, const char* who) {
 }  // namespace
 
 extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, const void* weights, const void* bias) {
+    ExactScope exact_scope(d ? d->flags : 0);
     RT_REQUIRE(out && d && weights, "rt_conv3d_plan_create: null pointer");
     if (int rc = check_conv3d_desc(d, "rt_conv3d_plan_create")) return rc;
     const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
@@ -1183,6 +1204,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
 
 extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dDesc* d, const int in_dims[3],
                                                const void* weights, const void* bias) {
+    ExactScope exact_scope(d ? d->flags : 0);
     RT_REQUIRE(out && d && in_dims && weights, "rt_conv3d_transpose_plan_create: null pointer");
     if (int rc = check_conv3d_desc(d, "rt_conv3d_transpose_plan_create")) return rc;
     // fused epilogue layouts (executor only, see rt_stereo.h): keep the first out_depth output slices (Slice plugin)
@@ -1637,6 +1659,40 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
     SubConv& sc = plan->subs[0];
     RT_REQUIRE(!sc.rb || (x_il8 != 0) == (r_il8 != 0), "rt_conv_plan_set_layouts: a residual block's residual is its input tensor");
     sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
+    return 0;
+}
+
+extern "C" int rt_conv_plan_input_limit(const rtConvPlan* plan, float* limit) {
+    RT_REQUIRE(plan && limit, "rt_conv_plan_input_limit: null pointer");
+    bool f16_pipe = plan->rb_w1_dev != nullptr;
+    for (const SubConv& sc : plan->subs) f16_pipe = f16_pipe || sc.split3 || sc.s3first || sc.s3p || sc.rb || sc.x_f16 || sc.f16mma;
+    *limit = f16_pipe ? 65504.f : __builtin_inff();
+    return 0;
+}
+
+extern "C" int rt_check_range(const void* x, int64_t rows, int64_t valid, int64_t pitch, int dtype, float limit, float* max_abs, int64_t* violations,
+                              rtStream s) {
+    RT_REQUIRE(x && rows >= 0 && valid >= 0 && pitch >= valid && (dtype == RT_F32 || dtype == RT_F16), "rt_check_range: bad arguments");
+    unsigned* out = nullptr;
+    RT_HIP(hipMalloc((void**)&out, 16));
+    int rc = 0;
+    if (hipMemsetAsync(out, 0, 16, S(s)) != hipSuccess) rc = fail(RT_E_RUNTIME, "rt_check_range: memset failed");
+    const int64_t n = rows * valid;
+    if (!rc && n > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>(rt::cdiv(n, 256), 2048);
+        if (dtype == RT_F16) hipLaunchKernelGGL((rt::range_check_kernel<_Float16>), dim3(grid), dim3(256), 0, S(s), static_cast<const _Float16*>(x), rows, valid, pitch, limit, out);
+        else hipLaunchKernelGGL((rt::range_check_kernel<float>), dim3(grid), dim3(256), 0, S(s), static_cast<const float*>(x), rows, valid, pitch, limit, out);
+        if (hipGetLastError() != hipSuccess) rc = fail(RT_E_RUNTIME, "rt_check_range: launch failed");
+    }
+    unsigned host[4] = {0, 0, 0, 0};
+    if (!rc && (hipMemcpyAsync(host, out, 16, hipMemcpyDeviceToHost, S(s)) != hipSuccess || hipStreamSynchronize(S(s)) != hipSuccess))
+        rc = fail(RT_E_RUNTIME, "rt_check_range: read-back failed");
+    (void)hipFree(out);
+    if (rc) return rc;
+    float m;
+    std::memcpy(&m, &host[0], 4);
+    if (max_abs) *max_abs = m;
+    if (violations) *violations = (int64_t)(((unsigned long long)host[3] << 32) | host[2]);
     return 0;
 }
 

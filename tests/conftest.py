@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("RT_DEV_KNOBS", "1")      # the tests' A/B switches (RT_NO_FUSION, RT_RB, ...) are development knobs: opt in
 import os
 import sys
 

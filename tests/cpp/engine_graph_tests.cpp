@@ -237,6 +237,7 @@ void siamese(bool unequal) {
 }  // namespace
 
 int main() {
+    setenv("RT_DEV_KNOBS", "1", 1);       // RT_NO_FUSION / RT_SINGLE_STREAM / RT_NO_SIAMESE below are development knobs
     two_tower_concat();
     siamese(false);
     siamese(true);

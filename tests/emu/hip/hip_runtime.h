@@ -180,6 +180,9 @@ static inline void hipemu_buffer_load_lds(const hipemu::buffer_rsrc& r, void* ld
     }
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, size, voff, soff, off, aux) hipemu_buffer_load_lds(r, lds, size, (voff) + (off), soff)
+// atomics: fibers run one at a time, plain read-modify-write is atomic
+static inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -3,10 +3,13 @@ kernels, driven through include/rt_stereo_net.h) against the oracle's op-for-op 
 reference's generated networks.  BASELINE tolerance: 1e-3 abs on the network's raw `disp` output.
 CPU tier: tiny images on the SIMT emulator; GPU tier (-m gpu): the real sizes incl. 1257x369."""
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import stereo_oracle as O
 from redtail_amd import build, capi, model_files
@@ -537,3 +540,90 @@ def test_resnet18_2d_interleaved_equals_planar(rt, monkeypatch):
     planar, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
     assert n1 == n2
     assert np.abs(il - planar).max() <= 2e-6         # bit-identical convolutions; the correlation kernel differs (see above)
+
+
+def test_development_knobs_need_opt_in(tmp_path):
+    """RT_* environment switches (RT_NO_FUSION, RT_RB, ...) are honoured only with RT_DEV_KNOBS=1 -- what this test session sets in
+    conftest.py; a process without it builds the default engine whatever its environment says"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from redtail_amd import build, capi, synth\n"
+            "lib = capi.NetLib(build.build_host_emu(), build.build_emu())\n"
+            "net = lib.create('resnet18_2D', 41, 25, weights=synth.synth_weights_resnet18_2d(), max_disp=8)\n"
+            "print('LAUNCHES', net.num_launches)\n" % ROOT)
+    counts = {}
+    for dev in ("0", "1"):
+        env = dict(os.environ, RT_NO_FUSION="1", RT_DEV_KNOBS=dev)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        counts[dev] = int(out.stdout.split("LAUNCHES")[1].split()[0])
+    assert counts["0"] == 48 - 15 and counts["1"] > 100, counts      # ignored / honoured (one launch per layer)
+
+
+def test_exact_fp32_is_an_api_option(rt, monkeypatch):
+    """rtNetOptions.flags = RT_CONV_EXACT_FP32 (IBuilder::setExactFp32Mode): the engine of the RT_CONV_EXACT_FP32=1 development knob,
+    bit for bit, without touching the environment; no residual block is fused and the result is within fp32 roundoff of the default"""
+    from redtail_amd import capi
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 25, 41)         # batch 2: the residual of the left tower's first block is a channel range of the folded concatenation
+                                    # with its own per-sample stride (round 3: the Winograd kernel read it with the output's)
+
+    def run(**kw):
+        net = rt.lib.create("resnet18_2D", 41, 25, max_batch=2, weights=w, max_disp=8, **kw)
+        out = rt.empty(2, 1, 25, 41)
+        net.execute(rt.dev(l), rt.dev(r), out, 2)
+        res = np.array(rt.host(out))
+        net.destroy()
+        return res
+    base = run()
+    opt = run(flags=capi.RT_CONV_EXACT_FP32)
+    monkeypatch.setenv("RT_CONV_EXACT_FP32", "1")
+    knob = run()
+    assert np.array_equal(opt, knob)
+    assert not np.array_equal(opt, base) and np.abs(opt - base).max() <= 2e-5
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w, max_disp=8).numpy()
+    assert np.abs(opt - ref).max() <= 2e-4
+
+
+def test_debug_mode_reports_the_fp16_split_domain(rt):
+    """|x| >= 65504 overflows the fp16 split (conv_split.hip.h): the default path then produces inf / NaN -- loud but far from the
+    cause.  In debug mode (rt_net_set_debug, IExecutionContext::setDebugSync) execute() fails at the first such launch with its name;
+    the exact-fp32 engine has no such domain.  Also rt_check_range / rt_conv_plan_input_limit at the operator level."""
+    from redtail_amd import capi
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 25, 41)
+    big = l.copy()
+    big[0, 1, 5, 7] = 7e4                                     # one pixel just outside the fp16 range
+    net = rt.lib.create("resnet18_2D", 41, 25, weights=w, max_disp=8)
+    out = rt.empty(1, 1, 25, 41)
+    net.execute(rt.dev(big), rt.dev(r), out, 1)               # default: runs, and the damage is visible
+    assert not np.isfinite(np.array(rt.host(out))).all()
+    net.set_debug(True)
+    net.execute(rt.dev(l), rt.dev(r), out, 1)                 # in-domain input passes the checks
+    assert np.isfinite(np.array(rt.host(out))).all()
+    with pytest.raises(capi.RtError) as e:
+        net.execute(rt.dev(big), rt.dev(r), out, 1)
+    assert "left_conv1" in str(e.value) and "fp16-split" in str(e.value), str(e.value)
+    net.destroy()
+    exact = rt.lib.create("resnet18_2D", 41, 25, weights=w, max_disp=8, flags=capi.RT_CONV_EXACT_FP32)
+    exact.set_debug(True)
+    exact.execute(rt.dev(big), rt.dev(r), out, 1)             # no such domain: passes the (vacuous) checks and matches the oracle
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(big), torch.from_numpy(r), w, max_disp=8).numpy()
+    got = np.array(rt.host(out))
+    assert np.isfinite(ref).all() and np.isfinite(got).all() and np.abs(got - ref).max() <= 1e-3
+    exact.destroy()
+    # operator level
+    k = rt.lib.kernels
+    x = np.zeros((3, 10), np.float32)
+    x[:, :8] = np.arange(24, dtype=np.float32).reshape(3, 8)
+    x[:, 8:] = np.nan                                         # row padding is not looked at
+    x[1, 3] = -70000.0
+    mx, bad = k.check_range(rt.dev(x), 3, 8, 10)
+    assert bad == 1 and mx == 70000.0
+    x[2, 0] = np.inf
+    assert k.check_range(rt.dev(x), 3, 8, 10)[1] == 2
+    wt = np.zeros((4, 4, 3, 3), np.float32)
+    assert k.conv2d_plan(wt, None, 4, 4, 9, 9, 3, 1, 1).input_limit() == 65504.0
+    assert k.conv2d_plan(wt, None, 4, 4, 9, 9, 3, 1, 1, flags=capi.RT_CONV_EXACT_FP32).input_limit() == float("inf")

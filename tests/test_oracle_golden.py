@@ -142,3 +142,22 @@ def test_softargmin_batch2(golden):                     # :1056-1077
 
 def test_softargmax_basic(golden):                      # :1079-1099
     assert_near(O.softargmax(T(golden["softargmax_03_x"]), False), golden["softargmax_03_y"], 2e-6)
+
+
+def test_corr_cpu_c_restatement(golden):
+    """oracle/corr_cpu.c -- the plain C loop of lib/kernels.cu:168-200 that tools/bench_ops.py times as the op-level CPU baseline --
+    against the reference's golden cost volume (corr_cost_vol_01, tests_main.cpp EXPECT_NEAR 1e-5... here 1e-6) and the torch oracle"""
+    import ctypes
+    from redtail_amd import build
+    lib = ctypes.CDLL(build.build_oracle_c())
+    l, r, want = golden["corr_cost_vol_01_l"], golden["corr_cost_vol_01_r"], golden["corr_cost_vol_01_cv"]
+    l, r = np.ascontiguousarray(l, np.float32), np.ascontiguousarray(r, np.float32)
+    c, h, w = l.shape[-3:]
+    n = int(np.prod(l.shape[:-3]))
+    d = want.shape[1]                                       # (1, D, 1, H, W)
+    out = np.empty((n, d, h, w), np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.corr_cost_volume_cpu(l.ctypes.data_as(fp), r.ctypes.data_as(fp), n, c, h, w, d, out.ctypes.data_as(fp))
+    assert np.abs(out[:, :, None] - want).max() <= 1e-6
+    ref = O.corr_cost_volume(T(l).reshape(n, c, h, w), T(r).reshape(n, c, h, w), d).numpy()
+    assert np.abs(out - ref).max() <= 1e-6

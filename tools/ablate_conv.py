@@ -4,6 +4,7 @@ kernel compiled out (RT_ABLATE mask, see conv_mfma.hip.h).  `build` cross-compil
 `run` times them (GPU box)."""
 import ctypes
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -9,6 +9,7 @@ import argparse
 import ctypes
 import json
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 import numpy as np
@@ -103,6 +104,27 @@ def main():
         if want("corr"):
             t = timeit(lambda: k.corr_cost_volume(l, r, cv, b, C, H, W, D))
             report("corr cost volume C32 D48 @185x629 b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + D) * H * W)
+            if b == 1:
+                # the op-level CPU baseline of BASELINE.md section 2: the reference's kernel as a plain single-thread C loop
+                # (oracle/corr_cpu.c restates lib/kernels.cu:168-200), same tensors, one core, result checked against the GPU's
+                from redtail_amd import build
+                import time
+                lib = ctypes.CDLL(build.build_oracle_c())
+                lh, rh = l.cpu().numpy(), r.cpu().numpy()
+                ch = np.empty((1, D, H, W), np.float32)
+                fp = ctypes.POINTER(ctypes.c_float)
+                args_ = (lh.ctypes.data_as(fp), rh.ctypes.data_as(fp), 1, C, H, W, D, ch.ctypes.data_as(fp))
+                lib.corr_cost_volume_cpu(*args_)
+                n_, t0_ = 0, time.perf_counter()
+                while n_ < 2 or time.perf_counter() - t0_ < 3.0:
+                    lib.corr_cost_volume_cpu(*args_)
+                    n_ += 1
+                tc = (time.perf_counter() - t0_) / n_
+                err = float(np.abs(cv.cpu().numpy() - ch).max())
+                print("%-46s %9.1f us  (%d runs, 1 core, plain C restatement of corrCostVolumeKernel; GPU / CPU = %.0fx; max |GPU - CPU| = %.2g)" % (
+                    "  CPU corr cost volume C32 D48 @185x629 b1", tc * 1e6, n_, tc / t, err))
+                results.append(dict(name="cpu corr cost volume C32 D48 @185x629 b1 (oracle/corr_cpu.c, 1 core)", us=tc * 1e6, kind="port", cores=1,
+                                    max_abs_diff_vs_gpu=err))
             t = timeit(lambda: k.corr_softargmax(l, r, sa, b, C, H, W, D, False))
             report("corr+softargmax fused b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
         if want("softargmax"):

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_DEV_KNOBS=1      # the RT_* switches below are development knobs (see rt_capi.hip: dev_knobs)
 # Everything profiles/ is made of, in one gpurun call (see profiles/README.md):
 #   gpurun -- 'bash tools/collect_profiles.sh r02p' ; python tools/summarize_profiles.py gpurun_out/r02p r02
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-prof}

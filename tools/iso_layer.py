@@ -6,6 +6,7 @@ residual block, launched back to back on an idle GPU.  For rocprofv3 passes (too
 """
 import ctypes
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Per-launch times of ResNet-18 2D at 1257x369 through the executor's IProfiler path (production
 two-stream schedule).  RT_CONV_VARIANT selects the conv tile variant."""
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_DEV_KNOBS=1      # the RT_* switches below are development knobs (see rt_capi.hip: dev_knobs)
 # Hardware-counter passes over the dominant convolution alone (tools/bench_ops.py, one counter group per run).
 #   tools/pmc_conv.sh <outdir> [bench_ops --only filter]
 OUT=${1:-/root/repo/gpurun_out/pmc_conv}; FILTER=${2:-"+res+ELU b8"}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_DEV_KNOBS=1      # the RT_* switches below are development knobs (see rt_capi.hip: dev_knobs)
 # Hardware-counter passes over the dominant layer alone (tools/iso_layer.py), one counter group per run.
 #   tools/pmc_layer.sh <outdir> <conv|block> [kernel-name filter]
 OUT=${1:-$GRAFT_REPO_ROOT/gpurun_out/pmc_layer}; KIND=${2:-conv}; FILTER=${3:-conv_s3}

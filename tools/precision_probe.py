@@ -2,6 +2,7 @@
 """Where does the end-to-end error of a deep 3-D model come from?  Compares the GPU result (Winograd on / off) and the
 fp32 oracle against an fp64 evaluation of the same graph (ResNet-18 3D, 1025x321, synthetic weights)."""
 import os, sys, time
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import stereo_oracle as O

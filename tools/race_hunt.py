@@ -9,6 +9,7 @@ creation), so each configuration runs in its own process:
 """
 import json
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import subprocess
 import sys
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RT_DEV_KNOBS=1      # the RT_* switches below are development knobs (see rt_capi.hip: dev_knobs)
 # CPU test tier under sanitizers (test infrastructure; run from the repo root, no GPU needed):
 #   1. the HIP kernel sources on the SIMT emulator, compiled with UB checks in trap mode (signed overflow, shifts,
 #      bounds, null, division by zero, bool/enum loads): any hit kills the test run with SIGILL;

@@ -2,6 +2,7 @@
 """Per-phase timing of conv_mfma_f32_kernel on the 3x3 32->32 @185x629 layer (s_memtime stamps of
 thread 0 of every workgroup; instrumented library built by redtail_amd.build.build_hip_timing)."""
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 import numpy as np

@@ -4,6 +4,7 @@ workgroup; instrumented library from redtail_amd.build.build_hip_timing).  RT_S3
 instead of the general one (one workgroup per 4x32 tile)."""
 import ctypes
 import os
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 import sys
 
 import numpy as np

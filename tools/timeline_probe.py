@@ -1,4 +1,5 @@
 import os, sys, numpy as np, torch
+os.environ.setdefault("RT_DEV_KNOBS", "1")      # the RT_* switches this tool uses are development knobs
 sys.path.insert(0, '/root/repo')
 from redtail_amd import capi, synth
 lib = capi.NetLib()
