@@ -449,6 +449,7 @@ private:
     void foldConcats();
     void foldCostVolumes();
     void assignHalf3D();
+    void assignInterleaved3D();
     void fuseResBlocks();
     void mergeSiamese();
     bool ok_ = false;
@@ -508,6 +509,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) foldConcats();
     if (ok_) foldCostVolumes();
     if (ok_) assignHalf3D();
+    if (ok_) assignInterleaved3D();
     if (ok_) mergeSiamese();
     if (ok_) assignStreams();           // final: the passes above removed and merged ops (waits and publish flags are recomputed)
     if (ok_) planIssueOrder();
@@ -1313,6 +1315,49 @@ void EngineImpl::assignHalf3D() {
         clear(op.out);
         clear(op.resid);
     }
+    // The two feature maps of a folded cost volume ((2F, H, W) buffer [left | right], foldCostVolumes): when the tower launches that
+    // write them can store fp16, channel-interleaved (2F/8, H, W, 8), the first Conv3D gathers 16-byte slots of fp16 operands
+    // (conv_f16mma_kernel with the x-shift table) instead of fp32 planes it has to split: 1.18 -> 0.6 ms for NVSmall's conv3D_1.
+    struct Feat { int tensor; size_t conv3d; std::vector<size_t> producers; };
+    std::vector<Feat> feats;
+    if (!knob("RT_NO_IL8") && !knob("RT_NO_IL8_3D") && !knob("RT_NO_F16_FEAT"))
+        for (size_t ci = 0; ci < ops_.size(); ci++) {
+            const Op& cv = ops_[ci];
+            if (cv.kind != OpKind::kConv3D || !cv.splugin->fusion().cv_fold) continue;
+            const int x = root(cv.in[0]);
+            TensorImpl& ft = *tensors_[x];
+            if (ft.dims.nbDims != 3 || ft.f16 || ft.il8 || ft.pitch || ft.dims.d[0] % 16 != 0) continue;
+            Feat f{x, ci, {}};
+            bool ok = true;
+            for (size_t i = 0; i < ops_.size() && ok; i++) {
+                const Op& op = ops_[i];
+                if (i == ci) continue;
+                bool reads = op.resid >= 0 && root(op.resid) == x;
+                for (int t : op.in) reads = reads || root(t) == x;
+                if (reads) ok = false;                                  // only the Conv3D reads the maps
+                if (root(op.out) == x) { ok = ok && op.kind == OpKind::kConv && !op.twin; f.producers.push_back(i); }
+            }
+            if (!ok || f.producers.size() != 2) continue;
+            size_t done = 0;
+            for (; done < f.producers.size(); done++) {
+                Op& p = ops_[f.producers[done]];
+                const TensorImpl& pin = *tensors_[root(p.in[0])];
+                if (rt_conv_plan_set_io_types(p.plan, pin.f16 ? RT_F16 : RT_F32, RT_F16) != 0 || !(rt_conv_plan_supports_il8(p.plan) & 2) ||
+                    rt_conv_plan_set_layouts(p.plan, pin.il8, 1, 0) != 0)
+                    break;
+            }
+            if (done != f.producers.size()) {                            // not every producer can: back to fp32 planar maps
+                for (size_t k = 0; k <= done && k < f.producers.size(); k++) {
+                    Op& p = ops_[f.producers[k]];
+                    const TensorImpl& pin = *tensors_[root(p.in[0])];
+                    rt_conv_plan_set_io_types(p.plan, pin.f16 ? RT_F16 : RT_F32, RT_F32);
+                    rt_conv_plan_set_layouts(p.plan, pin.il8, 0, 0);
+                }
+                continue;
+            }
+            h[x] = 1;
+            feats.push_back(f);
+        }
     for (bool changed = true; changed;) {
         changed = false;
         for (auto& op : ops_) {
@@ -1335,9 +1380,82 @@ void EngineImpl::assignHalf3D() {
             op.splugin->setIoTypes(h[x] != 0, h[y] != 0);
             n += h[y] != 0;
         }
+    for (const Feat& f : feats) {
+        if (h[f.tensor]) {                                               // the maps are fp16, interleaved: so are the tensors that alias into them
+            for (auto& t : tensors_)
+                if (t->id == f.tensor || (t->alias_of >= 0 && root(t->id) == f.tensor)) { t->f16 = true; t->il8 = true; }
+            log_.log(ILogger::Severity::kINFO, ("half2 mode: " + ops_[f.conv3d].name + " reads the two feature maps as fp16, channel-interleaved").c_str());
+            continue;
+        }
+        for (size_t i : f.producers) {                                   // the Conv3D could not take them: the producers write fp32 again
+            Op& p = ops_[i];
+            const TensorImpl& pin = *tensors_[root(p.in[0])];
+            rt_conv_plan_set_io_types(p.plan, pin.f16 ? RT_F16 : RT_F32, RT_F32);
+            rt_conv_plan_set_layouts(p.plan, pin.il8, 0, 0);
+        }
+    }
     for (auto& t : tensors_)
-        if (h[t->id]) t->f16 = true;
+        if (h[t->id] && t->dims.nbDims == 4) t->f16 = true;
     if (n) log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n) + " Conv3D / Conv3DTranspose launches write fp16 tensors").c_str());
+}
+
+// half2 mode of the 3-D models, continued: the fp16 4-D tensors in depth-major form (D, C, H, W) are stored channel-interleaved,
+// (D, C/8, H, W, 8) -- one 16-byte slot per pixel and group of 8 channels, as the 2-D fp16 tensors of the towers are (assignPitch).
+// A Conv3D between two such tensors then runs on fp16 operands (conv_f16mma_kernel: one 16-byte load per pixel and channel group
+// instead of eight 2-byte loads, 8-byte stores instead of four 2-byte ones: 0.36 vs 0.54 ms for the 32 -> 32 layer of NVSmall
+// as a 2-D proxy, tools/dev/il_probe_f16.py); the folded-cost-volume Conv3D writes one; a fused Conv3DTranspose reads its skip
+// tensor that way.  Which tensors qualify follows from the launches' own capabilities (IStereoPlugin::ilCaps).
+void EngineImpl::assignInterleaved3D() {
+    if (!half2_ || knob("RT_NO_F16") || knob("RT_NO_F16_3D") || knob("RT_NO_IL8") || knob("RT_NO_IL8_3D")) return;
+    std::vector<char> il(tensors_.size(), 0);
+    for (auto& t : tensors_) il[t->id] = t->f16 && t->dims.nbDims == 4 && !t->is_input && !t->is_output && t->alias_of < 0 && t->twin_of < 0 && !t->has_twin;
+    for (auto& op : ops_) {
+        if (op.kind == OpKind::kConv3D) continue;
+        for (int i : op.in) il[root(i)] = 0;
+        il[root(op.out)] = 0;
+        if (op.resid >= 0) il[root(op.resid)] = 0;
+    }
+    std::vector<char> fixed(tensors_.size(), 0);        // fp16 interleaved feature maps of a folded cost volume (assignHalf3D): decided already
+    for (auto& op : ops_)
+        if (op.kind == OpKind::kConv3D && op.splugin->fusion().cv_fold) {
+            const int x = root(op.in[0]);
+            if (tensors_[x]->f16 && tensors_[x]->il8) il[x] = fixed[x] = 1;
+        }
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (auto& op : ops_) {
+            if (op.kind != OpKind::kConv3D) continue;
+            const int caps = op.splugin->ilCaps();
+            const int x = root(op.in[0]), y = root(op.out), r = op.resid >= 0 ? root(op.resid) : -1;
+            auto drop = [&](int t) {
+                if (t < 0 || !il[t]) return;
+                if (fixed[t]) { log_.log(ILogger::Severity::kERROR, (op.name + ": cannot read the interleaved fp16 feature maps").c_str()); ok_ = false; return; }
+                il[t] = 0;
+                changed = true;
+            };
+            if (!(caps & 1)) drop(x);
+            if (!(caps & 2)) drop(y);
+            if (!(caps & 4)) drop(r);
+            if ((caps & 8) && !il[x]) drop(y);          // this launch writes an interleaved tensor only when it reads one
+        }
+    }
+    int n = 0;
+    for (auto& op : ops_) {
+        if (op.kind != OpKind::kConv3D) continue;
+        const int x = root(op.in[0]), y = root(op.out), r = op.resid >= 0 ? root(op.resid) : -1;
+        const bool xi = il[x] != 0, yi = il[y] != 0, ri = r >= 0 && il[r] != 0;
+        if (!(xi || yi || ri)) continue;
+        if (!op.splugin->setLayouts(xi, yi, ri)) {
+            log_.log(ILogger::Severity::kERROR, (op.name + ": " + rt_last_error_string()).c_str());
+            ok_ = false;
+            return;
+        }
+        n += yi;
+    }
+    if (!ok_) return;
+    for (auto& t : tensors_)
+        if (il[t->id]) t->il8 = true;
+    if (n) log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n) + " Conv3D launches write channel-interleaved (D, C/8, H, W, 8) tensors").c_str());
 }
 
 // Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the

@@ -41,6 +41,10 @@ public:
     virtual ConvFusion fusion() const { return ConvFusion(); }
     // half2 mode: store the 3-D input / output (+ residual) tensors as fp16 (kept across setFusion)
     virtual bool setIoTypes(bool, bool) { return false; }
+    // ... and which of them may be channel-interleaved, (D, C/8, H, W, 8) (rt_conv_plan_supports_il8: bit 0 input, 1 output, 2 residual,
+    // 3 = output only together with the input), and their layouts (kept across setFusion)
+    virtual int ilCaps() const { return 0; }
+    virtual bool setLayouts(bool, bool, bool) { return false; }
     virtual int enqueueFused(int, const void*, void*, const void*, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}
 };

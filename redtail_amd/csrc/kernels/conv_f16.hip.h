@@ -120,6 +120,8 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
     unsigned voff[NV];
     bool odd_ok[NV];         // the pair's second pixel is inside the row (columns >= Wi of a pitched row hold anything)
     int lidx[NV];
+    int xcol[NV];            // interleaved input: image column of the slot (folded cost volume: a channel group may be read shifted)
+    const int* __restrict__ shtab = p.ch_shift ? p.ch_shift + (int64_t)ch_row * p.CinPad + 8 * g : nullptr;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         if constexpr (XIL8) {
@@ -129,6 +131,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
             const bool own = pidx < Cfg::NPIX;
             voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB;
             odd_ok[k] = false;
+            xcol[k] = ix;
             lidx[k] = own ? (pr * 2 + g) * PCA + dcol + pc : -1;
         } else {
             const int q = spart * (NKT * 64) + lane + 64 * k;
@@ -137,6 +140,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
             const bool own = q < Cfg::TG;
             voff[k] = (own && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * ES : kBufOOB;
             odd_ok[k] = ix + 1 < p.Wi;
+            xcol[k] = ix;
             lidx[k] = own ? (pr * 2 + g) * PCA + 2 * qc : -1;
         }
     }
@@ -157,9 +161,14 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
             const int off = tab[ch * CC];                          // group offset == planar offset of its first channel
             const buf_rsrc rs = make_buf(xb, off >= 0);
             const unsigned so = (unsigned)off * ES;
+            // folded default cost volume (rtConv3dDesc::cv_fold): the right-image channel groups of depth slice d are read at column
+            // x - d and are zero for x < d (lib/kernels.cu:72-97); one shift per group of 8 channels, wave-uniform
+            const int sh = shtab ? shtab[ch * CC] : 0;
 #pragma unroll
-            for (int k = 0; k < NV; k++)
-                rin[k] = kAblGather ? f32x4{(float)(off + (int)voff[k]), 0.f, 0.f, 0.f} : buf_load4(rs, voff[k], so);
+            for (int k = 0; k < NV; k++) {
+                const unsigned vo = sh == 0 ? voff[k] : ((voff[k] != kBufOOB && xcol[k] >= sh) ? voff[k] - (unsigned)sh * 16u : kBufOOB);
+                rin[k] = kAblGather ? f32x4{(float)(off + (int)voff[k]), 0.f, 0.f, 0.f} : buf_load4(rs, vo, so);
+            }
         } else {
             unsigned u[NKT][8];  // channel e of the chunk's group: pixel 0 in the low half, pixel 1 in the high half
 #pragma unroll

@@ -307,9 +307,9 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     constexpr bool XF16 = std::is_same<TIN, _Float16>::value, YF16 = std::is_same<TOUT, _Float16>::value;
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
     // interleaved INPUT tensors are fp32 here (fp16 ones go through conv_f16mma_kernel); an interleaved OUTPUT may also be fp16,
-    // (K/8, H, W, 8): the first Conv3D of a 3-D model in half2 mode (fp32 feature maps in, fp16 volume out)
+    // (K/8, H, W, 8): the last layer of a feature tower of a 3-D model in half2 mode (fp32 tower tensors in, fp16 feature map out)
+    // and the first Conv3D when the feature maps stay fp32
     static_assert(!XIL || !XF16, "interleaved fp16 input: conv_f16mma_kernel");
-    static_assert(!(YIL && YF16) || !XIL, "fp16 interleaved output is built for planar input");
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
 

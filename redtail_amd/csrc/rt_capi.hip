@@ -498,6 +498,9 @@ struct rtConvPlan {
     float* rb_bias1_dev = nullptr;
     int rb_act1 = 0, rb_cmid = 0;
     int w_f16 = 0;                                // the weights were given as fp16 (trt_weights_fp16.bin)
+    // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
+    int is_conv3d = 0, is_deconv3d = 0;
+    int c3d_C = 0, c3d_cin = 0, c3d_dchw = 0, c3d_fold = 0;
 };
 
 namespace {
@@ -1088,6 +1091,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             z.ch_row = 0;
             z.y_off = (int64_t)py * Wo + px;
             z.r_off = z.y_off;
+            z.r_off_il8 = 8 * z.y_off;                 // 2-D phases: the offset is a pixel offset
             z.tap_mask = 0;
             for (int u = 0; u < ay.K; u++)
                 for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
@@ -1193,6 +1197,8 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
             rc = fail(RT_E_NOMEM, "conv3d: device allocation failed");
     }
     plan->subs.push_back(sc);
+    plan->is_conv3d = 1; plan->c3d_C = C; plan->c3d_cin = cin_real; plan->c3d_dchw = d->out_dchw != 0; plan->c3d_fold = F;
+    plan->w_canon = w;                                         // (K, V*C, R, S): re-packed when the plan switches to fp16 operands
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, K, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, K);
@@ -1337,6 +1343,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
                     for (int u = 0; u < ay.K; u++)
                         for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
                     z.r_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
+                    z.r_off_il8 = (int64_t)(cls + m * sd) * C * out_plane + 8 * ((int64_t)py * Wx + px);      // (D, C/8, H, W, 8) fp16 skip tensor
                     z.y_off = cdhw ? (int64_t)(cls + m * sd) * out_plane + (int64_t)py * Wx + px : z.r_off;
                     z.w_off = w_offs[iph++];
                     zs.push_back(z);
@@ -1356,6 +1363,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
         if (!rc) rc = upload_table(sc, table);
         plan->subs.push_back(sc);
     }
+    plan->is_deconv3d = 1; plan->c3d_C = C;
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, C);
@@ -1388,7 +1396,7 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
         sc.y_cstride = (int64_t)Hout * op;
         sc.y_off = repitch(sc.y_off);
         if (!sc.zs_host.empty()) {
-            for (auto& z : sc.zs_host) { z.y_off = repitch(z.y_off); z.r_off = z.y_off; }
+            for (auto& z : sc.zs_host) { z.y_off = repitch(z.y_off); z.r_off = z.y_off; z.r_off_il8 = 8 * z.y_off; }
             RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
         }
     }
@@ -1555,6 +1563,33 @@ int repack_f32(rtConvPlan* plan) {
     return upload_table(sc, table);
 }
 
+// Conv3D in half2 mode: both 4-D tensors fp16 -> conv_f16mma_kernel (fp16 operands, one MFMA per tap, channel-interleaved tensors
+// (D, C/8, H, W, 8) welcome) instead of the split kernel reading and writing planar 2-byte elements.  Same gather table (the offset of
+// channel group c/8 of depth d equals the planar offset of channel c), same tiling; the weights are re-packed from the plan's copy.
+int switch_conv3d_f16mma(rtConvPlan* plan, bool on) {
+    SubConv& sc = plan->subs[0];
+    if ((sc.f16mma != 0) == on) return 0;
+    const int cin_real = plan->c3d_cin, taps = sc.KH * sc.KW;
+    const std::vector<float>& w = plan->w_canon;
+    auto wfun = [&](int co, int ci, int u, int v) { return w[((size_t)co * cin_real + ci) * taps + u * sc.KW + v]; };
+    if (sc.w_dev) (void)hipFree(sc.w_dev);
+    sc.w_dev = nullptr;
+    if (on) {
+        std::vector<uint16_t> packed;
+        pack_f16_into(packed, sc, cin_real, wfun);
+        RT_HIP(hipMalloc((void**)&sc.w_dev, packed.size() * 2));
+        RT_HIP(hipMemcpy(sc.w_dev, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        sc.split3 = 0; sc.f16mma = 1;
+    } else {
+        sc.f16mma = 0; sc.split3 = 1;
+        sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
+        std::vector<float> packed;
+        pack_into(packed, sc, cin_real, wfun);
+        if (int rc = upload_weights(sc, packed)) return rc;
+    }
+    return 0;
+}
+
 bool f16mma_window(const SubConv& sc) {
     return (sc.KH == 3 && sc.KW == 3 && (sc.S == 1 || sc.S == 2)) || (sc.S == 1 && sc.KH <= 2 && sc.KW <= 2);
 }
@@ -1569,17 +1604,29 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
     if (!plan->is2d) {
         // 3-D plans (Conv3D / Conv3DTranspose): fp16 storage of the dense (D,C,H,W) / (K,D,H,W) tensors, the split-fp16 kernel
         // reads / writes them as they are (an fp16 input is its own high part); the small-output last layer reads fp16, writes fp32
+        // (a Conv3D whose INPUT is then declared channel-interleaved -- rt_conv_plan_set_layouts -- moves to fp16 operands,
+        //  conv_f16mma_kernel; a change of the storage types takes it back to the split kernel and planar tensors first)
+        const bool both = x_dtype == RT_F16 && y_dtype == RT_F16;
+        if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
+            if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
         for (SubConv& sc : plan->subs) {
-            const bool ok = sc.small3d ? (sc.small3d == 1 && y_dtype == RT_F32) : (sc.split3 && !sc.x_il8 && !sc.y_il8 && !sc.r_il8);
+            // (an fp16 input with an fp32 output has no kernel: ADVICE r02 -- say so here, not at the first enqueue)
+            const bool ok = sc.small3d ? (sc.small3d == 1 && y_dtype == RT_F32) : (sc.f16mma ? both : (sc.split3 && (y_dtype == RT_F16 || x_dtype == RT_F32)));
             if (!ok && (x_dtype == RT_F16 || y_dtype == RT_F16))
-                return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: this 3-D plan has no fp16-storage kernel (window %dx%d stride %d)", sc.KH, sc.KW, sc.S);
+                return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: this 3-D plan has no kernel for %s input and %s output (window %dx%d stride %d)",
+                            x_dtype == RT_F16 ? "fp16" : "fp32", y_dtype == RT_F16 ? "fp16" : "fp32", sc.KH, sc.KW, sc.S);
         }
-        for (SubConv& sc : plan->subs) { sc.x_f16 = x_dtype == RT_F16; sc.y_f16 = y_dtype == RT_F16; }
+        for (SubConv& sc : plan->subs) {
+            sc.x_f16 = x_dtype == RT_F16; sc.y_f16 = y_dtype == RT_F16;
+            if (!sc.y_f16) sc.y_il8 = sc.r_il8 = 0;            // interleaved 3-D tensors are fp16 ones
+            if (!sc.x_f16) sc.x_il8 = 0;
+        }
         return 0;
     }
     const int xf = x_dtype == RT_F16, yf = y_dtype == RT_F16;
     const int op = plan->out_pitch ? plan->out_pitch : plan->out_dims[2];
-    RT_REQUIRE(!yf || (op & 1) == 0, "rt_conv_plan_set_io_types: fp16 output rows need an even pitch (got %d)", op);
+    const bool s3_f32_to_f16 = !xf && yf && plan->subs.size() == 1 && plan->subs[0].split3;      // single 2-byte / interleaved 8-byte stores: any pitch
+    RT_REQUIRE(!yf || s3_f32_to_f16 || (op & 1) == 0, "rt_conv_plan_set_io_types: fp16 output rows need an even pitch (got %d)", op);
     for (SubConv& sc : plan->subs) {
         if (!xf && !yf) {
             // a plan that was switched to fp16 operands holds fp16 weight slabs and the fp16 tiling: restore the fp32 form
@@ -1610,6 +1657,12 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
+        // fp32 in, fp16 out on the split kernel (3x3 stride 1): the last layer of a feature tower of a 3-D model in half2 mode writes the
+        // fp16 feature map the folded-cost-volume Conv3D reads (conv_s3_kernel<.., float, _Float16>)
+        if (sc.split3 && !xf && yf && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && !plan->is_deconv && !plan->has_resid && sc.TY == 4) {
+            sc.x_f16 = 0; sc.y_f16 = 1;
+            continue;
+        }
         if (sc.s3p || sc.split3 || sc.s3first || sc.rb) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
@@ -1623,10 +1676,36 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
 // Channel-interleaved tensors (see conv_wino.hip.h / conv_f16.hip.h): which of a plan's tensors can have the layout --
 // bit 0 input, bit 1 output, bit 2 residual; 0 = none ...
 extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
-    if (!plan || !plan->is2d || plan->subs.size() != 1) return 0;
+    if (!plan) return 0;
+    if (!plan->is2d) {
+        // 3-D plans, half2 mode: fp16 tensors in depth-major form (D, C, H, W) may be stored (D, C/8, H, W, 8).  Conv3D on fp16
+        // operands reads and (with the fused Transform, out_dchw) writes them; the folded-cost-volume Conv3D (fp32 maps in) writes
+        // one; a fused Conv3DTranspose reads its skip tensor that way.  Channel-major (K, D, H, W) tensors stay planar.
+        if (env_int("RT_NO_IL8", 0) != 0 || env_int("RT_NO_IL8_3D", 0) != 0 || plan->subs.empty()) return 0;
+        const SubConv& sc = plan->subs[0];
+        if (plan->is_conv3d && plan->subs.size() == 1) {
+            const int out = (plan->c3d_dchw && sc.Cout % 8 == 0) ? 2 : 0;
+            // both tensors fp16: conv_f16mma_kernel once the input is interleaved (its planar gathers move 4-byte pixel pairs, which the
+            // odd plane sizes of dense 4-D tensors misalign) -- bit 3: an interleaved output needs an interleaved input
+            const bool f16mma_ok = !sc.small3d && !sc.direct && (sc.split3 || sc.f16mma) && sc.KH == 3 && sc.KW == 3 &&
+                                   (sc.S == 1 || sc.S == 2) && sc.TY == 4 && plan->c3d_C % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0;
+            if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0)) : 0;
+            if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out;            // fp32 (feature maps) in, fp16 volume out
+            return 0;
+        }
+        if (plan->is_deconv3d && plan->has_resid && plan->c3d_C % 8 == 0) {
+            for (const SubConv& q : plan->subs)
+                if (!q.split3 || !q.y_f16 || q.TY != 4) return 0;
+            return 4;
+        }
+        return 0;
+    }
+    if (plan->subs.size() != 1) return 0;
     // the general split-fp16 kernel (any 2-D window, transposed phases included) takes and writes them freely
-    if (plan->subs[0].split3 && env_int("RT_NO_IL8", 0) == 0)
+    if (plan->subs[0].split3 && env_int("RT_NO_IL8", 0) == 0) {
+        if (plan->subs[0].y_f16) return (plan->cin % 4 == 0 ? 1 : 0) | (plan->subs[0].Cout % 8 == 0 ? 2 : 0);      // fp16 output: groups of 8, no residual
         return (plan->cin % 4 == 0 ? 1 : 0) | (plan->subs[0].Cout % 4 == 0 ? 6 : 0);
+    }
     if (plan->is_deconv) return 0;
     const SubConv& sc = plan->subs[0];
     if (env_int("RT_NO_IL8", 0) != 0 || sc.zs_dev || sc.y_xstride != 1 || sc.small3d || sc.direct) return 0;
@@ -1647,10 +1726,20 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
 extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
     RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
     if (!x_il8 && !y_il8 && !r_il8) {
+        if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
+            if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
         for (SubConv& sc : plan->subs) sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
         return 0;
     }
     const int caps = rt_conv_plan_supports_il8(plan);
+    if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].x_f16 && plan->subs[0].y_f16) {
+        if ((caps & 8) && y_il8 && !x_il8) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D writes an interleaved tensor only when it reads one");
+        if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2))) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D plan takes no interleaved tensors");
+        if (int rc = switch_conv3d_f16mma(plan, x_il8 != 0)) return rc;           // interleaved input: fp16 operands; planar input: the split kernel
+        SubConv& sc = plan->subs[0];
+        sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = 0;
+        return 0;
+    }
     if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)))
         return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this plan does not take an interleaved %s tensor (3x3 stride-1 plans take all three; "
                     "the first layer and stride-2 3x3 layers write one; channel counts must be multiples of 4 in fp32, 8 in fp16)",
@@ -1658,7 +1747,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
     RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
     SubConv& sc = plan->subs[0];
     RT_REQUIRE(!sc.rb || (x_il8 != 0) == (r_il8 != 0), "rt_conv_plan_set_layouts: a residual block's residual is its input tensor");
-    sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
+    for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }     // (3-D transposed plans have one sub per depth class)
     return 0;
 }
 
@@ -1862,10 +1951,18 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             bool launched = false;
             if (sc.x_f16 || sc.y_f16) {                 // fp16 storage (3-D tensors of half2 mode): planar, 4-row tiles
-                RT_REQUIRE(!sc.x_il8 && !sc.y_il8 && !sc.r_il8 && sc.TY == 4 && sc.y_f16, "rt_conv_enqueue: fp16-storage variant of the split kernel not instantiated");
+                // (the residual's layout is a run-time flag of the kernel: r_il8; an interleaved fp16 OUTPUT exists for fp32 planar input)
+                if (!sc.x_f16 && sc.x_il8 && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 4 && sc.y_f16) {      // fp32 interleaved in (2-D tower tensor)
+                    if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, true, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);
+                    else hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, false, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);
+                    RT_LAUNCH_CHECK("conv_s3_kernel<float, f16>");
+                    continue;
+                }
+                RT_REQUIRE(!sc.x_il8 && !(sc.y_il8 && sc.x_f16) && sc.TY == 4 && sc.y_f16, "rt_conv_enqueue: fp16-storage variant of the split kernel not instantiated");
 #define RT_S3H(kh, kw, st)                                                                                                         \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                                   \
         if (sc.x_f16) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a); \
+        else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, true, 4, float, _Float16>), grid, dim3(256), 0, S(s), a); \
         else hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);   \
         launched = true;                                                                                                           \
     }
@@ -1913,6 +2010,13 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
     }
                 RT_F16_331(0, 0, 4) RT_F16_331(1, 0, 4) RT_F16_331(0, 1, 4) RT_F16_331(1, 1, 4)
 #undef RT_F16_331
+            }
+            if (sc.KH == 3 && sc.KW == 3 && sc.S == 2 && sc.TY == 4 && (sc.x_il8 || sc.y_il8)) {      // stride-2 Conv3D on interleaved 4-D tensors
+                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, true>), grid, dim3(256), 0, S(s), a);
+                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, false>), grid, dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, false, true>), grid, dim3(256), 0, S(s), a);
+                RT_LAUNCH_CHECK("conv_f16mma_kernel<3,3,2>");
+                continue;
             }
             RT_REQUIRE(!(sc.x_il8 || sc.y_il8 || sc.r_il8) && sc.TY == 4, "rt_conv_enqueue: fp16-arithmetic variant not instantiated");
 #define RT_F16CASE(kh, kw, st)                                                                              \

@@ -472,10 +472,9 @@ def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
     print("NVSmall 1025x321, real fp16 weights, half2 mode (fp16 3-D tensors): max |disp - oracle| = %.3g px, mean %.3g px, disparities up to %.1f px"
           % (err.max().item(), err.mean().item(), ref.max().item()))
     assert not torch.isnan(out).any()
-    # fp16 storage of 11 stacked 3-D layers on disparities up to ~100 px: measured 0.11 px at worst / 3e-4 px on average against the
-    # fp32-tensor oracle, asserted at 1.3x that (the reference's accuracy metric D1 counts errors above 3 px); with fp32 tensors
-    # (RT_NO_F16_3D) the same weights give < 1e-3 px, below
-    assert err.max().item() <= 0.15 and err.mean().item() <= 4e-4, (err.max().item(), err.mean().item())
+    # fp16 storage of the two feature maps and of 11 stacked 3-D layers on disparities up to ~100 px: measured 0.19 px at worst / 3e-4 px
+    # on average against the fp32-tensor oracle (the reference's accuracy metric D1 counts errors above 3 px), bounded below by the
+    # error of the reference's own fp16 mode; with fp32 tensors (RT_NO_F16_3D) the same weights give < 1e-3 px, further down
     # ... and it is the error class of the REFERENCE's own fp16 mode: its Conv3D / Conv3DTranspose plugins convert to fp16 before cuDNN,
     # get an fp16 tensor back, add the bias to it and convert to fp32 (lib/conv3d_plugin.cpp:187-216, 247-274).  The oracle restates
     # that (plugin_fp16=True); our half2 output must be no further from it than twice its own distance from the fp32-tensor oracle.
@@ -487,6 +486,7 @@ def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
           % (d_ref.max().item(), d_ref.mean().item(), d_hip.max().item(), d_hip.mean().item()))
     assert d_hip.max().item() <= 2 * d_ref.max().item() and d_hip.mean().item() <= 2 * d_ref.mean().item(), (d_hip.max().item(), d_ref.max().item())
     assert err.max().item() <= 2 * d_ref.max().item() and err.mean().item() <= 2 * d_ref.mean().item()      # no worse than the reference's mode
+    assert err.max().item() <= 0.25 and err.mean().item() <= 4e-4, (err.max().item(), err.mean().item())    # 1.3x the measured figures
     net.destroy()
     monkeypatch.setenv("RT_NO_F16_3D", "1")
     net = lib.create("nvsmall", 1025, 321, weights_path=model_files.weight_file("nvsmall", True), fp16_weights=True)
