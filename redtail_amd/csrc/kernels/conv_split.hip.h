@@ -283,6 +283,15 @@ struct S3Cfg {
     static constexpr int PXB = 80;
     static constexpr int W_SLOTS = TAPS * 2 * 2 * 32;              // 16-byte slots of one chunk's weights
     static constexpr int NK_W = (W_SLOTS + NT - 1) / NT;
+    static constexpr int IN_BYTES = PR * PCL * PXB, GRP_BYTES = IN_BYTES + W_SLOTS * 16;   // LDS of one contraction group (dynamic)
+    // split-K: at most KS_MAX groups of NW waves per workgroup (the register budget below: 4 resp. 2 waves per SIMD)
+    static constexpr int KS_MAX = NW_ != 4 ? 1 : (S == 2 ? 2 : 4);
+    static constexpr int max_groups(int want) {
+        int ks = want < 1 ? 1 : (want > KS_MAX ? KS_MAX : want);
+        while (ks > 1 && (ks == 3 || ks * GRP_BYTES < (ks - 1) * NW * 64 * 16 * 4)) ks--;   // partial sums travel through the operand images
+        return ks;
+    }
+    static_assert(IN_BYTES % 16 == 0, "weight image alignment");
     static_assert(S == 1 || S == 2, "stride 1 or 2");
 };
 
@@ -301,8 +310,16 @@ struct S3Cfg {
 // reference's Conv3D plugins convert fp32 <-> fp16 around cuDNN, lib/conv3d_plugin.cpp:247-274).  An fp16 input IS its own
 // high part (low part 0) and fp16 weights are theirs (p.w_exact), so the corresponding MFMAs are skipped: 3 -> 2 -> 1
 // matrix instructions per tap, fp32 accumulation throughout.
+// Split-K (the low-resolution layers): a launch with KS * 64 * NW threads per workgroup (and KS * GRP_BYTES of dynamic LDS) runs KS
+// groups of NW waves on the workgroup's tile; group g contracts chunks g, g + KS, ... from its own LDS images and the groups' fp32
+// partial sums are added in a fixed order (1, 2, .. after group 0's) before the epilogue.  A 128->128 layer at 158 x 47 is 240
+// workgroups of 8 chunks: with ONE wave per SIMD every LDS fetch and every dependent MFMA pair of a tap is exposed (3.3 k cycles
+// per chunk for 27 MFMAs, tools/time_tail.py); four groups put four independent chunk streams on each SIMD.  KS is a launch
+// parameter, not a template parameter: a second instantiation would start with cold instruction caches once per pair (+6 us on
+// its first launch, tools/sync_trace.py), which is what the split saves.  KS follows from the per-sample geometry only
+// (rt_capi.hip), never from the batch, so a result does not depend on how many samples a launch carries.
 template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4, typename TIN = float, typename TOUT = float>
-__global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_s3_kernel(ConvArgs p) {
     using Cfg = S3Cfg<KH, KW, S, NW>;
     constexpr bool XF16 = std::is_same<TIN, _Float16>::value, YF16 = std::is_same<TOUT, _Float16>::value;
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
@@ -313,12 +330,21 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     constexpr int TY = Cfg::TY, TX = Cfg::TX, CC = Cfg::CC, TAPS = Cfg::TAPS, PC = Cfg::PC, PCL = Cfg::PCL, PXB = Cfg::PXB;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, NT = Cfg::NT;
 
-    __shared__ __attribute__((aligned(16))) char sIn[Cfg::PR * PCL * PXB];
-    __shared__ __attribute__((aligned(16))) f32x4 sW[Cfg::W_SLOTS];
+    constexpr int IN_BYTES = Cfg::IN_BYTES, GRP_BYTES = Cfg::GRP_BYTES;
+#ifdef HIPEMU
+    HIP_DYNAMIC_SHARED(char, smem)
+#else
+    extern __shared__ __attribute__((aligned(16))) char smem[];                       // KS * GRP_BYTES (rt_capi.hip: launch_s3)
+#endif
 
-    const int tid = threadIdx.x;
+    const int tid_wg = threadIdx.x;
+    const int KS = Cfg::KS_MAX == 1 ? 1 : __builtin_amdgcn_readfirstlane((int)blockDim.x / NT);
+    const int kgi = Cfg::KS_MAX == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid_wg / NT);       // contraction group of this wave
+    const int tid = tid_wg - kgi * NT;                                                // thread index inside the group
+    char* const sIn = smem + kgi * GRP_BYTES;
+    f32x4* const sW = reinterpret_cast<f32x4*>(smem + kgi * GRP_BYTES + IN_BYTES);
 #ifdef RT_KERNEL_TIMING
-    unsigned long long* dbgp = p.dbg ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
+    unsigned long long* dbgp = (p.dbg && kgi == 0) ? p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 : nullptr;
     int dbi = 0;
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -432,7 +458,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
     const bool r_il = p.r_il8 != 0;
     const int cb = nblk * 32;                                       // first channel of this block
     f32x4 rr[4];
-    if (p.resid != nullptr) {
+    if (p.resid != nullptr && kgi == 0) {
         // interleaved tensors (2-D plans only): pixel offsets -- r_off / y_off of a transposed-convolution phase -- count
         // 16-byte slots, i.e. 4 elements
         const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + (YF16 ? r_off_il8 : 4 * r_off) : rbase, ESY));
@@ -491,16 +517,39 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
         }
     };
 
-    prefetch(0);
+    if (kgi < nchunks) prefetch(kgi);
     RT_TSTAMP();                                  // 1: residual + first gathers issued
-    for (int ch = 0; ch < nchunks; ch++) {
-        if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
-        stage_to_lds();
+    for (int ch = kgi; ch < nchunks + kgi; ch += KS) {      // every group runs the same number of rounds (barriers are workgroup-wide)
+        const bool mine = KS == 1 || ch < nchunks;          // wave-uniform
+        if (ch != kgi) __syncthreads();       // everyone finished reading the previous chunk from LDS
+        if (mine) stage_to_lds();
         __syncthreads();
         RT_TSTAMP();                              // 2, 4: chunk in LDS
-        if (ch + 1 < nchunks) prefetch(ch + 1);
-        compute();
+        if (ch + KS < nchunks) prefetch(ch + KS);
+        if (mine) compute();
         RT_TSTAMP();                              // 3, 5: MFMAs issued
+    }
+
+    // main + cross terms; split-K: the sums of groups 1 .. KS-1 travel through LDS (the operand images are dead) and are added in group order
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_m[r] = fmaf(acc_c[r], kSplitInv, acc_m[r]);
+    if (KS > 1) {
+        f32x4* const red = reinterpret_cast<f32x4*>(smem);
+        __syncthreads();
+        if (kgi > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                red[(((kgi - 1) * NW + wv) * 4 + q) * 64 + lane] = f32x4{acc_m[4 * q], acc_m[4 * q + 1], acc_m[4 * q + 2], acc_m[4 * q + 3]};
+        }
+        __syncthreads();
+        if (kgi > 0) return;
+        for (int g = 1; g < KS; g++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = red[(((g - 1) * NW + wv) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc_m[4 * q + e] += v[e];
+            }
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
@@ -512,7 +561,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_S3_WAVES(S)) conv_
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), decltype(ACT)::value);
+                o[e] = apply_act_fast(acc_m[4 * q + e] + (bv[e] + rr[q][e]), decltype(ACT)::value);
             if constexpr (YIL && YF16) {
                 // (K/8, H, W, 8) fp16: the lane's 4 consecutive channels of the pixel as one 8-byte store (y_off = depth-slice offset in elements)
                 const unsigned vo = (inb && cb + 8 * q + 4 * kg < p.Cout) ? (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 8 + 4 * kg) * 2u : kBufOOB;

@@ -481,7 +481,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -791,6 +791,23 @@ int upload_s3first(SubConv& sc, int cin_real, F wfun) {
     sc.s3first = 1; sc.s3p = 0; sc.split3 = 0; sc.wino = 0;
     sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
     return 0;
+}
+
+// conv_s3_kernel with ks contraction groups per workgroup (clamped to what the instantiation's LDS and register budget allow)
+template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4, typename TIN = float, typename TOUT = float>
+void launch_s3(dim3 grid, int ks, int64_t per_cu, hipStream_t st, const rt::ConvArgs& a) {
+    using Cfg = rt::S3Cfg<KH, KW, S, NW>;
+    ks = Cfg::max_groups(ks);                                  // per_cu: a sample's workgroups per CU; co-resident ones share 160 KB
+    while (ks > 1 && std::min<int64_t>(per_cu, 4) * ks * Cfg::GRP_BYTES > 160 * 1024) ks = Cfg::max_groups(ks - 1);
+#ifndef HIPEMU
+    static const bool once = [] {        // dynamic LDS beyond the default limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt::conv_s3_kernel<KH, KW, S, XIL, YIL, NW, TIN, TOUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::KS_MAX * Cfg::GRP_BYTES);
+        return true;
+    }();
+    (void)once;
+#endif
+    hipLaunchKernelGGL((rt::conv_s3_kernel<KH, KW, S, XIL, YIL, NW, TIN, TOUT>), grid, dim3(64 * NW * ks), (size_t)ks * Cfg::GRP_BYTES, st, a);
 }
 
 int device_cus() {
@@ -1834,7 +1851,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         }
         std::call_once(plan->env_once, [&] {        // execution contexts of one engine share the plan and may launch it from different threads
             plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
-            plan->opt_rb_tiles = env_int("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0);
+            plan->opt_rb_tiles = env_int("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
         });
         rt::ConvArgs a;
@@ -1950,38 +1967,50 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_s3 %dx%d s%d x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.x_il8, sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
             bool launched = false;
+            // split-K for launches that leave SIMDs with a single wave (the low-resolution layers; conv_split.hip.h): KS groups of
+            // 4 waves per workgroup, as many as the CU's 16 wave slots at this kernel's register budget allow.  Chosen from the
+            // per-sample grid so that a sample's result does not depend on the batch it travels in.
+            int ks = 1;
+            const int64_t per_cu = rt::cdiv((int64_t)grid.x * grid.y * (gz / batch), (int64_t)device_cus());
+            // Not with the throughput hint: there other contexts' launches fill the SIMDs, and a 16-wave workgroup with 139 KB of LDS
+            // keeps them off its CU (six one-stream contexts: 2502 against 2589 pairs/s; one context, synchronous: 0.541 against 0.557 ms).
+            if (plan->opt_ksplit > 0 || (plan->opt_ksplit < 0 && !(hints & RT_HINT_THROUGHPUT))) {
+                const int nch = a.CinPad / 16;
+                ks = plan->opt_ksplit > 0 ? plan->opt_ksplit : (per_cu == 1 && nch >= 4 ? 4 : (per_cu <= 2 && nch >= 2 ? 2 : 1));
+                if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3 split-K request %d\n", ks);
+            }
             if (sc.x_f16 || sc.y_f16) {                 // fp16 storage (3-D tensors of half2 mode): planar, 4-row tiles
                 // (the residual's layout is a run-time flag of the kernel: r_il8; an interleaved fp16 OUTPUT exists for fp32 planar input)
                 if (!sc.x_f16 && sc.x_il8 && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 4 && sc.y_f16) {      // fp32 interleaved in (2-D tower tensor)
-                    if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, true, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);
-                    else hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, false, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);
+                    if (sc.y_il8) launch_s3<3, 3, 1, true, true, 4, float, _Float16>(grid, ks, per_cu, S(s), a);
+                    else launch_s3<3, 3, 1, true, false, 4, float, _Float16>(grid, ks, per_cu, S(s), a);
                     RT_LAUNCH_CHECK("conv_s3_kernel<float, f16>");
                     continue;
                 }
                 RT_REQUIRE(!sc.x_il8 && !(sc.y_il8 && sc.x_f16) && sc.TY == 4 && sc.y_f16, "rt_conv_enqueue: fp16-storage variant of the split kernel not instantiated");
 #define RT_S3H(kh, kw, st)                                                                                                         \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                                   \
-        if (sc.x_f16) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a); \
-        else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, true, 4, float, _Float16>), grid, dim3(256), 0, S(s), a); \
-        else hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false, 4, float, _Float16>), grid, dim3(256), 0, S(s), a);   \
+        if (sc.x_f16) launch_s3<kh, kw, st, false, false, 4, _Float16, _Float16>(grid, ks, per_cu, S(s), a); \
+        else if (sc.y_il8) launch_s3<kh, kw, st, false, true, 4, float, _Float16>(grid, ks, per_cu, S(s), a); \
+        else launch_s3<kh, kw, st, false, false, 4, float, _Float16>(grid, ks, per_cu, S(s), a);   \
         launched = true;                                                                                                           \
     }
                 RT_S3H(3, 3, 1) RT_S3H(3, 3, 2) RT_S3H(1, 1, 1) RT_S3H(1, 2, 1) RT_S3H(2, 1, 1) RT_S3H(2, 2, 1)
 #undef RT_S3H
             }
             if (!launched && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
-                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, true, 8>), grid, dim3(512), 0, S(s), a);
-                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, true, false, 8>), grid, dim3(512), 0, S(s), a);
-                else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, false, true, 8>), grid, dim3(512), 0, S(s), a);
-                else hipLaunchKernelGGL((rt::conv_s3_kernel<3, 3, 1, false, false, 8>), grid, dim3(512), 0, S(s), a);
+                if (sc.x_il8 && sc.y_il8) launch_s3<3, 3, 1, true, true, 8>(grid, ks, per_cu, S(s), a);
+                else if (sc.x_il8) launch_s3<3, 3, 1, true, false, 8>(grid, ks, per_cu, S(s), a);
+                else if (sc.y_il8) launch_s3<3, 3, 1, false, true, 8>(grid, ks, per_cu, S(s), a);
+                else launch_s3<3, 3, 1, false, false, 8>(grid, ks, per_cu, S(s), a);
                 launched = true;
             }
 #define RT_S3(kh, kw, st)                                                                                                   \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                            \
-        if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, true, true>), grid, dim3(256), 0, S(s), a);        \
-        else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, true, false>), grid, dim3(256), 0, S(s), a);              \
-        else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, true>), grid, dim3(256), 0, S(s), a);              \
-        else hipLaunchKernelGGL((rt::conv_s3_kernel<kh, kw, st, false, false>), grid, dim3(256), 0, S(s), a);                           \
+        if (sc.x_il8 && sc.y_il8) launch_s3<kh, kw, st, true, true>(grid, ks, per_cu, S(s), a);        \
+        else if (sc.x_il8) launch_s3<kh, kw, st, true, false>(grid, ks, per_cu, S(s), a);              \
+        else if (sc.y_il8) launch_s3<kh, kw, st, false, true>(grid, ks, per_cu, S(s), a);              \
+        else launch_s3<kh, kw, st, false, false>(grid, ks, per_cu, S(s), a);                           \
         launched = true;                                                                                                    \
     }
             RT_S3(3, 3, 1) RT_S3(3, 3, 2) RT_S3(1, 1, 1) RT_S3(1, 2, 1) RT_S3(2, 1, 1) RT_S3(2, 2, 1)

@@ -137,7 +137,13 @@ def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act
     ho, wo = shape[-2:]
     ip, op = (w + 31) // 32 * 32, (wo + 31) // 32 * 32
     outs = []
-    for x_il, y_il, r_il in (il, (0, 0, 0)):
+    # the interleaved form once as shipped (low-resolution layers split their contraction over wave groups: another summation
+    # order) and once with that switched off, where layouts change addressing only
+    for (x_il, y_il, r_il), ksplit in ((il, None), (il, "0"), ((0, 0, 0), "0"), ((0, 0, 0), None)):
+        if ksplit is None:
+            monkeypatch.delenv("RT_S3_KSPLIT", raising=False)
+        else:
+            monkeypatch.setenv("RT_S3_KSPLIT", ksplit)
         plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, 1 if tr else k // 2, act=act, has_residual=resid, transposed=tr)
         plan.set_pitch(ip, op)
         if x_il or y_il or r_il:
@@ -154,8 +160,9 @@ def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act
         if op > wo:
             assert np.isnan(out[..., wo:]).all(), "padding columns were written"
         outs.append(out[..., :wo])
-    assert np.abs(outs[0] - ref).max() <= 4e-7 * np.sqrt(cin * k * k) + 2e-6, np.abs(outs[0] - ref).max()
-    assert np.array_equal(outs[0], outs[1])                       # layouts change addressing only
+    for o in outs:
+        assert np.abs(o - ref).max() <= 4e-7 * np.sqrt(cin * k * k) + 2e-6, np.abs(o - ref).max()
+    assert np.array_equal(outs[1], outs[2])                       # layouts change addressing only
 
 
 @pytest.mark.parametrize("cin,cout,h,w,batch,pitch,y_il", [
