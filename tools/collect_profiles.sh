@@ -22,4 +22,8 @@ python $R/tools/race_hunt.py 2>&1 | grep -v amdgpu.ids > $O/race.txt
 bash $R/tools/pmc_layer.sh $O/pmc_block block conv_s3rbs > $O/pmc_layer_resblock.txt 2>&1
 bash $R/tools/pmc_layer.sh $O/pmc_conv conv conv_s3_kernel > $O/pmc_layer_conv_s3.txt 2>&1
 (RT_TIME_BLOCK=1 python $R/tools/time_phases_split.py 1; python $R/tools/time_phases_split.py 1; python $R/tools/host_overhead.py) 2>&1 | grep -v amdgpu.ids > $O/phases.txt
+(python $R/tools/time_tail.py; RT_S3_KSPLIT=0 python $R/tools/time_tail.py | grep "per launch") 2>&1 | grep -v amdgpu.ids > $O/tail.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/sync_trace -o t -- python $R/tools/sync_trace.py run > /dev/null 2>&1
+python $R/tools/sync_trace.py show $O/sync_trace > $O/sync_timeline.txt 2>&1
+python $R/tools/micro/cold_code_probe.py 2>&1 | grep -v amdgpu.ids > $O/cold_code.txt
 ls $O $O/trace | head -40

@@ -72,7 +72,8 @@ def main():
     shutil.copy(os.path.join(run, "trace", "bench_kernel_stats.csv"), os.path.join(out, tag + "_kernel_stats.csv"))
     shutil.copy(os.path.join(run, "bench_plain.json"), os.path.join(out, tag + "_bench.json"))
     for extra in ("bench_20_5.json", "bench_layer_by_layer.json", "bench_half2_b1.json", "bench_half2_b8.json", "bench_nvsmall_half2_b8.json",
-                  "bench_resnet18_3d_b4.json", "bench_3d.txt", "layers.txt", "race.txt", "pmc_layer_resblock.txt", "pmc_layer_conv_s3.txt", "phases.txt"):
+                  "bench_resnet18_3d_b4.json", "bench_3d.txt", "layers.txt", "race.txt", "pmc_layer_resblock.txt", "pmc_layer_conv_s3.txt", "phases.txt",
+                  "tail.txt", "sync_timeline.txt", "cold_code.txt"):
         if os.path.exists(os.path.join(run, extra)):
             shutil.copy(os.path.join(run, extra), os.path.join(out, tag + "_" + extra))
 
