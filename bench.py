@@ -114,7 +114,11 @@ def measured_traffic(half2=False, fused=None):
         return None, None                                   # the PMC pass was taken with the other kernel as the dominant one
     if t.get("sources_sha16") not in (None, kernel_sources_sha16()):
         return None, "%s is stale: taken on kernel sources %s, these are %s" % (os.path.relpath(files[-1], ROOT), t.get("sources_sha16"), kernel_sources_sha16())
-    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    src = os.path.relpath(files[-1], ROOT)
+    if "images_per_launch" in t:            # what a counted launch covers (since round 3: both towers' samples of a block) and its algorithmic bytes
+        src += "; counted launches cover %d image(s): %.1f MB algorithmic" % (
+            t["images_per_launch"], (t["algorithmic_read_bytes"] + t["algorithmic_write_bytes"]) / 1e6)
+    return t["hbm_bytes_per_launch"], src
 
 
 def kernel_sources_sha16():

@@ -1732,8 +1732,13 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
     if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
     if (sc.x_f16 || sc.y_f16) return 0;
-    // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three ...
-    if (sc.wino) return (sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
+    // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three -- but exact-fp32 engines do not
+    // use it that way any more (round 3): with 2+ execution contexts in flight, tools/race_hunt.py saw about one output in 3000
+    // of the exact engine deviate from the others in a tile-sized region (up to 1e-3 on the disparity; 8 of 24 000 outputs), never with
+    // planar tensors (0 of 24 000), never without the Winograd kernel (0 of 12 000), never in the split-fp16 engine, and never with the
+    // kernel alone (tools/race_kernel.py: 80 000 launches per layout mix on 4 streams).  Unexplained; the instantiations stay for the
+    // kernel-level tests behind the development knob RT_WINO_IL8=1.
+    if (sc.wino) return (env_int("RT_WINO_IL8", 0) != 0 && sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
     // (the direct-form kernel had an interleaved-output form for the first layer and the stride-2 layers behind RT_IL_DIRECT in round 1;
     //  whole networks were wrong with it on the GPU only -- tools/race_hunt.py reproduced that in round 2 even with one stream and one
     //  context -- and the split-fp16 kernels that now serve those layers write interleaved tensors themselves, so the form was removed)

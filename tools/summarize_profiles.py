@@ -41,6 +41,7 @@ DOMINANT_GRID = 47 * 20 * 256        # the 3x3 32->32 @629x185 launches only (th
 # with the streaming ELU / add+ELU kernels of tools/bench_ops.py in this round: 7302 KB reported for
 # 14546 KiB read, 14575 for 29091); WRITE_SIZE is exact (14545.6 KB for 14545.6 KiB written).
 FETCH_SCALE, WRITE_SCALE = 2.0, 1.0
+IMAGES = 1
 ALGO_READ = 4.0 * (2 * 32 * 185 * 629 + 32 * 32 * 9 + 32)      # x + residual + weights + bias
 ALGO_WRITE = 4.0 * 32 * 185 * 629
 
@@ -51,7 +52,7 @@ def short(name):
 
 
 def main():
-    global FUSED, DOMINANT, DOMINANT_GRID, ALGO_READ, ALGO_WRITE
+    global FUSED, DOMINANT, DOMINANT_GRID, ALGO_READ, ALGO_WRITE, IMAGES
     run, tag = sys.argv[1], sys.argv[2]
     stats = open(os.path.join(run, "trace", "bench_kernel_stats.csv")).read()
     if "conv_s3rbs_kernel" in stats:
@@ -63,8 +64,8 @@ def main():
         for r in csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))):
             if short(r["Kernel_Name"]).startswith("conv_s3rbs_kernel"):
                 grids[int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])] += 1
-        DOMINANT_GRID = max(grids)
-        images = 2 if DOMINANT_GRID in (21 * 3 * 512 * 2, 21 * 6 * 512 * 2, 21 * 4 * 512 * 2, 21 * 2 * 512 * 2) else 1
+        DOMINANT_GRID = grids.most_common(1)[0][0]      # the timed configuration's (six one-stream contexts; the PMC passes run one such context)
+        IMAGES = images = 2 if DOMINANT_GRID in (21 * 3 * 512 * 2, 21 * 6 * 512 * 2, 21 * 4 * 512 * 2, 21 * 2 * 512 * 2) else 1
         ALGO_READ = images * 4.0 * (32 * 185 * 629) + 4.0 * 2 * (32 * 32 * 9 + 32)   # x of every image + both layers' weights and biases
         ALGO_WRITE = images * 4.0 * 32 * 185 * 629
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
@@ -108,7 +109,7 @@ def main():
     traffic = dict(kernel=DOMINANT, launches_counted=len(dom["FETCH_SIZE"]),
                    fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
                    algorithmic_read_bytes=ALGO_READ, algorithmic_write_bytes=ALGO_WRITE,
-                   fetch_scale=FETCH_SCALE, write_scale=WRITE_SCALE,
+                   fetch_scale=FETCH_SCALE, write_scale=WRITE_SCALE, images_per_launch=IMAGES,
                    rocprof_avg_launch_us=sum(durs) / len(durs) / 1e3, rocprof_launches=len(durs), dominant_grid_threads=DOMINANT_GRID,
                    sources_sha16=kernel_sources_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     json.dump(traffic, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
