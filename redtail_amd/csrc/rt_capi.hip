@@ -793,6 +793,28 @@ int upload_s3first(SubConv& sc, int cin_real, F wfun) {
     return 0;
 }
 
+// deconv3d_s2_small_kernel: weights packed [.. ][phase][neighbour]; when every pair outside rt::SmallTaps' pattern is zero (the padding of
+// every network of the reference; PAT: rt::SmallTaps) keep only the pairs that carry a tap.  Returns whether it did (RT_NO_SMALL_SPARSE:
+// development knob).
+template <bool Z, int PAT>
+bool drop_structural_zeros(std::vector<float>& packed) {
+    using Taps = rt::SmallTaps<Z, PAT>;
+    constexpr int NJ = Taps::NJ;
+    if (env_int("RT_NO_SMALL_SPARSE", 0) != 0) return false;
+    const size_t rows = packed.size() / (NJ * NJ);
+    for (size_t r = 0; r < rows; r++)
+        for (int f = 0; f < NJ; f++)
+            for (int j = 0; j < NJ; j++)
+                if (!Taps::valid(f, j) && packed[(r * NJ + f) * NJ + j] != 0.f) return false;
+    std::vector<float> dense(rows * Taps::NV);
+    for (size_t r = 0; r < rows; r++)
+        for (int f = 0; f < NJ; f++)
+            for (int j = 0; j < NJ; j++)
+                if (Taps::valid(f, j)) dense[r * Taps::NV + Taps::index(f, j)] = packed[(r * NJ + f) * NJ + j];
+    packed.swap(dense);
+    return true;
+}
+
 // conv_s3_kernel with ks contraction groups per workgroup (clamped to what the instantiation's LDS and register budget allow)
 template <int KH, int KW, int S, bool XIL, bool YIL, int NW = 4, typename TIN = float, typename TOUT = float>
 void launch_s3(dim3 grid, int ks, int64_t per_cu, hipStream_t st, const rt::ConvArgs& a) {
@@ -1060,6 +1082,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             sc.s3.Dx = 1; sc.s3.Hx = Ho; sc.s3.Wx = Wo; sc.s3.C = Cout;
             sc.s3.bz = 0; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = 1;
             sc.s3.xp = d->Win; sc.s3.yp = Wo;
+            sc.s3.sparse = (by == 0 && bx == 0 && drop_structural_zeros<false, 0>(packed)) ? 1 : 0;
             int rc = upload_weights(sc, packed);
             plan->subs.push_back(sc);
             if (!rc) {
@@ -1290,6 +1313,8 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             sc.s3.Dx = Dlim; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
             sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dlim + 1) / 2;
             sc.s3.xp = Wy; sc.s3.yp = Wx;
+            sc.s3.sparse = (by != 0 || bx != 0) ? 0 : (bz == 0 && drop_structural_zeros<true, 0>(packed)) ? 1 :
+                           (bz == -1 && drop_structural_zeros<true, 4>(packed)) ? 1 + 4 : 0;
             RT_REQUIRE((int64_t)Dx * C * Hx * Wx < (1ll << 29), "conv3d_transpose: output sample exceeds 2 GB (32-bit buffer offsets)");
             rc = upload_weights(sc, packed);
             plan->subs.push_back(sc);

@@ -238,6 +238,12 @@ def test_conv3d_tran_small_output(backend, monkeypatch, k, c, ydims, xdims, ps, 
     od = (xdims[0], c, xdims[1], xdims[2])
     ref = O.elu(O.conv3d_transpose_tf(T(y), T(w), T(b), od, (2, 2, 2), ps, pe)).numpy()
     out = conv3d_tran_run(backend, y, w, b, od, (2, 2, 2), ps, pe, act=capi.RT_ACT_ELU)
+    # with the reference's padding only 27 of the 64 (phase, neighbour) products carry a tap and the plan drops the rest
+    # (rt::SmallTaps); the products it drops are exact zeros, so the dense form gives the same bits
+    monkeypatch.setenv("RT_NO_SMALL_SPARSE", "1")
+    dense = conv3d_tran_run(backend, y, w, b, od, (2, 2, 2), ps, pe, act=capi.RT_ACT_ELU)
+    monkeypatch.delenv("RT_NO_SMALL_SPARSE")
+    assert np.array_equal(out, dense)
     monkeypatch.setenv("RT_NO_DECONV3D_SMALL", "1")
     gen = conv3d_tran_run(backend, y, w, b, od, (2, 2, 2), ps, pe, act=capi.RT_ACT_ELU)
     near(out, ref, 2e-5)
