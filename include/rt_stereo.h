@@ -250,6 +250,11 @@ int rt_conv3d_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const voi
 int rt_conv3d_transpose_plan_create(rtConvPlan** plan, const rtConv3dDesc* desc, const int in_dims[3],
                                     const void* weights_host, const void* bias_host);
 
+/* 1 when the library was built with -DRT_EXPERIMENTAL: the measured-and-rejected kernel families (persistent split kernel, per-tile fused
+ * residual block, 8-row / 8-wave tiles, Winograd on interleaved tensors) are then compiled in and selectable through development knobs.
+ * The product build returns 0; the CPU test tier's emulator build returns 1. */
+int rt_has_experimental(void);
+
 /* The domain of a plan's arithmetic.  The default fp32 path multiplies 22-bit fp16 splits on the fp16 matrix pipe: an input value with
  * |x| >= 65504 (or a non-finite one) becomes inf / NaN in the result -- loud, but far from its cause.  rt_conv_plan_input_limit gives the
  * bound a plan needs (65504 for split / fp16-operand plans, +inf for RT_CONV_EXACT_FP32 and the small direct kernels);

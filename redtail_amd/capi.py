@@ -82,6 +82,7 @@ KERNEL_SYMBOLS = {
     "rt_preprocess_bgr8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
     "rt_conv_plan_input_limit": (c_int, [c_void_p, POINTER(c_float)]),
+    "rt_has_experimental": (c_int, []),
     "rt_check_range": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_float, POINTER(c_float), POINTER(c_int64), c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
@@ -203,6 +204,10 @@ class KernelLib:
                    "rt_concat_channels")
 
     # -- convolution plans -------------------------------------------------------------------------
+    def has_experimental(self):
+        """the library carries the rejected kernel families (RT_EXPERIMENTAL build: the emulator library of the CPU test tier)"""
+        return bool(self.lib.rt_has_experimental())
+
     def check_range(self, x, rows, valid, pitch, dtype=RT_F32, limit=65504.0, stream=None):
         """(max finite |x|, number of elements with |x| >= limit or non-finite) of a device tensor (rt_check_range)"""
         mx, bad = c_float(), c_int64()

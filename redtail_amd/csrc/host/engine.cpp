@@ -1023,11 +1023,11 @@ void EngineImpl::fuseResBlocks() {
         };
         const rtConv2dDesc d1 = desc(a, false), d2 = desc(b, true);
         const TensorImpl &x = *tensors_[root(a.in[0])], &y = *tensors_[root(b.out)];
-        if (!force) {
+        {
             bool ok = d1.Cin == 32 && d1.Cout == 32 && d2.Cout == 32 && a.act == RT_ACT_ELU && b.act == RT_ACT_ELU;
-            ok = ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200;       // enough strips (30 columns) x segments (16 rows) for every CU
             ok = ok && x.il8 && y.il8 && !x.f16 && !y.f16;                        // what the streaming kernel reads and writes
-            if (!ok) continue;
+            // forced: also small images, and -- in RT_EXPERIMENTAL builds of the kernel library -- every other block through the per-tile form
+            if (force ? (!ok && !rt_has_experimental()) : !(ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200)) continue;   // default: enough strips x segments for every CU
         }
         const LayerData *la = a.conv_layer, *lb = b.conv_layer;
         rtConvPlan* rb = nullptr;

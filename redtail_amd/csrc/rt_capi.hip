@@ -674,6 +674,15 @@ int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+
+// Kernel families that were measured and rejected (the persistent split kernel, the per-tile fused residual block, 8-row /
+// 8-wave tiles, the Winograd kernel on interleaved tensors) are compiled only with -DRT_EXPERIMENTAL -- the emulator build of the CPU
+// test tier has it, the product library does not -- and the development knobs that select them read as their defaults otherwise.
+#ifdef RT_EXPERIMENTAL
+inline int exp_knob(const char* name, int dflt) { return env_int(name, dflt); }
+#else
+inline int exp_knob(const char*, int dflt) { return dflt; }
+#endif
 // RT_CONV_EXACT_FP32 as an API option: set from the descriptor's flags for the duration of one *_plan_create call
 thread_local int tl_exact_fp32 = 0;
 int exact_fp32() { return tl_exact_fp32 || env_int("RT_CONV_EXACT_FP32", 0) != 0; }
@@ -719,7 +728,7 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
     set_tile(sc, forced >= 0 ? forced : 6);
     // Winograd F(2x2,3x3) for the stride-1 3x3 windows with at least one full pair of 16-channel blocks
     sc.wino = (allow_wino && !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.Cout >= 24 && env_int("RT_CONV_NO_WINO", 0) == 0) ? 1 : 0;
-    if (sc.wino) { sc.CC = 8; sc.NBW = 1; sc.TY = env_int("RT_WINO_WAVES", 4); sc.TXW = 1; sc.NW = sc.TY; }
+    if (sc.wino) { sc.CC = 8; sc.NBW = 1; sc.TY = exp_knob("RT_WINO_WAVES", 4); sc.TXW = 1; sc.NW = sc.TY; }
     const int nbw = env_int("RT_CONV_NBW", 0);
     if (nbw == 1 || (nbw == 2 && sc.KH != 5)) sc.NBW = nbw;
     // fp32 tensors on the fp16 matrix pipe (3-term split, conv_split.hip.h) for every window that kernel is built for;
@@ -730,7 +739,7 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
         sc.wino = 0; sc.CC = 16; sc.NBW = 1; sc.TY = 4; sc.TXW = 1; sc.NW = 4;
         // 3x3 stride 1: 8-row tiles (8 waves, weights staged once per 8 rows, less halo) are built and opt-in (RT_S3_ROWS=8):
         // measured on the 32->32 @629x185 layer 13.9 vs 14.5 us alone, but 2055 vs 2108 pairs/s in the network (4 contexts)
-        if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && env_int("RT_S3_ROWS", 4) == 8) sc.TY = sc.NW = 8;
+        if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && exp_knob("RT_S3_ROWS", 4) == 8) sc.TY = sc.NW = 8;
     }
 }
 
@@ -739,7 +748,7 @@ void choose_tiling(SubConv& sc, bool allow_wino = true) {
 // share a CU with the other stream's / other contexts' launches, so the network is slower with it (1830 vs 2081 pairs/s).
 bool s3p_eligible(const SubConv& sc, int cin) {
     return !sc.direct && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && cin <= 32 && sc.Cout <= 32 && sc.nz == 1 &&
-           !exact_fp32() && env_int("RT_S3P", 0) != 0;
+           !exact_fp32() && exp_knob("RT_S3P", 0) != 0;
 }
 
 // conv_s3p_kernel's LDS image of the layer's weights: [tap][chunk of 16 ci][hi / lo][k-group of 8][co % 32][8 halfs]
@@ -1762,8 +1771,8 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     // of the exact engine deviate from the others in a tile-sized region (up to 1e-3 on the disparity; 8 of 24 000 outputs), never with
     // planar tensors (0 of 24 000), never without the Winograd kernel (0 of 12 000), never in the split-fp16 engine, and never with the
     // kernel alone (tools/race_kernel.py: 80 000 launches per layout mix on 4 streams).  Unexplained; the instantiations stay for the
-    // kernel-level tests behind the development knob RT_WINO_IL8=1.
-    if (sc.wino) return (env_int("RT_WINO_IL8", 0) != 0 && sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
+    // kernel-level tests behind the development knob RT_WINO_IL8=1 of RT_EXPERIMENTAL builds.
+    if (sc.wino) return (exp_knob("RT_WINO_IL8", 0) != 0 && sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
     // (the direct-form kernel had an interleaved-output form for the first layer and the stride-2 layers behind RT_IL_DIRECT in round 1;
     //  whole networks were wrong with it on the GPU only -- tools/race_hunt.py reproduced that in round 2 even with one stream and one
     //  context -- and the split-fp16 kernels that now serve those layers write interleaved tensors themselves, so the form was removed)
@@ -1881,7 +1890,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         }
         std::call_once(plan->env_once, [&] {        // execution contexts of one engine share the plan and may launch it from different threads
             plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
-            plan->opt_rb_tiles = env_int("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
+            plan->opt_rb_tiles = exp_knob("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
         });
         rt::ConvArgs a;
@@ -1933,6 +1942,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             RT_LAUNCH_CHECK("conv_direct_f32_kernel");
             continue;
         }
+#ifdef RT_EXPERIMENTAL
         if (sc.s3p) {
             // persistent: one 8-wave workgroup per CU walks a contiguous range of tiles (RT_S3P_GRID: test knob)
             const int64_t T = (int64_t)a.tiles_x * tiles_y * batch;
@@ -1948,6 +1958,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             RT_LAUNCH_CHECK("conv_s3p_kernel");
             continue;
         }
+#endif
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
         if (sc.rb) {
             rt::RBArgs ra;
@@ -1978,6 +1989,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 RT_LAUNCH_CHECK("conv_s3rbs_kernel");
                 continue;
             }
+#ifdef RT_EXPERIMENTAL
             dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
             if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);
             if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_s3rb_kernel<true, true>), rgrid, dim3(256), 0, S(s), ra);
@@ -1986,6 +1998,10 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             else hipLaunchKernelGGL((rt::conv_s3rb_kernel<false, false>), rgrid, dim3(256), 0, S(s), ra);
             RT_LAUNCH_CHECK("conv_s3rb_kernel");
             continue;
+#else
+            return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue: this build plans residual blocks for the streaming kernel only (32 -> 32 -> 32 channels, "
+                                           "ELU / ELU, interleaved tensors); the per-tile form is compiled with RT_EXPERIMENTAL");
+#endif
         }
         if (sc.s3first) {
             if (sc.y_il8) hipLaunchKernelGGL((rt::conv_s3_first_kernel<true>), grid, dim3(256), 0, S(s), a);
@@ -2028,6 +2044,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 RT_S3H(3, 3, 1) RT_S3H(3, 3, 2) RT_S3H(1, 1, 1) RT_S3H(1, 2, 1) RT_S3H(2, 1, 1) RT_S3H(2, 2, 1)
 #undef RT_S3H
             }
+#ifdef RT_EXPERIMENTAL
             if (!launched && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
                 if (sc.x_il8 && sc.y_il8) launch_s3<3, 3, 1, true, true, 8>(grid, ks, per_cu, S(s), a);
                 else if (sc.x_il8) launch_s3<3, 3, 1, true, false, 8>(grid, ks, per_cu, S(s), a);
@@ -2035,6 +2052,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 else launch_s3<3, 3, 1, false, false, 8>(grid, ks, per_cu, S(s), a);
                 launched = true;
             }
+#endif
 #define RT_S3(kh, kw, st)                                                                                                   \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                            \
         if (sc.x_il8 && sc.y_il8) launch_s3<kh, kw, st, true, true>(grid, ks, per_cu, S(s), a);        \
@@ -2093,13 +2111,19 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (sc.x_f16 || sc.y_f16) {
                 RT_REQUIRE(sc.x_f16 && sc.y_f16, "rt_conv_enqueue: the Winograd kernel takes fp16 on both sides or on neither");
                 hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
-            } else if (sc.NW == 8) {
+            }
+#ifdef RT_EXPERIMENTAL
+            else if (sc.NW == 8) {
                 RT_REQUIRE(!(sc.x_il8 || sc.y_il8 || sc.r_il8), "rt_conv_enqueue: interleaved tensors need the 4-wave Winograd tile");
                 hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
             } else if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, true>), grid, dim3(256), 0, S(s), a);
             else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, false>), grid, dim3(256), 0, S(s), a);
             else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, true>), grid, dim3(256), 0, S(s), a);
             else if (sc.r_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, false, true>), grid, dim3(256), 0, S(s), a);
+#else
+            else if (sc.NW != 4 || sc.x_il8 || sc.y_il8 || sc.r_il8)
+                return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue: Winograd kernel: planar tensors, 4-wave tile (other forms: RT_EXPERIMENTAL builds)");
+#endif
             else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("conv_wino_f32_kernel");
             continue;
@@ -2107,6 +2131,14 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         if (int rc = launch_sub(sc, a, grid, S(s))) return rc;
     }
     return 0;
+}
+
+extern "C" int rt_has_experimental(void) {
+#ifdef RT_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int rt_conv_plan_destroy(rtConvPlan* plan) {

@@ -64,6 +64,8 @@ CASES = [
 def test_split_conv2d(backend, monkeypatch, cin, cout, h, w, act, resid, batch, pitch, il, grid):
     """grid = 3: three workgroups walk all tiles (persistent loop, double-buffered patch, prefetch across tiles and
     images); grid = 0: the default one-workgroup-per-CU launch"""
+    if not backend.klib.has_experimental():
+        pytest.skip("conv_s3p_kernel is compiled with RT_EXPERIMENTAL only (the emulator build of the CPU tier)")
     monkeypatch.setenv("RT_S3P", "1")
     if grid:
         monkeypatch.setenv("RT_S3P_GRID", str(grid))
@@ -224,6 +226,8 @@ RB_CASES = [
 def test_split_resblock(backend, c, cmid, h, w, batch, pitch, il):
     """whole residual block in one launch against an fp64 evaluation of the two layers, and against the same block run
     layer by layer through the general split kernel"""
+    if not (c == 32 and cmid == 32 and il == (1, 1)) and not backend.klib.has_experimental():
+        pytest.skip("the per-tile form (conv_s3rb_kernel) is compiled with RT_EXPERIMENTAL only (the emulator build of the CPU tier)")
     x = rnd(batch, c, h, w)
     w1, b1 = rnd(cmid, c, 3, 3) * np.float32(1 / np.sqrt(c * 9)), rnd(cmid)
     w2, b2 = rnd(c, cmid, 3, 3) * np.float32(1 / np.sqrt(cmid * 9)), rnd(c)
