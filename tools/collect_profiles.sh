@@ -19,6 +19,7 @@ python $R/bench.py --model resnet18 --batch 4 --steps 10 --warmup 2 > $O/bench_r
 (python $R/tools/bench_3d.py nvtiny nvsmall resnet18; python $R/tools/bench_3d.py nvsmall resnet18 --half2; python $R/tools/bench_3d.py nvsmall --half2 --batch=8; python $R/tools/bench_3d.py resnet18 --batch=4) 2>&1 | grep -v amdgpu.ids > $O/bench_3d.txt
 python $R/tools/layer_profile.py 2>&1 | grep -v amdgpu.ids > $O/layers.txt
 python $R/tools/race_hunt.py 2>&1 | grep -v amdgpu.ids > $O/race.txt
+python -c "import sys; sys.path.insert(0, '$R'); from redtail_amd import build; build.build_hip_timing()" > /dev/null 2>&1    # instrumented library of the phase tools (rebuilt only when stale)
 bash $R/tools/pmc_layer.sh $O/pmc_block block conv_s3rbs > $O/pmc_layer_resblock.txt 2>&1
 bash $R/tools/pmc_layer.sh $O/pmc_conv conv conv_s3_kernel > $O/pmc_layer_conv_s3.txt 2>&1
 (RT_TIME_BLOCK=1 python $R/tools/time_phases_split.py 1; python $R/tools/time_phases_split.py 1; python $R/tools/host_overhead.py) 2>&1 | grep -v amdgpu.ids > $O/phases.txt
