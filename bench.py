@@ -715,6 +715,29 @@ def main():
         single["synchronous_execute"] = {"value": b / dt1, "unit": "pairs/s", "ms_per_pair": dt1 / b * 1e3, "ms_per_pair_mean": float(np.mean(lat)) / b * 1e3,
                                          "calls": len(lat),
                                          "note": "context->execute() in a loop, the reference's timing protocol (sample_app/main.cpp:303-309)"}
+        # ... and the same loop in graph mode (IExecutionContext::setGraphMode: the pass is one hipGraph launch) -- reported, not the default
+        try:
+            nets[0].set_graph(True)
+            for _ in range(3):
+                nets[0].execute(left, right, disps[0], b)              # direct, capture, first replay
+            lat_g = []
+            for _ in range(max(n1, 50)):
+                t1 = time.perf_counter()
+                nets[0].execute(left, right, disps[0], b)
+                lat_g.append(time.perf_counter() - t1)
+            dtg = float(np.median(lat_g[len(lat_g) // 4:]))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                nets[0].execute(left, right, disps[0], b, stream=streams[0].cuda_stream)
+            torch.cuda.synchronize(dev)
+            dtp = (time.perf_counter() - t1) / n1
+            single["graph_mode"] = {"synchronous_execute_ms_per_pair": dtg / b * 1e3, "pipelined_ms_per_pair": dtp / b * 1e3,
+                                    "note": "one hipGraph launch per pair (rt_net_set_graph); same context, same streams"}
+        except Exception as e:                                          # noqa: BLE001 -- the figure is optional, the reason is reported
+            single["graph_mode"] = {"error": str(e)[:200]}
+        finally:
+            nets[0].set_graph(False)
         # the latency set-up is not the timed one (two streams; no throughput hint, so the low-resolution layers split their
         # contraction over wave groups, DESIGN.md 4.6: another fp32 summation order): its disparity is checked on its own below, and
         # context 0 runs one plain step again so that what is compared between the contexts is what was timed

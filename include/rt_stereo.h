@@ -58,6 +58,14 @@ int rt_event_create_ordering(void** ev);              /* no timestamps: for rt_s
 int rt_event_destroy(void* ev);
 int rt_event_record(void* ev, rtStream stream);
 int rt_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+/* hipGraph of everything issued on `stream` (and on streams that join it through events) between begin and end: an executor
+ * captures one pass over fixed bindings and replays it with ONE rt_graph_launch (TensorRT's enqueue is graph-capturable the same
+ * way; cudaStreamBeginCapture / cudaGraphInstantiate / cudaGraphLaunch).  Relaxed capture mode; RT_E_UNSUPPORTED on the emulator. */
+typedef struct rtGraph rtGraph;
+int rt_graph_begin_capture(rtStream stream);
+int rt_graph_end_capture(rtStream stream, rtGraph** graph);          /* ends the capture and instantiates; NULL graph on failure */
+int rt_graph_launch(rtGraph* graph, rtStream stream);
+int rt_graph_destroy(rtGraph* graph);
 
 /* ---- element-wise ------------------------------------------------------------------------ */
 /* ELU, alpha = 1: y = x > 0 ? x : exp(x) - 1.  Replaces EluPlugin::enqueue ->

@@ -83,6 +83,10 @@ int rt_net_num_layers(const rtStereoNet* net);     /* layers of the network defi
  * context (latency); 1 = everything on the caller's stream, best when several handles are kept busy side by side
  * (IExecutionContext::setExecutionStreams, an extension of the NvInfer.h subset; bench.py uses 1 with its six contexts). */
 int rt_net_set_streams(rtStereoNet* net, int streams);
+/* Graph mode (IExecutionContext::setGraphMode, an extension): the second rt_net_execute with the same device pointers, batch and stream
+ * is captured as a hipGraph (rt_stereo.h: rt_graph_*), every further one is a single graph launch; other pointers capture another graph.
+ * Off by default (the host is not the bottleneck of this path). */
+int rt_net_set_graph(rtStereoNet* net, int on);
 /* Debug mode (IExecutionContext::setDebugSync): every launch is synchronised and the input of every fp16-pipe convolution is range-checked
  * first (rt_check_range): an execute() whose activations leave the fp16-split domain fails with the layer's name in rt_net_last_error(). */
 int rt_net_set_debug(rtStereoNet* net, int on);

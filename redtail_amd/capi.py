@@ -83,6 +83,10 @@ KERNEL_SYMBOLS = {
     "rt_disparity_to_u16": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, c_void_p]),
     "rt_conv_plan_input_limit": (c_int, [c_void_p, POINTER(c_float)]),
     "rt_has_experimental": (c_int, []),
+    "rt_graph_begin_capture": (c_int, [c_void_p]),
+    "rt_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "rt_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "rt_graph_destroy": (c_int, [c_void_p]),
     "rt_check_range": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_float, POINTER(c_float), POINTER(c_int64), c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
@@ -311,6 +315,7 @@ NET_SYMBOLS = {
     "rt_net_num_layers": (c_int, [c_void_p]),
     "rt_net_num_launches": (c_int, [c_void_p]),
     "rt_net_set_streams": (c_int, [c_void_p, c_int]),
+    "rt_net_set_graph": (c_int, [c_void_p, c_int]),
     "rt_net_create_broadcast": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int]),
     "rt_net_weights_crc32": (c_int, [c_void_p, POINTER(ctypes.c_uint32)]),
     "rt_net_weights_image": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
@@ -463,6 +468,10 @@ class StereoNet:
     def set_streams(self, n):
         """1: all launches on the caller's stream (throughput with several contexts); 2: second stream for the right encoder"""
         self.netlib.check(self.netlib.lib.rt_net_set_streams(self.handle, n), "rt_net_set_streams")
+
+    def set_graph(self, on):
+        """graph mode: repeated executes with the same pointers replay one captured hipGraph (rt_net_set_graph)"""
+        self.netlib.check(self.netlib.lib.rt_net_set_graph(self.handle, int(bool(on))), "rt_net_set_graph")
 
     def profile(self, left, right, disp, batch=1):
         buf = ctypes.create_string_buffer(1 << 16)

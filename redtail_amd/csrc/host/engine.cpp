@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <cstdint>
 #include <map>
+#include <set>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -343,6 +345,8 @@ public:
     bool getDebugSync() const override { return debug_sync_; }
     void setExecutionStreams(int n) override { streams_ = n < 2 ? 1 : 2; }
     int getExecutionStreams() const override { return streams_; }
+    void setGraphMode(bool on) override { graph_mode_ = on; }
+    bool getGraphMode() const override { return graph_mode_; }
     void setProfiler(IProfiler* p) override { profiler_ = p; }
     IProfiler* getProfiler() const override { return profiler_; }
     const ICudaEngine& getEngine() const override;
@@ -350,6 +354,7 @@ public:
 
 private:
     bool run(int batch, void** bindings, cudaStream_t stream, bool sync);
+    bool issue(int batch, void** bindings, cudaStream_t stream, bool sync, bool capturing);
     bool checkInputRange(const Op& op, int batch, void** bindings, rtStream st);
     bool ensureBuffers(int batch);
     void* addr(int tensor, int batch, void** bindings) const;
@@ -369,6 +374,10 @@ private:
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
     void* ev_null_ = nullptr;
+    // graph mode: one captured pass per (stream, batch, schedule, bindings); second == nullptr: seen once, captured on the next call
+    bool graph_mode_ = false;
+    std::map<std::vector<uintptr_t>, rtGraph*> graphs_;
+    std::set<std::vector<uintptr_t>> graph_failed_;
     std::map<std::pair<int, int>, std::pair<void*, size_t>> half_buf_;   // (op, slot) -> fp16 staging buffer of a kHALF plugin
     void* halfBuffer(int op, int slot, size_t bytes);
 };
@@ -1636,6 +1645,7 @@ ContextImpl::~ContextImpl() {
     if (ev_fork_) rt_event_destroy(ev_fork_);
     if (ev_join_) rt_event_destroy(ev_join_);
     if (ev_null_) rt_event_destroy(ev_null_);
+    for (auto& g : graphs_) rt_graph_destroy(g.second);
     if (side_stream_) rt_stream_destroy(side_stream_);
     if (main_stream_) rt_stream_destroy(main_stream_);
 }
@@ -1753,7 +1763,44 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
     return true;
 }
 
+// Graph mode (setGraphMode): the first pass over a set of bindings runs as usual (buffers, streams and events come into being), the
+// second is captured -- the side stream joins the capture through the fork event and leaves it through the join event -- and from then
+// on a pass is one rt_graph_launch.  Profiling and debug mode keep the launch-by-launch path.
 bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync) {
+    if (!graph_mode_ || profiler_ || debug_sync_ || !stream) return issue(batch, bindings, stream, sync, false);
+    std::vector<uintptr_t> key{(uintptr_t)stream, (uintptr_t)batch, (uintptr_t)streams_, (uintptr_t)sync};
+    for (int b = 0; b < eng_.getNbBindings(); b++) key.push_back((uintptr_t)bindings[b]);
+    auto it = graphs_.find(key);
+    if (it != graphs_.end() && it->second) {
+        if (rt_graph_launch(it->second, (rtStream)stream) != 0) {
+            eng_.log_.log(ILogger::Severity::kERROR, (std::string("graph launch failed: ") + rt_last_error_string()).c_str());
+            return false;
+        }
+        return !sync || rt_stream_sync((rtStream)stream) == 0;
+    }
+    if (it == graphs_.end() || graph_failed_.count(key)) {       // first pass with these bindings (or graphs are not available): launch by launch
+        if (it == graphs_.end()) graphs_[key] = nullptr;
+        return issue(batch, bindings, stream, sync, false);
+    }
+    if (rt_graph_begin_capture((rtStream)stream) != 0) {
+        eng_.log_.log(ILogger::Severity::kWARNING, (std::string("graph mode: capture unavailable (") + rt_last_error_string() + "), launching directly").c_str());
+        graph_failed_.insert(key);
+        return issue(batch, bindings, stream, sync, false);
+    }
+    const bool issued = issue(batch, bindings, stream, sync, true);
+    rtGraph* g = nullptr;
+    const int rc = rt_graph_end_capture((rtStream)stream, &g);
+    if (!issued || rc != 0 || !g) {
+        eng_.log_.log(ILogger::Severity::kWARNING, (std::string("graph mode: capture failed (") + rt_last_error_string() + "), launching directly").c_str());
+        graph_failed_.insert(key);
+        return issue(batch, bindings, stream, sync, false);
+    }
+    it->second = g;
+    if (rt_graph_launch(g, (rtStream)stream) != 0) return false;
+    return !sync || rt_stream_sync((rtStream)stream) == 0;
+}
+
+bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sync, bool capturing) {
     ILogger& log = eng_.log_;
     if (batch < 1 || batch > eng_.max_batch_) {
         log.log(ILogger::Severity::kERROR, "execute: batch size exceeds the engine's max batch size");
@@ -1894,7 +1941,7 @@ bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync
         rt_event_record(ev_join_, side_stream_);
         rt_stream_wait_event(main, ev_join_);
     }
-    if (sync || profile) ok = (rt_stream_sync(main) == 0) && ok;
+    if ((sync || profile) && !capturing) ok = (rt_stream_sync(main) == 0) && ok;
     if (profile && ok) {
         for (size_t i = 0; i < eng_.ops_.size(); i++) {
             float ms = 0.f;

@@ -302,6 +302,12 @@ extern "C" int rt_net_set_streams(rtStereoNet* net, int streams) {
     return 0;
 }
 
+extern "C" int rt_net_set_graph(rtStereoNet* net, int on) {
+    if (!net || !net->context) return fail("rt_net_set_graph: null pointer");
+    net->context->setGraphMode(on != 0);
+    return 0;
+}
+
 extern "C" int rt_net_num_layers(const rtStereoNet* net) { return net ? net->layers : 0; }
 extern "C" int rt_net_num_launches(const rtStereoNet* net) { return net && net->engine ? net->engine->getNbLayers() : 0; }
 extern "C" int rt_net_destroy(rtStereoNet* net) {

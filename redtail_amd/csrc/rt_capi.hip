@@ -202,6 +202,62 @@ extern "C" int rt_event_elapsed_ms(void* a, void* b, float* ms) {
     return 0;
 }
 
+// hipGraph capture / replay of a stream's launches (the executor's graph mode, engine.cpp: ContextImpl::run)
+struct rtGraph {
+#ifndef HIPEMU
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+#endif
+};
+extern "C" int rt_graph_begin_capture(rtStream s) {
+#ifdef HIPEMU
+    (void)s;
+    return fail(RT_E_UNSUPPORTED, "rt_graph_begin_capture: no graphs on the emulator");
+#else
+    RT_REQUIRE(s, "rt_graph_begin_capture: the NULL stream cannot be captured");
+    RT_HIP(hipStreamBeginCapture(S(s), hipStreamCaptureModeRelaxed));
+    return 0;
+#endif
+}
+extern "C" int rt_graph_end_capture(rtStream s, rtGraph** out) {
+    RT_REQUIRE(out, "rt_graph_end_capture: null");
+    *out = nullptr;
+#ifdef HIPEMU
+    (void)s;
+    return fail(RT_E_UNSUPPORTED, "rt_graph_end_capture: no graphs on the emulator");
+#else
+    hipGraph_t g = nullptr;
+    RT_HIP(hipStreamEndCapture(S(s), &g));
+    RT_REQUIRE(g, "rt_graph_end_capture: the capture produced no graph");
+    hipGraphExec_t e = nullptr;
+    const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    if (rc != hipSuccess) { (void)hipGraphDestroy(g); return fail((int)rc, "hipGraphInstantiate: %s", hipGetErrorString(rc)); }
+    rtGraph* r = new rtGraph;
+    r->graph = g; r->exec = e;
+    *out = r;
+    return 0;
+#endif
+}
+extern "C" int rt_graph_launch(rtGraph* g, rtStream s) {
+    RT_REQUIRE(g, "rt_graph_launch: null graph");
+#ifdef HIPEMU
+    (void)s;
+    return fail(RT_E_UNSUPPORTED, "rt_graph_launch: no graphs on the emulator");
+#else
+    RT_HIP(hipGraphLaunch(g->exec, S(s)));
+    return 0;
+#endif
+}
+extern "C" int rt_graph_destroy(rtGraph* g) {
+    if (!g) return 0;
+#ifndef HIPEMU
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+#endif
+    delete g;
+    return 0;
+}
+
 // =================================================================================================
 // element-wise
 // =================================================================================================

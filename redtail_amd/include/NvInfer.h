@@ -328,6 +328,11 @@ public:
     // MI355X, ResNet-18 2D 1257x369: six one-stream contexts 2270 pairs/s, four two-stream contexts 2100).
     virtual void setExecutionStreams(int) {}
     virtual int getExecutionStreams() const { return 2; }
+    // Extension: graph mode.  The second execute() / enqueue() with the same bindings, batch size and stream is captured as a
+    // hipGraph and every further one replays it with a single graph launch (a change of bindings captures another graph).
+    // Off by default: measured on MI355X the 25 launches of ResNet-18 2D cost the host 70-95 us, well under the 0.55 ms the GPU needs.
+    virtual void setGraphMode(bool) {}
+    virtual bool getGraphMode() const { return false; }
 protected:
     virtual ~IExecutionContext() {}
 };

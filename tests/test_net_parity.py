@@ -171,6 +171,43 @@ def test_resnet18_2d_one_stream_per_context(rt, monkeypatch, ksplit):
         assert np.abs(outs[0] - outs[1]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("streams", [2, 1])
+def test_resnet18_2d_graph_mode(rt, streams):
+    """IExecutionContext::setGraphMode (rt_net_set_graph): the second execute with the same pointers is captured as a hipGraph -- both
+    streams of the context inside one capture -- and later ones replay it; new pointers capture another graph; switching the mode off
+    returns to direct launches.  Same bits throughout.  (The emulator has no graphs: the context logs that and launches directly.)"""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 25, 41)
+    l2, r2 = pairs(1, 25, 41, seed=7)
+    net = rt.lib.create("resnet18_2D", 41, 25, max_batch=1, weights=w, max_disp=8)
+    net.set_streams(streams)
+    L, R, L2, R2 = rt.dev(l), rt.dev(r), rt.dev(l2), rt.dev(r2)
+
+    def run(a, b, out=None):
+        out = rt.empty(1, 1, 25, 41) if out is None else out
+        net.execute(a, b, out, 1)
+        return out, np.array(rt.host(out))
+
+    _, ref1 = run(L, R)
+    _, ref2 = run(L2, R2)
+    assert not np.isnan(ref1).any() and not np.array_equal(ref1, ref2)
+    net.set_graph(True)
+    out = rt.empty(1, 1, 25, 41)
+    for i in range(4):                                   # 1: direct, 2: capture + launch, 3, 4: replay
+        _, got = run(L, R, out)
+        assert np.array_equal(got, ref1), i
+    out2 = rt.empty(1, 1, 25, 41)
+    for i in range(3):                                   # other bindings: another graph; the first one stays valid
+        _, got = run(L2, R2, out2)
+        assert np.array_equal(got, ref2), i
+        _, got = run(L, R, out)
+        assert np.array_equal(got, ref1), i
+    net.set_graph(False)
+    _, got = run(L, R, out)
+    assert np.array_equal(got, ref1)
+    net.destroy()
+
+
 def test_resnet18_2d_unfused_equals_fused(rt, monkeypatch):
     """RT_NO_FUSION runs every plugin through its own enqueue(), i.e. the reference's layer-by-layer order"""
     w = O.synth_weights_resnet18_2d()
