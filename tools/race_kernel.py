@@ -13,7 +13,7 @@ from redtail_amd import capi  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-k = capi.KernelLib()
+k = capi.KernelLib(os.environ.get("RT_KLIB"))          # RT_KLIB: another build of the kernel library (probes)
 EX = capi.RT_CONV_EXACT_FP32
 H, W = 185, 629
 rng = np.random.default_rng(5)
