@@ -101,6 +101,9 @@ BLOCK_FLOPS = 2.0 * DOMINANT_FLOPS
 BLOCK_BYTES = 4.0 * (2 * 32 * HALF_W * HALF_H + 2 * (32 * 32 * 9 + 32))
 
 
+NATIVE_STARTUP_HUNG = [False]       # main(): the native multi-GPU start-up was abandoned in its thread -> leave with os._exit after the JSON line
+
+
 def measured_traffic(half2=False, fused=None):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/rNN_traffic.json,
     written by tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this
@@ -607,13 +610,30 @@ def main():
     transport, nets = "none (one rank)", None
     if distributed:
         import torch.distributed as dist
-        try:
-            nets, blob_crc = parallel.create_nets_native(lib, "resnet18_2D", W, H, args.contexts, blob, rank, world, dist, max_batch=args.batch,
-                                                         fp16_weights=args.half2)
+        # ... under a watchdog: a start-up that does not come back within two minutes (a communicator bootstrap that never completes) is
+        # abandoned in its daemon thread and the ranks agree on the fallback below -- a hang here would cost the whole scaling run
+        import threading
+        res = {}
+
+        def native_startup():
+            try:
+                lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")      # the current device is per host thread
+                res["nets"] = parallel.create_nets_native(lib, "resnet18_2D", W, H, args.contexts, blob, rank, world, dist, max_batch=args.batch,
+                                                          fp16_weights=args.half2)
+            except Exception as e:                              # noqa: BLE001 -- any failure of the native entry must not cost the scaling run
+                res["error"] = e
+
+        th = threading.Thread(target=native_startup, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("BENCH_NATIVE_STARTUP_TIMEOUT_S", "120")))
+        if "nets" in res:
+            nets, blob_crc = res["nets"]
             transport = "rccl-native (rt_net_create_broadcast)"
-        except Exception as e:                                  # noqa: BLE001 -- any failure of the native entry must not cost the scaling run
-            print("bench.py: rank %d: native RCCL entry failed (%s: %s) -- broadcasting the weight image through torch.distributed instead" % (
-                rank, type(e).__name__, e), file=sys.stderr, flush=True)
+        else:
+            NATIVE_STARTUP_HUNG[0] = th.is_alive()
+            why = "no answer within the watchdog's time" if th.is_alive() else "%s: %s" % (type(res.get("error")).__name__, res.get("error"))
+            print("bench.py: rank %d: native RCCL entry failed (%s) -- broadcasting the weight image through torch.distributed instead" % (rank, why),
+                  file=sys.stderr, flush=True)
             nets = None
         ok = torch.tensor([1 if nets is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)               # all ranks on the same transport
@@ -1026,3 +1046,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if NATIVE_STARTUP_HUNG[0]:          # a thread is still inside the abandoned communicator bootstrap: do not wait for it at interpreter exit
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
