@@ -580,7 +580,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
-    distributed = world > 1
+    # BENCH_FORCE_DISTRIBUTED=1: walk the multi-rank start-up (process group, native RCCL entry, agreement on the transport) with a world of
+    # one rank -- a single-GPU box cannot host two RCCL ranks, and this is how that code is exercised there (tests/test_multi_gpu.py)
+    distributed = world > 1 or (os.environ.get("BENCH_FORCE_DISTRIBUTED", "0") != "0" and "WORLD_SIZE" in os.environ)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

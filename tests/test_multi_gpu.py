@@ -216,3 +216,25 @@ def test_rccl_broadcast_of_weights(tmp_path, world):
         with torch.no_grad():
             ref = O.resnet18_2d(torch.from_numpy(l)[None], torch.from_numpy(r)[None], weights).numpy()
         assert np.abs(np.load(tmp_path / ("out%d.npy" % rank)) - ref).max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_startup_with_a_world_of_one():
+    """bench.py itself under the driver's launcher (torch.distributed.run), with BENCH_FORCE_DISTRIBUTED=1 so that a single rank
+    walks the multi-rank start-up: process group on RCCL, native entry (rt_comm_init_rank + rt_net_create_broadcast) inside its
+    watchdog thread, agreement on the transport, barrier + max over ranks.  The JSON line names the transport."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DISTRIBUTED="1")
+    env.pop("RT_DEV_KNOBS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3",
+           "--no-secondary", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["weights_transport"].startswith("rccl-native"), (line["config"]["weights_transport"], out.stderr[-1500:])
+    assert "weight image crc32" in out.stderr
