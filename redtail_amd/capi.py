@@ -124,6 +124,18 @@ def _ptr(x):
     raise TypeError("cannot take the address of %r" % type(x))
 
 
+def _host_weights(a, dtype, what):
+    """Plan constructors read host weight / bias arrays through a raw pointer: refuse an array of another element type (a float32
+    array divided by np.sqrt(...) is float64 under NumPy 2 and would be read as garbage)."""
+    if a is not None and hasattr(a, "dtype") and hasattr(a, "ctypes"):
+        want = "float16" if dtype == RT_F16 else "float32"
+        if a.dtype.name != want:
+            raise TypeError("%s: expected a %s array, got %s" % (what, want, a.dtype))
+        if not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("%s: array is not C-contiguous" % what)
+    return a
+
+
 class KernelLib:
     """The op-level C ABI.  `path=None` loads the gfx950 build and requires a visible GPU."""
 
@@ -221,6 +233,7 @@ class KernelLib:
     def conv2d_plan(self, w_host, b_host, Cin, Cout, Hin, Win, k, stride, pad, act=0, has_residual=False,
                     dtype=RT_F32, transposed=False, flags=0):
         d = Conv2dDesc(Cin, Cout, Hin, Win, k, k, stride, pad, pad, act, int(has_residual), dtype, flags)
+        _host_weights(w_host, dtype, "conv2d_plan weights"); _host_weights(b_host, dtype, "conv2d_plan bias")
         plan = c_void_p()
         fn = self.lib.rt_deconv2d_plan_create if transposed else self.lib.rt_conv2d_plan_create
         self.check(fn(ctypes.byref(plan), ctypes.byref(d), _ptr(w_host), _ptr(b_host)), "conv2d plan")

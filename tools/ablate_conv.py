@@ -45,7 +45,7 @@ def main():
     b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     cin = cout = 32
     h, w = 185, 629
-    wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
+    wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.float32(np.sqrt(cin * 9)))
     bias = np.random.randn(cout).astype(np.float32)
     pitch = 640 if (f16 or os.environ.get("RT_ABL_IL8")) else w
     x = torch.randn(b, cin, h, pitch, device="cuda", dtype=torch.float16 if f16 else torch.float32)

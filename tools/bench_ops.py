@@ -81,7 +81,7 @@ def main():
     for name, cin, cout, h, w, ks, st, pad, res, b, tr in conv_cases:
         if not want(name):
             continue
-        wt = (np.random.randn(cin * cout * ks * ks).astype(np.float32) / np.sqrt(cin * ks * ks))
+        wt = (np.random.randn(cin * cout * ks * ks).astype(np.float32) / np.float32(np.sqrt(cin * ks * ks)))
         bias = np.random.randn(cout).astype(np.float32)
         plan = k.conv2d_plan(wt, bias, cin, cout, h, w, ks, st, pad, act=capi.RT_ACT_ELU, has_residual=res, transposed=tr)
         co, ho, wo, _ = plan.out_dims
@@ -141,7 +141,7 @@ def main():
     if want("3d"):
         for name, Dd, Cc, Kk, Hh, Ww in (("conv3D_1 NVTiny (24,16,81,257)->16", 24, 16, 16, 81, 257),
                                          ("conv3D_1 NVSmall (48,64,161,513)->32", 48, 64, 32, 161, 513)):
-            wt = (np.random.randn(Kk * 3 * Cc * 9).astype(np.float32) / np.sqrt(27 * Cc))
+            wt = (np.random.randn(Kk * 3 * Cc * 9).astype(np.float32) / np.float32(np.sqrt(27 * Cc)))
             bias = np.random.randn(Kk).astype(np.float32)
             plan = k.conv3d_plan(wt, bias, Cc, Kk, (Dd, Hh, Ww), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1),
                                  act=capi.RT_ACT_ELU, out_dchw=True)

@@ -15,7 +15,7 @@ big = torch.empty(1 << 29, dtype=torch.float32, device="cuda")         # 2 GB
 
 
 def mk(cin, cout, h, w, stride):
-    wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(9 * cin))
+    wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.float32(np.sqrt(9 * cin)))
     plan = k.conv2d_plan(wt, np.random.randn(cout).astype(np.float32), cin, cout, h, w, 3, stride, 1, act=capi.RT_ACT_ELU, has_residual=False)
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
     ip, op = (w + 7) // 8 * 8, (wo + 7) // 8 * 8

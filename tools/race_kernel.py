@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from redtail_amd import capi  # noqa: E402
 
+POISON = os.environ.get("RACE_POISON", "0") != "0"      # NaN instead of zeros (then the never-written padding columns show as well)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 k = capi.KernelLib(os.environ.get("RT_KLIB"))          # RT_KLIB: another build of the kernel library (probes)
@@ -36,7 +37,7 @@ only = os.environ.get("CASE")
 for name, cin, cout, h, w, ks, st, tr, res, (xi, yi, ri), flags in CASES:
     if only and only not in name:
         continue
-    wt = (rng.standard_normal(cout * cin * ks * ks).astype(np.float32) / np.sqrt(cin * ks * ks))
+    wt = (rng.standard_normal(cout * cin * ks * ks).astype(np.float32) / np.float32(np.sqrt(cin * ks * ks)))
     bias = rng.standard_normal(cout).astype(np.float32)
     if tr:
         ho, wo = 2 * h - 1 + 0, 2 * w - 1 + 0
@@ -69,9 +70,11 @@ for name, cin, cout, h, w, ks, st, tr, res, (xi, yi, ri), flags in CASES:
     keep = [None] * NS
     for it in range(iters):
         for i, (p, x, r, y, s) in enumerate(sets):
+            with torch.cuda.stream(s):                      # poison the output first: a store that never lands must show (the previous launch left the same values)
+                y.fill_(float("nan") if POISON else 0.0)
             p.enqueue(x, y, r, 1, stream=s.cuda_stream)
             with torch.cuda.stream(s):                      # every output is checked, on its own stream, without a host sync
-                d = (torch.nan_to_num(y) - ref).abs().max()
+                d = (torch.nan_to_num(y, nan=1e30) - ref).abs().max()
                 cnt[i] += (d > 0)
                 worst[i] = torch.maximum(worst[i], d)
         if it % 256 == 255:

@@ -22,7 +22,7 @@ for name, (res, args) in capi.KERNEL_SYMBOLS.items():
     fn.restype, fn.argtypes = res, args
 cin = cout = 32
 h, w = 185, 629
-wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.sqrt(cin * 9))
+wt = (np.random.randn(cout * cin * 9).astype(np.float32) / np.float32(np.sqrt(cin * 9)))
 bias = np.random.randn(cout).astype(np.float32)
 plan = k.conv2d_plan(wt, bias, cin, cout, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
 x = torch.randn(b, cin, h, 640 if F16 else w, device="cuda", dtype=torch.float16 if F16 else torch.float32)

@@ -24,7 +24,7 @@ for name, (res, args) in capi.KERNEL_SYMBOLS.items():
     fn = getattr(k.lib, name)
     fn.restype, fn.argtypes = res, args
 h, w = 185, 629
-wt = (np.random.randn(32 * 32 * 9).astype(np.float32) / np.sqrt(288))
+wt = (np.random.randn(32 * 32 * 9).astype(np.float32) / np.float32(np.sqrt(288)))
 if block:
     plan = k.resblock_plan(wt, np.random.randn(32).astype(np.float32), wt[::-1].copy(), np.random.randn(32).astype(np.float32), 32, 32, h, w)
 else:

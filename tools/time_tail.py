@@ -19,7 +19,7 @@ for name, (res, args) in capi.KERNEL_SYMBOLS.items():
     fn = getattr(k.lib, name)
     fn.restype, fn.argtypes = res, args
 for c, h, w in ((64, 93, 315), (128, 47, 158)):
-    wt = (np.random.randn(c * c * 9).astype(np.float32) / np.sqrt(9 * c))
+    wt = (np.random.randn(c * c * 9).astype(np.float32) / np.float32(np.sqrt(9 * c)))
     plan = k.conv2d_plan(wt, np.random.randn(c).astype(np.float32), c, c, h, w, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=False)
     pitch = (w + 7) // 8 * 8
     plan.set_pitch(pitch, pitch)
