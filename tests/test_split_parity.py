@@ -167,6 +167,42 @@ def test_split_general(backend, monkeypatch, cin, cout, h, w, k, stride, tr, act
     assert np.array_equal(outs[1], outs[2])                       # layouts change addressing only
 
 
+@pytest.mark.parametrize("ksplit", ["2", "4"])
+@pytest.mark.parametrize("cin,cout,h,w,k,stride,tr,resid,batch", [
+    (64, 64, 10, 37, 3, 1, False, True, 2),        # 4 chunks: every group one (KS = 4) or two (KS = 2) of them
+    (80, 32, 9, 33, 3, 1, False, False, 1),        # 5 chunks: groups with 2 / 1 / 1 / 1 chunks
+    (32, 64, 11, 37, 3, 2, False, False, 1),       # stride 2: at most two groups (a request for 4 is clamped)
+    (128, 64, 5, 9, 3, 2, True, True, 1),          # transposed: 2 x 2 phase windows with tap masks, 8 chunks
+    (16, 40, 6, 35, 1, 1, False, False, 2),        # 1 x 1 window, ONE chunk: groups 1 .. KS-1 contribute zeros
+])
+def test_split_k_forced(backend, monkeypatch, cin, cout, h, w, k, stride, tr, resid, batch, ksplit):
+    """RT_S3_KSPLIT forces the number of contraction groups of conv_s3_kernel (the launch clamps it to what the instantiation's LDS and
+    register budget allow): uneven chunk counts, fewer chunks than groups, stride 2, transposed phases -- against the fp64 reference and
+    within rounding of the unsplit launch"""
+    x, b = rnd(batch, cin, h, w), rnd(cout)
+    wt = rnd(*((cin, cout, k, k) if tr else (cout, cin, k, k))) * np.float32(1 / np.sqrt(cin * k * k / (stride * stride if tr else 1)))
+    shape = ref64_g(x, wt, b, None, capi.RT_ACT_NONE, stride, tr).shape
+    res = rnd(*shape) if resid else None
+    ref = ref64_g(x, wt, b, res, capi.RT_ACT_ELU, stride, tr)
+    ho, wo = shape[-2:]
+    ip, op = (w + 31) // 32 * 32, (wo + 31) // 32 * 32
+    outs = []
+    for ks in (ksplit, "0"):
+        monkeypatch.setenv("RT_S3_KSPLIT", ks)
+        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, 1 if tr else k // 2, act=capi.RT_ACT_ELU, has_residual=resid, transposed=tr)
+        plan.set_pitch(ip, op)
+        plan.set_layouts(1, 1, 1 if resid else 0)
+        y = backend.empty((batch, cout // 4, ho, op, 4))
+        plan.enqueue(backend.dev(to_il(pitched(x, ip), 4)), y, backend.dev(to_il(pitched(res, op), 4)) if resid else None, batch)
+        out = from_il(backend.host(y).copy())
+        plan.destroy()
+        assert np.isnan(out[..., wo:]).all() if op > wo else True, "padding columns were written"
+        outs.append(out[..., :wo])
+    tol = 4e-7 * np.sqrt(cin * k * k) + 2e-6
+    assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
+    assert np.abs(outs[0] - outs[1]).max() <= tol
+
+
 @pytest.mark.parametrize("cin,cout,h,w,batch,pitch,y_il", [
     (3, 32, 21, 77, 2, 64, 1),        # ResNet-18 2D / NVSmall first layer
     (3, 32, 9, 129, 1, 96, 0),
