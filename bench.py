@@ -619,7 +619,8 @@ def main():
 
         def native_startup():
             try:
-                lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")      # the current device is per host thread
+                torch.cuda.set_device(dev)                      # the current device is per host thread: torch's (the id travels as a device tensor) ...
+                lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")      # ... and HIP's
                 res["nets"] = parallel.create_nets_native(lib, "resnet18_2D", W, H, args.contexts, blob, rank, world, dist, max_batch=args.batch,
                                                           fp16_weights=args.half2)
             except Exception as e:                              # noqa: BLE001 -- any failure of the native entry must not cost the scaling run

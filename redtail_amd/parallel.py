@@ -28,7 +28,10 @@ def native_comm(lib, rank, world, dist=None):
     backend; its store, not a data path).  Call after rt_set_device."""
     uid = [lib.comm_unique_id() if rank == 0 else None]
     if world > 1:
-        dist.broadcast_object_list(uid, src=0)
+        kw = {}
+        if dist.get_backend() == "nccl":        # the pickled id travels as a tensor on THIS thread's current device (bench.py calls from a worker thread)
+            kw["device"] = torch.device("cuda", torch.cuda.current_device())
+        dist.broadcast_object_list(uid, src=0, **kw)
     return lib.comm_init_rank(world, rank, uid[0])
 
 
