@@ -273,6 +273,11 @@ int rt_conv_plan_input_limit(const rtConvPlan* plan, float* limit);
 int rt_check_range(const void* x, int64_t rows, int64_t valid, int64_t pitch, int dtype, float limit, float* max_abs, int64_t* violations,
                    rtStream stream);
 
+/* Order-independent 64-bit checksum of `bytes` (a multiple of 4) of device memory, written to the device word `out_dev` on `stream`
+ * (asynchronous).  Two buffers with the same bits give the same value; the executor's launch trace (rt_net_set_launch_trace) hashes every
+ * launch's output with it so that two passes over the same input can be compared launch by launch without copying tensors. */
+int rt_hash_buffer(const void* x, size_t bytes, unsigned long long* out_dev, rtStream stream);
+
 /* Output dims of a plan: 2-D -> (Cout,Hout,Wout,1); 3-D -> 4 dims in the order they are written. */
 int rt_conv_plan_out_dims(const rtConvPlan* plan, int dims[4]);
 /* Run: x, y (and residual, shaped like y, or NULL) are device pointers for `batch` samples. */

@@ -90,6 +90,14 @@ int rt_net_set_graph(rtStereoNet* net, int on);
 /* Debug mode (IExecutionContext::setDebugSync): every launch is synchronised and the input of every fp16-pipe convolution is range-checked
  * first (rt_check_range): an execute() whose activations leave the fp16-split domain fails with the layer's name in rt_net_last_error(). */
 int rt_net_set_debug(rtStereoNet* net, int on);
+/* Launch trace (IExecutionContext::setLaunchTrace, a debugging aid): while on, the output of every launch is hashed on the launch's own
+ * stream (rt_stereo.h: rt_hash_buffer).  rt_net_read_launch_trace waits for the last pass and returns one value per launch (count, or -1);
+ * two passes over the same input must agree launch by launch -- the first index that differs names the kernel that deviated.
+ * rt_net_launch_name: the launch's layer name; rt_net_read_launch_output: its output tensor as stored (host == NULL: size in bytes). */
+int rt_net_set_launch_trace(rtStereoNet* net, int on);
+int rt_net_read_launch_trace(rtStereoNet* net, unsigned long long* hashes, int max);
+const char* rt_net_launch_name(const rtStereoNet* net, int launch);
+long long rt_net_read_launch_output(rtStereoNet* net, int launch, void* host, long long bytes);
 int rt_net_num_launches(const rtStereoNet* net);   /* kernel launches after fusion       */
 int rt_net_destroy(rtStereoNet* net);
 const char* rt_net_last_error(void);

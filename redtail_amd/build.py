@@ -80,6 +80,22 @@ def build_hip_ablation(mask, force=False, timing=False):
     return out
 
 
+def build_variant(name, defines, force=False):
+    """Another build of the two product libraries side by side in tools/build/<name>/ (probes: RT_EXPERIMENTAL kernel families, hazard
+    probes ...; never the product).  Tools take the directory through RT_VARIANT_DIR."""
+    outdir = os.path.join(ROOT, "tools", "build", name)
+    os.makedirs(outdir, exist_ok=True)
+    kern = os.path.join(outdir, "librt_stereo_hip.so")
+    host = os.path.join(outdir, "libnvstereo_inference.so")
+    deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
+    if force or _newer(kern, deps):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + list(defines) +
+             [os.path.join(CSRC, "rt_capi.hip"), "-o", kern])
+    if force or _newer(host, [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]):
+        _build_host_against(kern, host)
+    return outdir
+
+
 def build_emu(force=False):
     """Host build of the same kernel sources on top of tests/emu (test infrastructure)."""
     os.makedirs(EMU_BUILD, exist_ok=True)

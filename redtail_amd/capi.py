@@ -88,6 +88,7 @@ KERNEL_SYMBOLS = {
     "rt_graph_launch": (c_int, [c_void_p, c_void_p]),
     "rt_graph_destroy": (c_int, [c_void_p]),
     "rt_check_range": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_float, POINTER(c_float), POINTER(c_int64), c_void_p]),
+    "rt_hash_buffer": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "rt_conv_plan_out_dims": (c_int, [c_void_p, POINTER(c_int)]),
     "rt_conv_plan_set_pitch": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_plan_set_batch_strides": (c_int, [c_void_p, c_int64, c_int64, c_int64]),
@@ -334,6 +335,10 @@ NET_SYMBOLS = {
     "rt_net_weights_image": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "rt_net_create_opt": (c_int, [POINTER(c_void_p), c_void_p]),
     "rt_net_set_debug": (c_int, [c_void_p, c_int]),
+    "rt_net_set_launch_trace": (c_int, [c_void_p, c_int]),
+    "rt_net_read_launch_trace": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong), c_int]),
+    "rt_net_launch_name": (c_char_p, [c_void_p, c_int]),
+    "rt_net_read_launch_output": (ctypes.c_longlong, [c_void_p, c_int, c_void_p, ctypes.c_longlong]),
     "rt_net_destroy": (c_int, [c_void_p]),
     "rt_net_last_error": (c_char_p, []),
 }
@@ -477,6 +482,33 @@ class StereoNet:
         p, n = c_void_p(), c_size_t()
         self.netlib.check(self.netlib.lib.rt_net_weights_image(self.handle, ctypes.byref(p), ctypes.byref(n)), "rt_net_weights_image")
         return ctypes.string_at(p.value, n.value)
+
+    def set_launch_trace(self, on=True):
+        """hash every launch's output on its own stream (debugging aid): read_launch_trace() after a pass"""
+        self.netlib.check(self.netlib.lib.rt_net_set_launch_trace(self.handle, int(on)), "rt_net_set_launch_trace")
+
+    def read_launch_trace(self):
+        n = self.num_launches
+        buf = (ctypes.c_ulonglong * n)()
+        got = self.netlib.lib.rt_net_read_launch_trace(self.handle, buf, n)
+        if got < 0:
+            raise RtError("rt_net_read_launch_trace failed: " + self.netlib.lib.rt_net_last_error().decode())
+        return list(buf[:got])
+
+    def launch_name(self, i):
+        s = self.netlib.lib.rt_net_launch_name(self.handle, i)
+        return s.decode() if s else None
+
+    def read_launch_output(self, i):
+        """raw bytes of launch i's output tensor as stored on the device (numpy uint8 array)"""
+        import numpy as np
+        n = self.netlib.lib.rt_net_read_launch_output(self.handle, i, None, 0)
+        if n < 0:
+            raise RtError("rt_net_read_launch_output failed: " + self.netlib.lib.rt_net_last_error().decode())
+        out = np.empty(n, np.uint8)
+        if self.netlib.lib.rt_net_read_launch_output(self.handle, i, out.ctypes.data, n) != n:
+            raise RtError("rt_net_read_launch_output failed: " + self.netlib.lib.rt_net_last_error().decode())
+        return out
 
     def set_streams(self, n):
         """1: all launches on the caller's stream (throughput with several contexts); 2: second stream for the right encoder"""

@@ -351,6 +351,10 @@ public:
     IProfiler* getProfiler() const override { return profiler_; }
     const ICudaEngine& getEngine() const override;
     void destroy() override { delete this; }
+    void setLaunchTrace(bool on) override { trace_ = on; }
+    int readLaunchTrace(unsigned long long* hashes, int max) override;
+    const char* getLaunchName(int i) const override;
+    long long readLaunchOutput(int launch, void* host, long long bytes) override;
 
 private:
     bool run(int batch, void** bindings, cudaStream_t stream, bool sync);
@@ -380,6 +384,14 @@ private:
     std::set<std::vector<uintptr_t>> graph_failed_;
     std::map<std::pair<int, int>, std::pair<void*, size_t>> half_buf_;   // (op, slot) -> fp16 staging buffer of a kHALF plugin
     void* halfBuffer(int op, int slot, size_t bytes);
+    // launch trace (setLaunchTrace): one device word per launch, the stream and the extent of the last pass's outputs
+    bool trace_ = false;
+    void* trace_dev_ = nullptr;
+    rtStream trace_stream_ = nullptr;
+    int trace_batch_ = 0;
+    std::vector<void*> trace_ptr_;
+    size_t outBytes(const Op& op, int batch) const;
+    void dropGraphs();
 };
 
 class HostMemory : public IHostMemory {
@@ -1636,6 +1648,7 @@ ContextImpl::~ContextImpl() {
     for (void* b : buffers_)
         if (b) rt_free(b);
     if (workspace_) rt_free(workspace_);
+    if (trace_dev_) rt_free(trace_dev_);
     for (auto& kv : half_buf_)
         if (kv.second.first) rt_free(kv.second.first);
     for (void* ev : events_)
@@ -1652,9 +1665,19 @@ ContextImpl::~ContextImpl() {
 
 const ICudaEngine& ContextImpl::getEngine() const { return eng_; }
 
+// A captured graph bakes in the addresses of the internal buffers: whenever one of them is freed or reallocated, every captured pass
+// is stale and must be captured again (batch 1, batch 2, batch 1 in graph mode replayed freed memory).
+void ContextImpl::dropGraphs() {
+    for (auto& g : graphs_)
+        if (g.second) rt_graph_destroy(g.second);
+    graphs_.clear();
+    graph_failed_.clear();
+}
+
 void* ContextImpl::halfBuffer(int op, int slot, size_t bytes) {
     auto& e = half_buf_[{op, slot}];
     if (e.second < bytes) {
+        if (e.first) { rt_stream_sync(nullptr); dropGraphs(); }
         if (e.first) rt_free(e.first);
         e.first = nullptr;
         e.second = 0;
@@ -1666,6 +1689,12 @@ void* ContextImpl::halfBuffer(int op, int slot, size_t bytes) {
 
 bool ContextImpl::ensureBuffers(int batch) {
     if (batch <= alloc_batch_) return true;
+    if (alloc_batch_ > 0) {             // growing: earlier passes may still be in flight on the old buffers, captured graphs point at them
+        rt_stream_sync(nullptr);
+        if (main_stream_) rt_stream_sync(main_stream_);
+        if (side_stream_) rt_stream_sync(side_stream_);
+        dropGraphs();
+    }
     for (void*& b : buffers_) {
         if (b) rt_free(b);
         b = nullptr;
@@ -1767,7 +1796,7 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
 // second is captured -- the side stream joins the capture through the fork event and leaves it through the join event -- and from then
 // on a pass is one rt_graph_launch.  Profiling and debug mode keep the launch-by-launch path.
 bool ContextImpl::run(int batch, void** bindings, cudaStream_t stream, bool sync) {
-    if (!graph_mode_ || profiler_ || debug_sync_ || !stream) return issue(batch, bindings, stream, sync, false);
+    if (!graph_mode_ || profiler_ || debug_sync_ || trace_ || !stream) return issue(batch, bindings, stream, sync, false);
     std::vector<uintptr_t> key{(uintptr_t)stream, (uintptr_t)batch, (uintptr_t)streams_, (uintptr_t)sync};
     for (int b = 0; b < eng_.getNbBindings(); b++) key.push_back((uintptr_t)bindings[b]);
     auto it = graphs_.find(key);
@@ -1807,6 +1836,12 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
         return false;
     }
     if (!ensureBuffers(batch)) return false;
+    if (trace_ && !capturing) {
+        if (!trace_dev_ && rt_malloc(&trace_dev_, 8 * eng_.ops_.size() + 8) != 0) return false;
+        trace_ptr_.assign(eng_.ops_.size(), nullptr);
+        trace_stream_ = stream;
+        trace_batch_ = batch;
+    }
     const bool profile = profiler_ != nullptr;
     const bool two = eng_.two_streams_ && streams_ > 1;
     rtStream main = stream;
@@ -1923,6 +1958,14 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
             break;
         }
         if (profile) rt_event_record(prof_events_[2 * op_index + 1], st);
+        if (trace_ && !capturing) {     // hash the output where it was produced: same stream, right behind the launch
+            trace_ptr_[op_index] = y;
+            if (rt_hash_buffer(y, outBytes(op, batch), static_cast<unsigned long long*>(trace_dev_) + op_index, st) != 0) {
+                log.log(ILogger::Severity::kERROR, (op.name + ": launch trace failed: " + rt_last_error_string()).c_str());
+                ok = false;
+                break;
+            }
+        }
         if (two && op.publish) {       // make the result visible to the consumer on the other stream
             int r = op.out;
             while (eng_.tensors_[r]->alias_of >= 0) r = eng_.tensors_[r]->alias_of;
@@ -1956,6 +1999,42 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
         }
     }
     return ok;
+}
+
+// ---- launch trace (IExecutionContext::setLaunchTrace) --------------------------------------------------------------------------
+// bytes of a launch's output as it lies in memory: the dense (or pitched) tensor for `batch` samples -- both towers' samples for a merged
+// siamese launch; a tensor placed inside another buffer with its own sample stride (folded concatenation) is covered for its first
+// sample only (the samples are not contiguous there)
+size_t ContextImpl::outBytes(const Op& op, int batch) const {
+    const TensorImpl& t = *eng_.tensors_[op.out];
+    const size_t elems = t.pitch ? (size_t)t.dims.d[0] * t.dims.d[1] * t.pitch : (size_t)volume(t.dims);
+    const size_t es = (t.f16 && !t.is_output && !t.is_input) ? 2 : 4;
+    size_t n = elems * es;
+    if (t.bstride == 0 && t.alias_of < 0) n *= (size_t)batch * (op.twin ? 2 : 1);
+    return n & ~(size_t)3;
+}
+
+int ContextImpl::readLaunchTrace(unsigned long long* hashes, int max) {
+    if (!trace_dev_ || !hashes || max <= 0) return 0;
+    if (trace_stream_) rt_stream_sync(trace_stream_);
+    else if (main_stream_) rt_stream_sync(main_stream_);
+    const int n = std::min<int>(max, (int)eng_.ops_.size());
+    if (rt_memcpy_d2h(hashes, trace_dev_, 8 * (size_t)n, nullptr) != 0 || rt_stream_sync(nullptr) != 0) return -1;
+    return n;
+}
+
+const char* ContextImpl::getLaunchName(int i) const {
+    return (i >= 0 && i < (int)eng_.ops_.size()) ? eng_.ops_[i].name.c_str() : nullptr;
+}
+
+long long ContextImpl::readLaunchOutput(int launch, void* host, long long bytes) {
+    if (launch < 0 || launch >= (int)eng_.ops_.size() || launch >= (int)trace_ptr_.size() || !trace_ptr_[launch]) return -1;
+    const long long n = (long long)outBytes(eng_.ops_[launch], trace_batch_);
+    if (!host) return n;
+    if (bytes < n) return -1;
+    if (trace_stream_) rt_stream_sync(trace_stream_);
+    if (rt_memcpy_d2h(host, trace_ptr_[launch], (size_t)n, nullptr) != 0 || rt_stream_sync(nullptr) != 0) return -1;
+    return n;
 }
 
 // ---- builder / runtime ------------------------------------------------------------------------------------------

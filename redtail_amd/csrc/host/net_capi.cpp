@@ -308,6 +308,30 @@ extern "C" int rt_net_set_graph(rtStereoNet* net, int on) {
     return 0;
 }
 
+extern "C" int rt_net_set_launch_trace(rtStereoNet* net, int on) {
+    if (!net || !net->context) return fail("rt_net_set_launch_trace: null pointer");
+    net->context->setLaunchTrace(on != 0);
+    return 0;
+}
+
+extern "C" int rt_net_read_launch_trace(rtStereoNet* net, unsigned long long* hashes, int max) {
+    if (!net || !net->context || !hashes) { fail("rt_net_read_launch_trace: null pointer"); return -1; }
+    const int n = net->context->readLaunchTrace(hashes, max);
+    if (n < 0) fail("rt_net_read_launch_trace: read-back failed");
+    return n;
+}
+
+extern "C" const char* rt_net_launch_name(const rtStereoNet* net, int launch) {
+    return net && net->context ? net->context->getLaunchName(launch) : nullptr;
+}
+
+extern "C" long long rt_net_read_launch_output(rtStereoNet* net, int launch, void* host, long long bytes) {
+    if (!net || !net->context) { fail("rt_net_read_launch_output: null pointer"); return -1; }
+    const long long n = net->context->readLaunchOutput(launch, host, bytes);
+    if (n < 0) fail("rt_net_read_launch_output: no traced pass, bad launch index or buffer too small");
+    return n;
+}
+
 extern "C" int rt_net_num_layers(const rtStereoNet* net) { return net ? net->layers : 0; }
 extern "C" int rt_net_num_launches(const rtStereoNet* net) { return net && net->engine ? net->engine->getNbLayers() : 0; }
 extern "C" int rt_net_destroy(rtStereoNet* net) {

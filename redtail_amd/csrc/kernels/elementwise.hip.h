@@ -75,4 +75,17 @@ __global__ void __launch_bounds__(256) range_check_kernel(const T* __restrict__ 
     if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), bad);
 }
 
+// Order-independent 64-bit checksum of a device buffer (rt_hash_buffer): sum over the 4-byte words of mix(word, index) modulo 2^64.
+// Bit-exact comparison of tensors without copying them to the host: the executor's launch trace (IExecutionContext::setLaunchTrace)
+// hashes every launch's output on the launch's own stream, so two passes over the same input can be compared launch by launch.
+__global__ void __launch_bounds__(256) hash_words_kernel(const unsigned* __restrict__ x, int64_t words, unsigned long long* out) {
+    unsigned long long h = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long v = ((unsigned long long)x[i] + 0x9e3779b97f4a7c15ull) * (2ull * (unsigned long long)i + 1ull);
+        v ^= v >> 29;
+        h += v * 0xbf58476d1ce4e5b9ull;
+    }
+    if (h) atomicAdd(out, h);
+}
+
 }  // namespace rt

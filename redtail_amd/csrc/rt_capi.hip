@@ -557,6 +557,8 @@ struct rtConvPlan {
     // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
     int is_conv3d = 0, is_deconv3d = 0;
     int c3d_C = 0, c3d_cin = 0, c3d_dchw = 0, c3d_fold = 0;
+    int flags = 0;                                // RT_CONV_* option bits of the descriptor(s) the plan was created with: every later re-planning
+                                                  // (set_io_types, set_layouts, set_pitch) runs under the same options (ExactScope)
 };
 
 namespace {
@@ -1001,7 +1003,7 @@ extern "C" int rt_conv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, co
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
     plan->is2d = 1; plan->cin = d->Cin; plan->hin = d->Hin; plan->win = d->Win;
-    plan->desc2d = *d; plan->is_deconv = 0;
+    plan->desc2d = *d; plan->is_deconv = 0; plan->flags = d->flags;
 
     SubConv sc;
     sc.KH = d->KH; sc.KW = d->KW; sc.S = d->stride;
@@ -1055,7 +1057,7 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
     plan->x_bstride = (int64_t)d1->Cin * d1->Hin * d1->Win;
     plan->y_bstride = (int64_t)d2->Cout * d1->Hin * d1->Win;
     plan->is2d = 1; plan->cin = d1->Cin; plan->hin = d1->Hin; plan->win = d1->Win;
-    plan->desc2d = *d2; plan->is_deconv = 0;
+    plan->desc2d = *d2; plan->is_deconv = 0; plan->flags = d1->flags | d2->flags;
     plan->rb_act1 = d1->act; plan->rb_cmid = d1->Cout;
     SubConv sc;
     sc.KH = 3; sc.KW = 3; sc.S = 1; sc.Cout = d2->Cout; sc.Hi = d1->Hin; sc.Wi = d1->Win; sc.Ho = d1->Hin; sc.Wo = d1->Win;
@@ -1111,7 +1113,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
     plan->x_bstride = (int64_t)d->Cin * d->Hin * d->Win;
     plan->y_bstride = (int64_t)d->Cout * Ho * Wo;
     plan->is2d = 1; plan->cin = d->Cin; plan->hin = d->Hin; plan->win = d->Win;
-    plan->desc2d = *d; plan->is_deconv = 1;
+    plan->desc2d = *d; plan->is_deconv = 1; plan->flags = d->flags;
     const std::vector<float> w = to_f32(weights, (size_t)d->Cin * d->Cout * d->KH * d->KW, d->dtype);
     plan->w_canon = w;
     const int Cin = d->Cin, Cout = d->Cout, KH = d->KH, KW = d->KW;
@@ -1251,6 +1253,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     if (!window_supported(R, Sk, sh)) return fail(RT_E_UNSUPPORTED, "conv3d: window %dx%d stride %d", R, Sk, sh);
 
     auto plan = new rtConvPlan();
+    plan->flags = d->flags;
     plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     const int K = d->K, C = d->C;
     if (d->out_dchw) { plan->out_dims[0] = Do; plan->out_dims[1] = K; }
@@ -1335,6 +1338,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     RT_REQUIRE((int64_t)K * Dy * Hy * Wy < (1ll << 29), "conv3d_transpose: input sample exceeds 2 GB (32-bit buffer offsets)");
 
     auto plan = new rtConvPlan();
+    plan->flags = d->flags;
     plan->act = d->act; plan->has_resid = d->has_residual; plan->dtype = RT_F32; plan->w_f16 = d->dtype == RT_F16;
     plan->out_dims[0] = cdhw ? C : Dlim; plan->out_dims[1] = cdhw ? Dlim : C; plan->out_dims[2] = Hx; plan->out_dims[3] = Wx;
     plan->x_bstride = (int64_t)K * Dy * Hy * Wy;
@@ -1707,6 +1711,7 @@ bool f16mma_window(const SubConv& sc) {
 // are written as one 4-byte word).
 extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype) {
     RT_REQUIRE(plan, "rt_conv_plan_set_io_types: null plan");
+    ExactScope exact_scope(plan->flags);       // re-planning (repack_f32: choose_tiling, s3first / s3p eligibility) under the plan's own options
     RT_REQUIRE((x_dtype == RT_F32 || x_dtype == RT_F16) && (y_dtype == RT_F32 || y_dtype == RT_F16), "rt_conv_plan_set_io_types: bad dtype");
     if (!plan->is2d) {
         // 3-D plans (Conv3D / Conv3DTranspose): fp16 storage of the dense (D,C,H,W) / (K,D,H,W) tensors, the split-fp16 kernel
@@ -1784,6 +1789,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
 // bit 0 input, bit 1 output, bit 2 residual; 0 = none ...
 extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (!plan) return 0;
+    ExactScope exact_scope(plan->flags);
     if (!plan->is2d) {
         // 3-D plans, half2 mode: fp16 tensors in depth-major form (D, C, H, W) may be stored (D, C/8, H, W, 8).  Conv3D on fp16
         // operands reads and (with the fused Transform, out_dchw) writes them; the folded-cost-volume Conv3D (fp32 maps in) writes
@@ -1837,6 +1843,7 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
 // ... and the layout of each of them (0 = planar NCHW with a row pitch, 1 = (C/4, H, pitch, 4) fp32 / (C/8, H, pitch, 8) fp16)
 extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
     RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
+    ExactScope exact_scope(plan->flags);
     if (!x_il8 && !y_il8 && !r_il8) {
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
@@ -1894,6 +1901,17 @@ extern "C" int rt_check_range(const void* x, int64_t rows, int64_t valid, int64_
     std::memcpy(&m, &host[0], 4);
     if (max_abs) *max_abs = m;
     if (violations) *violations = (int64_t)(((unsigned long long)host[3] << 32) | host[2]);
+    return 0;
+}
+
+extern "C" int rt_hash_buffer(const void* x, size_t bytes, unsigned long long* out_dev, rtStream s) {
+    RT_REQUIRE(x && out_dev && bytes % 4 == 0, "rt_hash_buffer: null pointer or a size that is not a multiple of 4");
+    RT_HIP(hipMemsetAsync(out_dev, 0, 8, S(s)));
+    if (!bytes) return 0;
+    const int64_t words = (int64_t)(bytes / 4);
+    const unsigned grid = (unsigned)std::min<int64_t>(rt::cdiv(words, 256 * 8), 1024);
+    hipLaunchKernelGGL(rt::hash_words_kernel, dim3(grid ? grid : 1), dim3(256), 0, S(s), static_cast<const unsigned*>(x), words, out_dev);
+    RT_LAUNCH_CHECK("hash_words_kernel");
     return 0;
 }
 

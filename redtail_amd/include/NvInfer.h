@@ -333,6 +333,14 @@ public:
     // Off by default: measured on MI355X the 25 launches of ResNet-18 2D cost the host 70-95 us, well under the 0.55 ms the GPU needs.
     virtual void setGraphMode(bool) {}
     virtual bool getGraphMode() const { return false; }
+    // Extension: launch trace (a debugging aid).  While it is on, every launch's output tensor is hashed on the launch's own stream
+    // (rt_hash_buffer) right after the launch; readLaunchTrace() waits for the pass and returns one 64-bit value per launch, in launch
+    // order, so two passes over the same input can be compared launch by launch.  getLaunchName / readLaunchOutput name a launch and copy
+    // its output tensor (as stored: fp32 / fp16, planar / interleaved, pitched) to the host.
+    virtual void setLaunchTrace(bool) {}
+    virtual int readLaunchTrace(unsigned long long* /*hashes*/, int /*max*/) { return 0; }
+    virtual const char* getLaunchName(int) const { return nullptr; }
+    virtual long long readLaunchOutput(int /*launch*/, void* /*host*/, long long /*bytes*/) { return -1; }
 protected:
     virtual ~IExecutionContext() {}
 };

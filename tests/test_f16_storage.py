@@ -224,11 +224,15 @@ def test_conv2d_f16_fuzz(backend, cin, cout, h, w, resid, x_il8, y_il8, r_il8, a
     plan.destroy()
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("cin,cout,h,w,k,stride,tr", [(32, 32, 9, 37, 3, 1, False), (3, 32, 11, 29, 5, 2, False), (64, 32, 5, 9, 3, 2, True)])
-def test_io_types_round_trip_restores_fp32(backend, cin, cout, h, w, k, stride, tr):
+def test_io_types_round_trip_restores_fp32(backend, cin, cout, h, w, k, stride, tr, exact):
     """set_io_types(F16, ..) switches a plan to the fp16-operand kernels (fp16 weight slabs, fp16 tiling);
     set_io_types(F32, F32) afterwards -- what the executor does when half2 mode has to fall back -- must restore the
-    fp32 form completely: same bits as a plan that never left fp32 (round 1 returned NaN with a success code)."""
+    fp32 form completely: same bits as a plan that never left fp32 (round 1 returned NaN with a success code).  exact: a plan created
+    with RT_CONV_EXACT_FP32 comes back as an exact-fp32 plan (the re-planning ran outside the option's scope and silently
+    returned a split-fp16 plan with its |x| < 65504 domain)."""
+    flags = capi.RT_CONV_EXACT_FP32 if exact else 0
     batch, pad = 2, (k // 2 if not tr else 1)
     x, b = rnd(batch, cin, h, w), rnd(cout)
     wt = rnd(*((cin, cout, k, k) if tr else (cout, cin, k, k))) * np.float32(1 / np.sqrt(cin * k * k))
@@ -237,11 +241,14 @@ def test_io_types_round_trip_restores_fp32(backend, cin, cout, h, w, k, stride, 
     ip, op = (w + 63) // 64 * 64, (wo + 63) // 64 * 64
     outs = []
     for switch in (False, True):
-        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, pad, transposed=tr)
+        plan = backend.klib.conv2d_plan(wt, b, cin, cout, h, w, k, stride, pad, transposed=tr, flags=flags)
         plan.set_pitch(ip, op)
+        limit = plan.input_limit()
+        assert limit == (float("inf") if exact else 65504.0)
         if switch:
             plan.set_io_types(capi.RT_F32 if cin == 3 else capi.RT_F16, capi.RT_F16)
             plan.set_io_types(capi.RT_F32, capi.RT_F32)
+            assert plan.input_limit() == limit
         y = backend.empty(ref.shape[:-1] + (op,))
         plan.enqueue(backend.dev(pitched(x, ip)), y, None, batch)
         outs.append(np.array(backend.host(y))[..., :wo])

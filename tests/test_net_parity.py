@@ -679,3 +679,67 @@ def test_debug_mode_reports_the_fp16_split_domain(rt):
     wt = np.zeros((4, 4, 3, 3), np.float32)
     assert k.conv2d_plan(wt, None, 4, 4, 9, 9, 3, 1, 1).input_limit() == 65504.0
     assert k.conv2d_plan(wt, None, 4, 4, 9, 9, 3, 1, 1, flags=capi.RT_CONV_EXACT_FP32).input_limit() == float("inf")
+
+
+def test_launch_trace_names_the_launch_that_differs(rt):
+    """IExecutionContext::setLaunchTrace (rt_net_set_launch_trace): one hash per launch, equal for two passes over the same pair,
+    different from the first launch on for another pair -- and only from the first launch that sees the other image on;
+    rt_net_read_launch_output returns a launch's tensor as stored (the last launch writes the `disp` binding)."""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 25, 41)
+    l2, _ = pairs(1, 25, 41, seed=99)
+    net = rt.lib.create("resnet18_2D", 41, 25, weights=w, max_disp=8)
+    net.set_launch_trace(True)
+    out = rt.empty(1, 1, 25, 41)
+    net.execute(rt.dev(l), rt.dev(r), out, 1)
+    a = net.read_launch_trace()
+    first = np.array(rt.host(out))
+    net.execute(rt.dev(l), rt.dev(r), out, 1)
+    b = net.read_launch_trace()
+    assert len(a) == net.num_launches and a == b and len(set(a)) > len(a) // 2
+    names = [net.launch_name(i) for i in range(len(a))]
+    assert names[0] and net.launch_name(len(a)) is None
+    last = net.read_launch_output(len(a) - 1).view(np.float32).reshape(1, 1, 25, 41)
+    assert np.array_equal(last, first)
+    net.execute(rt.dev(l2), rt.dev(r), out, 1)               # another LEFT image: right-tower-only launches keep their hashes
+    c = net.read_launch_trace()
+    differs = [i for i in range(len(a)) if a[i] != c[i]]
+    same = [names[i] for i in range(len(a)) if a[i] == c[i]]
+    assert differs and differs[-1] == len(a) - 1
+    assert all(n.startswith("right_") for n in same), same
+    net.set_launch_trace(False)
+    net.destroy()
+
+
+@pytest.mark.gpu
+def test_graph_mode_survives_a_growing_batch():
+    """captured graphs bake in the addresses of the context's internal buffers, and a larger batch reallocates them --
+    batch 1 (captured), batch 2, batch 1 again must not replay the stale graph"""
+    lib = netlib("gpu")
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(2, 65, 129)
+    net = lib.create("resnet18_2D", 129, 65, max_batch=2, weights=w, max_disp=16)
+    L, R = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    o1 = torch.full((1, 1, 65, 129), float("nan"), device="cuda")
+    o2 = torch.full((2, 1, 65, 129), float("nan"), device="cuda")
+    net.execute(L, R, o1, 1)
+    torch.cuda.synchronize()
+    ref1 = o1.cpu().numpy().copy()
+    net.set_graph(True)
+    for _ in range(3):                                        # direct, capture + launch, replay
+        o1.fill_(float("nan"))
+        net.execute(L, R, o1, 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(o1.cpu().numpy(), ref1)
+    for _ in range(3):
+        net.execute(L, R, o2, 2)                              # buffers grow: every captured pass is dropped
+        torch.cuda.synchronize()
+    assert np.array_equal(o2.cpu().numpy()[:1], ref1)
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]     # whatever was freed is somebody else's now
+    for _ in range(3):
+        o1.fill_(float("nan"))
+        net.execute(L, R, o1, 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(o1.cpu().numpy(), ref1)
+    del junk
+    net.destroy()

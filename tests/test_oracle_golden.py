@@ -161,3 +161,89 @@ def test_corr_cpu_c_restatement(golden):
     assert np.abs(out[:, :, None] - want).max() <= 1e-6
     ref = O.corr_cost_volume(T(l).reshape(n, c, h, w), T(r).reshape(n, c, h, w), d).numpy()
     assert np.abs(out - ref).max() <= 1e-6
+
+
+# ---- second witness for the TensorRT-native 2-D layers (the reference ships no fixture for them) -----------------------
+# The oracle's conv2d / deconv2d are torch.nn.functional calls.  These are plain fp64 loops written from the TensorFlow definitions the
+# converter assumes (scripts/tensorrt_model_builder.py:140-147 _compute_tf_padding, :149-228 Conv2D NHWC x RSCK -> addConvolution KCRS,
+# :230-288 Conv2DBackpropInput -> addDeconvolution with the SAME padding of its *output*), sharing no code with torch.
+def _tf_padding(in_dim, kern, stride):                   # tensorrt_model_builder.py:140-147, restated
+    along = max(kern - stride, 0) if in_dim % stride == 0 else max(kern - in_dim % stride, 0)
+    return along // 2, along - along // 2
+
+
+def _tf_conv2d_same(x_nhwc, f_rsck, stride):
+    """tf.nn.conv2d(padding='SAME'): out[b,i,j,k] = sum_{di,dj,q} x[b, s*i+di-pt, s*j+dj-pl, q] * f[di,dj,q,k], out = ceil(in / s)"""
+    n, h, w, c = x_nhwc.shape
+    kh, kw, _, k = f_rsck.shape
+    (pt, _), (pl, _) = _tf_padding(h, kh, stride), _tf_padding(w, kw, stride)
+    ho, wo = -(-h // stride), -(-w // stride)
+    out = np.zeros((n, ho, wo, k), np.float64)
+    for i in range(ho):
+        for j in range(wo):
+            for di in range(kh):
+                for dj in range(kw):
+                    y, xx = stride * i + di - pt, stride * j + dj - pl
+                    if 0 <= y < h and 0 <= xx < w:
+                        out[:, i, j, :] += x_nhwc[:, y, xx, :].astype(np.float64) @ f_rsck[di, dj].astype(np.float64)
+    return out
+
+
+def _tf_conv2d_transpose_same(y_nhwc, f_rsck, out_hw, stride):
+    """tf.nn.conv2d_transpose = Conv2DBackpropInput: the gradient of conv2d(SAME) with respect to its input of size out_hw; the filter is
+    (kh, kw, C of the OUTPUT of the transposed conv, K of its input):  dx[b, s*i+di-pt, s*j+dj-pl, c] += y[b,i,j,k] * f[di,dj,c,k]"""
+    n, hy, wy, k = y_nhwc.shape
+    kh, kw, c, _ = f_rsck.shape
+    H, W = out_hw
+    (pt, _), (pl, _) = _tf_padding(H, kh, stride), _tf_padding(W, kw, stride)
+    assert hy == -(-H // stride) and wy == -(-W // stride)
+    out = np.zeros((n, H, W, c), np.float64)
+    for i in range(hy):
+        for j in range(wy):
+            for di in range(kh):
+                for dj in range(kw):
+                    yy, xx = stride * i + di - pt, stride * j + dj - pl
+                    if 0 <= yy < H and 0 <= xx < W:
+                        out[:, yy, xx, :] += y_nhwc[:, i, j, :].astype(np.float64) @ f_rsck[di, dj].astype(np.float64).T
+    return out
+
+
+def _rsck_to_kcrs(f):                                    # scripts/data_converters.py:21-30
+    return np.ascontiguousarray(np.transpose(f, (3, 2, 0, 1)))
+
+
+@pytest.mark.parametrize("h,w,cin,cout,k,stride", [
+    (11, 17, 3, 8, 5, 2),      # the first layer's form (resnet18_2D_513x257_net.cpp:48-53): 5x5 stride 2 on the image, odd sizes
+    (9, 13, 6, 5, 3, 2),       # conv2D_*ds: 3x3 stride 2
+    (7, 9, 4, 4, 3, 1),        # tower / bottleneck layers: 3x3 stride 1
+])
+def test_conv2d_oracle_against_plain_tf_definition(h, w, cin, cout, k, stride):
+    rng = np.random.default_rng(h * 100 + w)
+    x = rng.standard_normal((2, h, w, cin)).astype(np.float32)
+    f = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    want = _tf_conv2d_same(x, f, stride) + b.astype(np.float64)
+    pad_h, pad_w = _tf_padding(h, k, stride), _tf_padding(w, k, stride)
+    assert pad_h[0] == pad_h[1] and pad_w[0] == pad_w[1]            # what the converter asserts before it uses setPadding (:196-199)
+    got = O.conv2d(T(np.transpose(x, (0, 3, 1, 2))).double(), T(_rsck_to_kcrs(f)).double(), T(b).double(), stride, pad_h[0]).numpy()
+    assert got.shape == (2, cout, -(-h // stride), -(-w // stride))
+    assert np.abs(np.transpose(got, (0, 2, 3, 1)) - want).max() <= 1e-12
+
+
+@pytest.mark.parametrize("hy,wy,H,W,k_in,c_out,k,stride", [
+    (5, 7, 9, 13, 6, 4, 3, 2),     # deconv2D_*: 3x3 stride 2, SAME padding 1 of the (odd) output
+    (4, 6, 7, 11, 8, 1, 3, 2),     # the last layer: one output channel
+    (5, 6, 5, 6, 3, 5, 3, 1),      # stride 1
+])
+def test_deconv2d_oracle_against_plain_tf_definition(hy, wy, H, W, k_in, c_out, k, stride):
+    rng = np.random.default_rng(H * 100 + W)
+    y = rng.standard_normal((2, hy, wy, k_in)).astype(np.float32)
+    f = rng.standard_normal((k, k, c_out, k_in)).astype(np.float32)       # TF: (kh, kw, output channels, input channels)
+    b = rng.standard_normal(c_out).astype(np.float32)
+    want = _tf_conv2d_transpose_same(y, f, (H, W), stride) + b.astype(np.float64)
+    pad_h, pad_w = _tf_padding(H, k, stride), _tf_padding(W, k, stride)
+    assert pad_h[0] == pad_h[1] and pad_w[0] == pad_w[1]            # :268-270
+    # rsck_to_kcrs of that filter is (k_in, c_out, R, S): addDeconvolution's (Cin, Cout, R, S)
+    got = O.deconv2d(T(np.transpose(y, (0, 3, 1, 2))).double(), T(_rsck_to_kcrs(f)).double(), T(b).double(), stride, pad_h[0]).numpy()
+    assert got.shape == (2, c_out, H, W)
+    assert np.abs(np.transpose(got, (0, 2, 3, 1)) - want).max() <= 1e-12

@@ -126,7 +126,13 @@ def main():
                 results.append(dict(name="cpu corr cost volume C32 D48 @185x629 b1 (oracle/corr_cpu.c, 1 core)", us=tc * 1e6, kind="port", cores=1,
                                     max_abs_diff_vs_gpu=err))
             t = timeit(lambda: k.corr_softargmax(l, r, sa, b, C, H, W, D, False))
-            report("corr+softargmax fused b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
+            report("corr+softargmax fused, planar fp32 (corr_f32_kernel) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
+            # the form the engine runs: channel-interleaved (C/4, H, pitch, 4) feature maps, Gram band on the matrix cores (corr_mfma.hip.h)
+            P = (W + 31) // 32 * 32
+            li, ri = rnd(b, C // 4, H, P, 4), rnd(b, C // 4, H, P, 4)
+            so = torch.empty(b, 1, H, P, device=dev)
+            t = timeit(lambda: k.corr_softargmax_il(li, ri, so, b, C, H, W, D, False, P, P))
+            report("corr+softargmax fused, interleaved (corr_softargmax_mfma_kernel) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
         if want("softargmax"):
             t = timeit(lambda: k.softargmax(cv, sa, b, D, H, W, False))
             report("softargmax D48 @185x629 b%d" % b, t, 0, 4.0 * b * (D + 1) * H * W)
@@ -156,7 +162,19 @@ def main():
         report("default cost volume NVSmall (48,64,161,513)", t, 0, 4.0 * (2 * Cc + 2 * Cc * Dd) * Hh * Ww)
         vol, out = rnd(1, 96, 321, 1025), torch.empty(1, 1, 321, 1025, device=dev)
         t = timeit(lambda: k.softargmax(vol, out, 1, 96, 321, 1025, True))
-        report("softargmin D96 @321x1025 (NVSmall)", t, 0, 4.0 * 97 * 321 * 1025)
+        report("softargmin D96 @321x1025 (NVSmall, C5)", t, 0, 4.0 * 97 * 321 * 1025)
+        # layout plugins at the NVSmall sizes (lib/transform_plugin.cpp, padding_plugin.cpp, slice_plugin.cpp; fused away in the engine)
+        Kk, Dd2, Hh2, Ww2 = 32, 48, 161, 513
+        x4, y4 = rnd(1, Kk, Dd2, Hh2, Ww2), torch.empty(1, Dd2, Kk, Hh2, Ww2, device=dev)
+        t = timeit(lambda: k.permute4d(x4, y4, 1, (Kk, Dd2, Hh2, Ww2), (1, 0, 2, 3)), iters=max(3, args.iters // 10))
+        report("transform (K,D,H,W)->(D,K,H,W) NVSmall (32,48,161,513)", t, 0, 8.0 * x4.numel())
+        inner = Kk * Hh2 * Ww2
+        xp, yp = rnd(1, Dd2, inner), torch.empty(1, Dd2 + 1, inner, device=dev)
+        t = timeit(lambda: k.pad_d(xp, yp, 1, Dd2, inner, 1), iters=max(3, args.iters // 10))
+        report("pad D 48->49 NVSmall (48,32,161,513)", t, 0, 4.0 * (xp.numel() + yp.numel()))
+        xs, ys = rnd(1, 97, 321 * 1025), torch.empty(1, 96, 321 * 1025, device=dev)
+        t = timeit(lambda: k.slice_d(xs, ys, 1, 97, 321 * 1025, 0, 96))
+        report("slice D 97->96 NVSmall (97,1,321,1025)", t, 0, 8.0 * ys.numel())
 
     if args.json:
         with open(args.json, "w") as f:

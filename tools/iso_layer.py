@@ -2,7 +2,7 @@
 """The dominant layer alone: 3x3 32->32 @629x185 (+bias, +residual, +ELU) on the executor's tensor layouts, or the fused
 residual block, launched back to back on an idle GPU.  For rocprofv3 passes (tools/pmc_layer.sh) and quick timings.
 
-    python tools/iso_layer.py [conv|block] [launches] [batch]
+    python tools/iso_layer.py [conv|block] [launches] [batch] [hints]      (hints 1 = RT_HINT_THROUGHPUT: 64-row segments of the block)
 """
 import ctypes
 import os
@@ -18,6 +18,7 @@ from redtail_amd import capi  # noqa: E402
 kind = sys.argv[1] if len(sys.argv) > 1 else "conv"
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 b = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+hints = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 k = capi.KernelLib()
 H, W = 185, 629
 rng = np.random.default_rng(1)
@@ -33,15 +34,15 @@ x = torch.randn(b, 32, H, 640, device="cuda")
 y = torch.empty_like(x)
 r = x if kind == "block" else torch.randn_like(x)
 for _ in range(3):
-    plan.enqueue(x, y, r, b)
+    plan.enqueue(x, y, r, b, hints=hints)
 torch.cuda.synchronize()
 e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
 k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
 k.lib.rt_event_record(e0, None)
 for _ in range(launches):
-    plan.enqueue(x, y, r, b)
+    plan.enqueue(x, y, r, b, hints=hints)
 k.lib.rt_event_record(e1, None)
 torch.cuda.synchronize()
 ms = ctypes.c_float()
 k.lib.rt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-print("%s batch %d: %.2f us per launch (%d launches back to back)" % (kind, b, ms.value * 1e3 / launches, launches))
+print("%s batch %d hints %d: %.2f us per launch (%d launches back to back)" % (kind, b, hints, ms.value * 1e3 / launches, launches))
