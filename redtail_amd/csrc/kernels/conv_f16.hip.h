@@ -104,8 +104,9 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
     unsigned tap_mask = ~0u;
     if (p.zs) {
         const ZSlice z = p.zs[zi];
-        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
-        r_off = z.r_off;
+        pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; w_off = z.w_off;
+        y_off = YIL8 ? z.y_off_il8 : z.y_off;          // phases of a transposed convolution: the pixel part of an interleaved offset counts 8 elements
+        r_off = p.r_il8 ? z.r_off_il8 : z.r_off;
         tap_mask = z.tap_mask;
     }
     const int act = p.act;
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
     const bool inb = oy < Ho && ox < Wo;
     const bool r_il8 = p.r_il8 != 0;              // uniform
     // planar: element (c, y, x) at c*cstride + y*ystride + x*xstride; interleaved: 16-byte pixel slots, lane's 4 channels
-    const unsigned il8off = (unsigned)((oy * p.y_ystride + ox) * 8 + 4 * half) * ES;
+    const unsigned il8off = (unsigned)((oy * p.y_ystride + ox * p.y_xstride) * 8 + 4 * half) * ES;
     const unsigned yvoff = !inb ? kBufOOB : (YIL8 ? il8off : (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * cs32) * ES);
     const unsigned rvoff = !inb ? kBufOOB : (r_il8 ? il8off : (unsigned)(oy * p.y_ystride + ox * p.y_xstride + 4 * half * rs32) * ES);
 

@@ -44,6 +44,7 @@ struct ZSlice {
     int64_t w_off;         // element offset of this slice's packed weights
     int64_t r_off;         // like y_off, for the residual tensor (differs when the output layout is transposed)
     int64_t r_off_il8;     // r_off for a channel-interleaved fp16 residual (C/8, H, W, 8): the pixel part of the offset counts 8 elements
+    int64_t y_off_il8;     // y_off for a channel-interleaved fp16 output: (D, C/8, H, W, 8), or (C/8, D, H, W, 8) when the layout is transposed
 };
 
 struct ConvArgs {

@@ -42,6 +42,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // with 1-8 spills), so the register-staged form is built.
 #define RT_WINO_LDS_DMA 0
 #endif
+// Probes of the round-4 hunt for the multi-context deviation of the interleaved instantiations (profiles/r04_race.txt; tools/race_locate.py):
+// 1 = the next chunk's global loads are issued AFTER the chunk's MFMAs (no vector-memory returns land while MFMAs execute),
+// 2 = ~128 idle cycles after each k-step's 16 MFMAs (they have drained before the next LDS reads are issued),
+// 3 = every LDS operand of a k-step is in registers before its first MFMA issues (no LDS return lands while MFMAs execute),
+// 4 = 32 idle cycles before each 16-byte store of the interleaved epilogue.   0 = the kernel as measured in rounds 1-3.
+#ifndef RT_WINO_PROBE
+#define RT_WINO_PROBE 0
+#endif
 template <int NW>
 struct WinoCfg {
     static constexpr int CC = 8;                          // input channels per chunk (2 MFMA k-steps of 4)
@@ -271,6 +279,11 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             f32x4 a4[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) a4[q] = ubase[ub + (j * 16 + q) * 32];
+#if RT_WINO_PROBE == 3 && !defined(HIPEMU)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // rows: w = B^T d  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), two columns at a time
             f32x2 w[4][2];
 #pragma unroll
@@ -295,6 +308,14 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q >> 2][q & 3], v[q], acc[q], 0, 0, 0);
+#if RT_WINO_PROBE == 3 && !defined(HIPEMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if RT_WINO_PROBE == 2 && !defined(HIPEMU)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
 
@@ -312,8 +333,14 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
         stage_to_lds();
         __syncthreads();
+#if RT_WINO_PROBE == 1
+        compute(WDMA ? (ch & 1) * (Cfg::U_ELEMS / 4) : 0);
+        asm volatile("" ::: "memory");
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+#else
         if (ch + 1 < nchunks) prefetch(ch + 1);
         compute(WDMA ? (ch & 1) * (Cfg::U_ELEMS / 4) : 0);
+#endif
     }
 
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
@@ -357,6 +384,9 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const f32x4 o = {yo[0][a][b], yo[1][a][b], yo[2][a][b], yo[3][a][b]};
+#if RT_WINO_PROBE == 4 && !defined(HIPEMU)
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
                     if (!kAblStore || o[0] == 12345.678f)
                         buf_store4(o, rs_y, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
                 }
