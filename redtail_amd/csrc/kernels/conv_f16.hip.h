@@ -86,17 +86,10 @@ __global__ void __launch_bounds__(64 * NW) RT_WAVES_PER_EU(RT_F16_WAVES) conv_f1
     const int half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int tile = blockIdx.x;
-    if (p.xcd_order) {                            // contiguous tile range per XCD (see conv_mfma.hip.h)
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    RT_WG_TILE(p, tile, zi, n)
     const int tx0 = (tile % p.tiles_x) * TX;
     const int ty0 = (tile / p.tiles_x) * TY;
     const int nblk = blockIdx.y;
-    const int zi = blockIdx.z % p.nz;
-    const int n = blockIdx.z / p.nz;
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
     const int nchunks = p.CinPad / CC;
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;

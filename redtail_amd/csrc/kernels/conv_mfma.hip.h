@@ -84,7 +84,24 @@ struct ConvArgs {
     // at column ix - shift and is zero for ix < shift -- the right-image half of a folded default cost volume
     const int* ch_shift;
     int w_exact;           // conv_s3_kernel: the weights came from an fp16 file -- their low parts are zero and are not multiplied
+    // 3-D launches: the z-slices are folded into grid.x with z running FASTEST (grid.x = tiles * nz, grid.z = samples).  With the per-XCD
+    // contiguous ranges of xcd_order the workgroups an XCD runs side by side then belong to neighbouring depth slices (and output phases)
+    // of the same image tile: the slices a 3x3x3 window shares are served by that XCD's L2 instead of being fetched three times
+    // (round 4, PMC: conv3D_2 of NVSmall fetched 836 MB for a 254 MB input with z outermost).
+    int z_inner;
 };
+
+// workgroup -> (tile of the output plane, z-slice, sample)
+#define RT_WG_TILE(p, tile, zi, n)                                                                  \
+    int tile = blockIdx.x;                                                                          \
+    if ((p).xcd_order) {                          /* contiguous range per XCD (see conv_mfma_f32_kernel) */ \
+        const int nwg_ = gridDim.x, q_ = nwg_ >> 3, r_ = nwg_ & 7;                                  \
+        const int xcd_ = blockIdx.x & 7, idx_ = blockIdx.x >> 3;                                    \
+        tile = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + idx_;             \
+    }                                                                                               \
+    int zi, n;                                                                                      \
+    if ((p).z_inner) { zi = tile % (p).nz; tile /= (p).nz; n = blockIdx.z; }                        \
+    else { zi = blockIdx.z % (p).nz; n = blockIdx.z / (p).nz; }
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with
 // -DRT_KERNEL_TIMING): thread 0 stamps s_memtime at phase boundaries.  Compiles to nothing otherwise.

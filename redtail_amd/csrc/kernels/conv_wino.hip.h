@@ -46,7 +46,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 1 = the next chunk's global loads are issued AFTER the chunk's MFMAs (no vector-memory returns land while MFMAs execute),
 // 2 = ~128 idle cycles after each k-step's 16 MFMAs (they have drained before the next LDS reads are issued),
 // 3 = every LDS operand of a k-step is in registers before its first MFMA issues (no LDS return lands while MFMAs execute),
-// 4 = 32 idle cycles before each 16-byte store of the interleaved epilogue.   0 = the kernel as measured in rounds 1-3.
+// 4 = 32 idle cycles before each 16-byte store of the interleaved epilogue,
+// 5 = the interleaved residual is read with four 4-byte loads per pixel instead of one 16-byte load,
+// 6 = s_waitcnt vmcnt(0) after each 16-byte residual load (the four loads of a lane do not overlap).   0 = the kernel as measured in rounds 1-3.
 #ifndef RT_WINO_PROBE
 #define RT_WINO_PROBE 0
 #endif
@@ -234,7 +236,15 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
+#if RT_WINO_PROBE == 5
+                f32x4 v;
+                for (int i = 0; i < 4; i++) v[i] = buf_load(rs_r, il_off(a, b) == kBufOOB ? kBufOOB : il_off(a, b) + 4u * i, (unsigned)(nblk * 32 * cs32) * 4u);
+#else
                 const f32x4 v = kAblResid ? f32x4{0.f, 1.f, 2.f, 3.f} : buf_load4(rs_r, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
+#endif
+#if RT_WINO_PROBE == 6 && !defined(HIPEMU)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; i++) rr[i][a][b] = v[i];
             }

@@ -146,4 +146,105 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
     }
 }
 
+// ---- the same layer on the matrix cores, channel-interleaved input -------------------------------------------------------------------
+// half2 mode of the 3-D models stores the layer's input as (K/8, Dy, Hy, Wy, 8) fp16 (rt_conv_plan_set_layouts): the 8 channels of a
+// group at one voxel are ONE 16-byte slot.  Written as a GEMM per 2x2x2 output block, out[phase f][block] = sum_{j, k} W[f][j][k] *
+// x[k][neighbour j of block], the contraction index of one v_mfma_f32_16x16x32_f16 is 32 input channels at a fixed neighbour j:
+//   B operand (32 k x 16 blocks): lane (n = l % 16, g = l / 16) needs channels 8g .. 8g+7 of block n's neighbour j -- exactly one slot,
+//                                 one 16-byte load, no LDS, no fp16 -> fp32 conversion, no per-channel 2-byte loads (the vector-ALU form
+//                                 above issues 8 x K of those per block and was bound by the L1 / TA path at 0.12 of the HBM roof);
+//   A operand (16 rows x 32 k):   rows = co * 8 + phase (one or two output channels), constant per (j, channel block): 4 VGPRs each,
+//                                 packed by the plan in the MFMA's lane order (rt_capi.hip) and held in registers;
+//   D (16 x 16):                  lane (n, q = l / 16) holds rows 4q .. 4q+3 = (co = q / 2, fz = q % 2, fy, fx) of block n: the two
+//                                 x-phases of an output row are adjacent, stored as one 8-byte access; 16 lanes cover 128 bytes.
+// A wave owns 16 consecutive blocks along x and kSmallIlIters such groups; 8 MFMAs (K = 32) per group.
+constexpr int kSmallIlIters = 3;
+typedef _Float16 f16x8_small __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // grid.x = x-groups-of-workgroups * Mz with the depth block running fastest and a contiguous range per XCD (as conv_mfma.hip.h:
+    // RT_WG_TILE): the workgroups an XCD runs side by side are depth neighbours, so the input slice two of them share comes from its L2
+    int lin = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q_ = nwg >> 3, r_ = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
+    }
+    const int mz = lin % p.Mz, bx = lin / p.Mz;
+    const int my0 = 2 * blockIdx.y, n = blockIdx.z;              // a wave works on TWO block rows: they share the input row between them
+    const int KC = p.K / 32;
+    const int ngroups = (int)cdiv((p.Wx + 1) / 2, 16);
+    const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 2));
+    const buf_rsrc rs_w = make_buf(p.w);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride, 4));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.y_bstride, 4), p.resid != nullptr);
+    const unsigned gstride = (unsigned)(p.Dy * p.Hy * p.xp) * 16u;           // bytes between channel groups of the input
+    const int co = q >> 1, fz = q & 1;
+    const float bias = co < p.C ? p.bias[co] : 0.f;
+    const bool has_r = p.resid != nullptr;                        // uniform
+    const int nrows = (p.Hx + 1) / 2;                              // block rows
+
+    // K = 32 (every network of the reference): the 8 weight operands live in registers for the whole workgroup
+    f32x4 a0[8];
+    if (KC == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) a0[j] = buf_load4(rs_w, (unsigned)(j * 64 + lane) * 16u, 0);
+    }
+    for (int it = 0; it < kSmallIlIters; it++) {
+        const int grp = (bx * 4 + wv) * kSmallIlIters + it;                    // wave-uniform
+        if (grp >= ngroups) break;
+        const int mx = grp * 16 + n16;
+        f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
+        for (int kc = 0; kc < KC; kc++) {
+            // neighbours (jz, row, jx): rows my0 + by + {0, 1, 2}; block row 0 uses rows 0, 1, block row 1 rows 1, 2
+            f32x4 b[2][3][2];
+#pragma unroll
+            for (int jz = 0; jz < 2; jz++)
+#pragma unroll
+                for (int ry = 0; ry < 3; ry++)
+#pragma unroll
+                    for (int jx = 0; jx < 2; jx++) {
+                        const int iz = mz + p.bz + jz, iy = my0 + p.by + ry, ix = mx + p.bx + jx;
+                        const bool ok = iz >= 0 && iz < p.Dy && iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy;
+                        const unsigned vo = ok ? (unsigned)((iz * p.Hy + iy) * p.xp + ix) * 16u + (unsigned)(kc * 4 + q) * gstride : kBufOOB;
+                        b[jz][ry][jx] = buf_load4(rs_x, vo, 0);
+                    }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f32x4 av = KC == 1 ? a0[j] : buf_load4(rs_w, (unsigned)((j * KC + kc) * 64 + lane) * 16u, 0);      // L1 / L2 resident
+                const f16x8_small a = __builtin_bit_cast(f16x8_small, av);
+#pragma unroll
+                for (int row = 0; row < 2; row++)
+                    acc[row] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(f16x8_small, b[j >> 2][row + ((j >> 1) & 1)][j & 1]), acc[row], 0, 0, 0);
+            }
+        }
+        // rows 4q + r of the MFMA tile: output channel co, depth phase fz, (fy, fx) = (r >> 1, r & 1)
+        const int oz = 2 * mz + fz, ox = 2 * mx;
+#pragma unroll
+        for (int row = 0; row < 2; row++) {
+            if (my0 + row >= nrows) break;                         // uniform
+#pragma unroll
+            for (int fy = 0; fy < 2; fy++) {
+                const int oy = 2 * (my0 + row) + fy;
+                const bool row_ok = co < p.C && oz < p.Dx && oy < p.Hx;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
+                const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
+                const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
+                f32x2_t o = {acc[row][2 * fy], acc[row][2 * fy + 1]};
+                if (has_r) {
+                    const f32x2_t r2 = buf_load2(rs_r, v2, 0);
+                    const float r1 = buf_load(rs_r, v1, 0);
+                    o[0] += r2[0] + r1;
+                    o[1] += r2[1];
+                }
+                o[0] = apply_act_rt(o[0], p.act);
+                o[1] = apply_act_rt(o[1], p.act);
+                buf_store2(o, rs_y, v2, 0);
+                buf_store(o[0], rs_y, v1, 0);
+            }
+        }
+    }
+}
+
 }  // namespace rt

@@ -20,6 +20,7 @@
 #include "kernels/imgproc.hip.h"
 #include "kernels/conv_f16.hip.h"
 #include "kernels/conv_f16_first.hip.h"
+#include "kernels/conv_f16r4.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
 #include "kernels/cost_volume.hip.h"
@@ -528,6 +529,8 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int s3p = 0;                        // conv_s3p_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe, persistent (3x3 s1, Cin, Cout <= 32)
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
+    std::vector<float> small_w;         // ... its weights as [K][COUT][phase 8][neighbour 8] before structural zeros are dropped (3-D form)
+    void* small_il_dev = nullptr;       // deconv3d_s2_il_kernel: the MFMA A operands (set when the input becomes channel-interleaved)
 };
 
 }  // namespace
@@ -537,7 +540,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -557,6 +560,8 @@ struct rtConvPlan {
     // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
     int is_conv3d = 0, is_deconv3d = 0;
     int c3d_C = 0, c3d_cin = 0, c3d_dchw = 0, c3d_fold = 0;
+    rtConv3dDesc desc3d{};                        // transposed 3-D plans: the descriptor and input dims they were created with (the launches are
+    int in_dims3[3] = {0, 0, 0};                  // rebuilt when the plan moves between the split-fp16 and the fp16-operand kernel)
     int flags = 0;                                // RT_CONV_* option bits of the descriptor(s) the plan was created with: every later re-planning
                                                   // (set_io_types, set_layouts, set_pitch) runs under the same options (ExactScope)
 };
@@ -682,6 +687,26 @@ int upload_packed(SubConv& sc, int cin_real, F wfun) {
     std::vector<float> packed;
     pack_into(packed, sc, cin_real, wfun);
     return upload_weights(sc, packed);
+}
+
+// fp16 operand slabs of conv_f16mma_kernel: [nblk][chunk of 16 ci][tap][h][co % 32][8 halfs], ci = chunk*16 + 8*h + e.
+// Appends one slab set (all nblk x chunks) and returns its offset in 16-byte slots.
+template <typename F>
+int64_t pack_f16_into(std::vector<uint16_t>& packed, const SubConv& sc, int cin_real, F wfun) {
+    const int64_t base = (int64_t)packed.size() / 8;
+    const int taps = sc.KH * sc.KW, nblk = (int)rt::cdiv(sc.Cout, 32), nch = sc.CinPad / 16;
+    packed.resize(packed.size() + (size_t)nblk * nch * taps * 2 * 32 * 8, 0);
+    for (int co = 0; co < sc.Cout; co++)
+        for (int ci = 0; ci < cin_real; ci++)
+            for (int u = 0; u < sc.KH; u++)
+                for (int v = 0; v < sc.KW; v++) {
+                    const _Float16 hv = (_Float16)wfun(co, ci, u, v);
+                    uint16_t bits;
+                    std::memcpy(&bits, &hv, 2);
+                    const int nb = co / 32, cc = co % 32, ch = ci / 16, h = (ci % 16) / 8, e = ci % 8;
+                    packed[(size_t)base * 8 + ((((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * 32 + cc) * 8) + e] = bits;
+                }
+    return base;
 }
 
 int upload_zslices(SubConv& sc, const std::vector<rt::ZSlice>& zs) {
@@ -969,14 +994,20 @@ int launch_sub(const SubConv& sc, const rt::ConvArgs& a, dim3 grid, hipStream_t 
     return fail(RT_E_UNSUPPORTED, "conv: no kernel for window %dx%d stride %d", sc.KH, sc.KW, sc.S);
 }
 
-void free_plan(rtConvPlan* p) {
-    if (!p) return;
+void free_subs(rtConvPlan* p) {
     for (auto& s : p->subs) {
         if (s.w_dev) (void)hipFree(s.w_dev);
         if (s.choff_dev) (void)hipFree(s.choff_dev);
         if (s.shift_dev) (void)hipFree(s.shift_dev);
         if (s.zs_dev) (void)hipFree(s.zs_dev);
+        if (s.small_il_dev) (void)hipFree(s.small_il_dev);
     }
+    p->subs.clear();
+}
+
+void free_plan(rtConvPlan* p) {
+    if (!p) return;
+    free_subs(p);
     if (p->bias_dev) (void)hipFree(p->bias_dev);
     if (p->rb_w1_dev) (void)hipFree(p->rb_w1_dev);
     if (p->rb_bias1_dev) (void)hipFree(p->rb_bias1_dev);
@@ -1316,6 +1347,123 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     return 0;
 }
 
+namespace {
+// The launches of a transposed 3-D convolution (not the small-output last layer): one launch per output-depth class (depths cls, cls+sd,
+// ... share the same set of depth taps); inside it every (depth position, y/x output phase) is a ZSlice -- see rt_deconv2d_plan_create.
+// f16mma = false: the split-fp16 kernel (fp32 tensors, or planar fp16 ones in half2 mode).  f16mma = true: fp16 operands on
+// conv_f16mma_kernel with a CHANNEL-INTERLEAVED input (K/8, Dy, Hy, Wy, 8) fp16 -- one 16-byte load per pixel and channel group instead of
+// eight 2-byte ones, one MFMA per tap instead of two -- which then also writes interleaved outputs, (D, C/8, H, W, 8) or, with the fused
+// Transform, (C/8, D, H, W, 8) (ZSlice::y_off_il8).  Rebuilds plan->subs from plan->desc3d / in_dims3 / w_canon; storage types and layouts
+// of the old launches are carried over by the caller.
+int build_deconv3d_subs(rtConvPlan* plan, bool f16mma) {
+    const rtConv3dDesc* d = &plan->desc3d;
+    const std::vector<float>& w = plan->w_canon;
+    const int Dlim = d->out_depth > 0 ? d->out_depth : d->D;
+    const bool cdhw = d->out_dchw != 0;
+    const int V = d->kernel[0], R = d->kernel[1], Sk = d->kernel[2];
+    const int sd = d->stride[0], sh = d->stride[1];
+    const int pd = d->pad_start[0], ph_ = d->pad_start[1], pw = d->pad_start[2];
+    const int Dy = plan->in_dims3[0], Hy = plan->in_dims3[1], Wy = plan->in_dims3[2];
+    const int Hx = d->H, Wx = d->W, K = d->K, C = d->C;
+    const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
+    free_subs(plan);
+    int rc = 0;
+    std::vector<Phase1D> py_ph, px_ph;
+    int wy = 1, wx = 1;
+    for (int ph = 0; ph < sh; ph++) {
+        py_ph.push_back(phase1d(sh, ph_, R, ph));
+        px_ph.push_back(phase1d(sh, pw, Sk, ph));
+        wy = std::max(wy, py_ph.back().K);
+        wx = std::max(wx, px_ph.back().K);
+    }
+    for (int cls = 0; cls < sd && !rc; cls++) {          // output depths dx = cls, cls + sd, ...
+        if (cls >= Dlim) continue;
+        const Phase1D az = phase1d(sd, pd, V, cls);
+        const int nzd = (Dlim - cls + sd - 1) / sd;
+        const int nv = std::max(az.K, 1);
+        SubConv sc;
+        sc.KH = wy; sc.KW = wx; sc.S = 1; sc.Cout = C; sc.Hi = Hy; sc.Wi = Wy;
+        sc.Ho = (Hx + sh - 1) / sh; sc.Wo = (Wx + sh - 1) / sh;
+        sc.y_cstride = cdhw ? (int64_t)Dlim * out_plane : out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
+        sc.r_cstride = out_plane;
+        int nph = 0;
+        for (int py = 0; py < sh; py++)
+            for (int px = 0; px < sh; px++)
+                if (py < Hx && px < Wx) nph++;
+        sc.nz = nzd * nph;
+        choose_tiling(sc, false);      // phase launches carry ZSlice tables
+        const int cin_real = nv * K;
+        sc.cin_real = cin_real;
+        check_direct(sc, cin_real);
+        if (f16mma) {
+            if (!sc.split3 || sc.direct) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: no fp16-operand form for this window"); break; }
+            sc.split3 = 0; sc.f16mma = 1; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
+        }
+        sc.CinPad = sc.direct ? cin_real : rt::round_up(cin_real, sc.CC);
+        if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
+        std::vector<float> packed;
+        std::vector<uint16_t> packed16;
+        std::vector<int64_t> w_offs;
+        for (int py = 0; py < sh; py++)
+            for (int px = 0; px < sh; px++) {
+                if (py >= Hx || px >= Wx) continue;
+                const Phase1D &ay = py_ph[py], &ax = px_ph[px];
+                auto wfun = [&](int co, int ci, int u, int v) {
+                    if (az.K == 0 || u >= ay.K || v >= ax.K) return 0.f;
+                    const int j = ci / K, k = ci % K;                        // gathered channel = (depth tap j, input channel k)
+                    return w[((((size_t)k * V + az.tap[j]) * C + co) * R + ay.tap[u]) * Sk + ax.tap[v]];   // KVCRS
+                };
+                w_offs.push_back(f16mma ? pack_f16_into(packed16, sc, cin_real, wfun) : pack_into(packed, sc, cin_real, wfun));
+            }
+        std::vector<rt::ZSlice> zs;
+        for (int m = 0; m < nzd; m++) {
+            int iph = 0;
+            for (int py = 0; py < sh; py++)
+                for (int px = 0; px < sh; px++) {
+                    if (py >= Hx || px >= Wx) continue;
+                    const Phase1D &ay = py_ph[py], &ax = px_ph[px];
+                    rt::ZSlice z{};
+                    z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
+                    z.Ho = (Hx - py + sh - 1) / sh; z.Wo = (Wx - px + sh - 1) / sh;
+                    z.ch_row = m;
+                    z.tap_mask = 0;
+                    for (int u = 0; u < ay.K; u++)
+                        for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
+                    const int64_t pix = (int64_t)py * Wx + px, dx = cls + m * sd;
+                    z.r_off = dx * C * out_plane + pix;
+                    z.r_off_il8 = dx * C * out_plane + 8 * pix;                                 // (D, C/8, H, W, 8) fp16 skip tensor
+                    z.y_off = cdhw ? dx * out_plane + pix : z.r_off;
+                    z.y_off_il8 = cdhw ? 8 * (dx * out_plane + pix) : z.r_off_il8;              // (C/8, D, H, W, 8) / (D, C/8, H, W, 8)
+                    z.w_off = w_offs[iph++];
+                    zs.push_back(z);
+                }
+        }
+        // table row m <-> output depth dx = cls + m*sd, which reads input depth m + j - az.pad for depth tap j.  Planar input (K, Dy, Hy, Wy):
+        // plane offset of channel k; interleaved input (K/8, Dy, Hy, Wy, 8): element offset of the slot plane of channel group k / 8
+        std::vector<int> table((size_t)nzd * sc.CinPad, -1);
+        for (int m = 0; m < nzd; m++)
+            for (int j = 0; j < az.K; j++) {
+                const int dy = m + j - az.pad;
+                if (dy < 0 || dy >= Dy) continue;
+                for (int k = 0; k < K; k++)
+                    table[(size_t)m * sc.CinPad + j * K + k] = f16mma ? (int)((((int64_t)(k / 8) * Dy + dy) * in_plane) * 8 + k % 8)
+                                                                      : (int)(((int64_t)k * Dy + dy) * in_plane);
+            }
+        if (f16mma) {
+            if (hipMalloc((void**)&sc.w_dev, packed16.size() * 2) != hipSuccess ||
+                hipMemcpy(sc.w_dev, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(RT_E_NOMEM, "conv3d_transpose: device allocation failed");
+        } else {
+            rc = upload_weights(sc, packed);
+        }
+        if (!rc) rc = upload_zslices(sc, zs);
+        if (!rc) rc = upload_table(sc, table);
+        plan->subs.push_back(sc);
+    }
+    return rc;
+}
+}  // namespace
+
 extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dDesc* d, const int in_dims[3],
                                                const void* weights, const void* bias) {
     ExactScope exact_scope(d ? d->flags : 0);
@@ -1382,6 +1530,8 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             sc.s3.Dx = Dlim; sc.s3.Hx = Hx; sc.s3.Wx = Wx; sc.s3.C = C;
             sc.s3.bz = bz; sc.s3.by = by; sc.s3.bx = bx; sc.s3.Mz = (Dlim + 1) / 2;
             sc.s3.xp = Wy; sc.s3.yp = Wx;
+            sc.small_w = packed;
+            plan->is_deconv3d = 1; plan->c3d_C = C;
             sc.s3.sparse = (by != 0 || bx != 0) ? 0 : (bz == 0 && drop_structural_zeros<true, 0>(packed)) ? 1 :
                            (bz == -1 && drop_structural_zeros<true, 4>(packed)) ? 1 + 4 : 0;
             RT_REQUIRE((int64_t)Dx * C * Hx * Wx < (1ll << 29), "conv3d_transpose: output sample exceeds 2 GB (32-bit buffer offsets)");
@@ -1396,85 +1546,11 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
             return 0;
         }
     }
-    // One launch per output-depth class (depths cls, cls+sd, ... share the same set of depth taps); inside
-    // it every (depth position, y/x output phase) is a ZSlice -- see rt_deconv2d_plan_create.
-    std::vector<Phase1D> py_ph, px_ph;
-    int wy = 1, wx = 1;
-    for (int ph = 0; ph < sh; ph++) {
-        py_ph.push_back(phase1d(sh, ph_, R, ph));
-        px_ph.push_back(phase1d(sh, pw, Sk, ph));
-        wy = std::max(wy, py_ph.back().K);
-        wx = std::max(wx, px_ph.back().K);
-    }
-    for (int cls = 0; cls < sd && !rc; cls++) {          // output depths dx = cls, cls + sd, ...
-        if (cls >= Dlim) continue;
-        const Phase1D az = phase1d(sd, pd, V, cls);
-        const int nzd = (Dlim - cls + sd - 1) / sd;
-        const int nv = std::max(az.K, 1);
-        SubConv sc;
-        sc.KH = wy; sc.KW = wx; sc.S = 1; sc.Cout = C; sc.Hi = Hy; sc.Wi = Wy;
-        sc.Ho = (Hx + sh - 1) / sh; sc.Wo = (Wx + sh - 1) / sh;
-        sc.y_cstride = cdhw ? (int64_t)Dlim * out_plane : out_plane; sc.y_ystride = sh * Wx; sc.y_xstride = sh;
-        sc.r_cstride = out_plane;
-        int nph = 0;
-        for (int py = 0; py < sh; py++)
-            for (int px = 0; px < sh; px++)
-                if (py < Hx && px < Wx) nph++;
-        sc.nz = nzd * nph;
-        choose_tiling(sc, false);      // phase launches carry ZSlice tables
-        const int cin_real = nv * K;
-        sc.cin_real = cin_real;
-        check_direct(sc, cin_real);
-    sc.CinPad = sc.direct ? cin_real : rt::round_up(cin_real, sc.CC);
-        if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
-        std::vector<float> packed;
-        std::vector<int64_t> w_offs;
-        for (int py = 0; py < sh; py++)
-            for (int px = 0; px < sh; px++) {
-                if (py >= Hx || px >= Wx) continue;
-                const Phase1D &ay = py_ph[py], &ax = px_ph[px];
-                w_offs.push_back(pack_into(packed, sc, cin_real, [&](int co, int ci, int u, int v) {
-                    if (az.K == 0 || u >= ay.K || v >= ax.K) return 0.f;
-                    const int j = ci / K, k = ci % K;                        // gathered channel = (depth tap j, input channel k)
-                    return w[((((size_t)k * V + az.tap[j]) * C + co) * R + ay.tap[u]) * Sk + ax.tap[v]];   // KVCRS
-                }));
-            }
-        std::vector<rt::ZSlice> zs;
-        for (int m = 0; m < nzd; m++) {
-            int iph = 0;
-            for (int py = 0; py < sh; py++)
-                for (int px = 0; px < sh; px++) {
-                    if (py >= Hx || px >= Wx) continue;
-                    const Phase1D &ay = py_ph[py], &ax = px_ph[px];
-                    rt::ZSlice z{};
-                    z.pad_y = ay.K ? ay.pad : 0; z.pad_x = ax.K ? ax.pad : 0;
-                    z.Ho = (Hx - py + sh - 1) / sh; z.Wo = (Wx - px + sh - 1) / sh;
-                    z.ch_row = m;
-                    z.tap_mask = 0;
-                    for (int u = 0; u < ay.K; u++)
-                        for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
-                    z.r_off = (int64_t)(cls + m * sd) * C * out_plane + (int64_t)py * Wx + px;
-                    z.r_off_il8 = (int64_t)(cls + m * sd) * C * out_plane + 8 * ((int64_t)py * Wx + px);      // (D, C/8, H, W, 8) fp16 skip tensor
-                    z.y_off = cdhw ? (int64_t)(cls + m * sd) * out_plane + (int64_t)py * Wx + px : z.r_off;
-                    z.w_off = w_offs[iph++];
-                    zs.push_back(z);
-                }
-        }
-        // table row m <-> output depth dx = cls + m*sd, which reads input depth m + j - az.pad for depth tap j
-        std::vector<int> table((size_t)nzd * sc.CinPad, -1);
-        for (int m = 0; m < nzd; m++)
-            for (int j = 0; j < az.K; j++) {
-                const int dy = m + j - az.pad;
-                if (dy < 0 || dy >= Dy) continue;
-                for (int k = 0; k < K; k++)
-                    table[(size_t)m * sc.CinPad + j * K + k] = (int)(((int64_t)k * Dy + dy) * in_plane);
-            }
-        rc = upload_weights(sc, packed);
-        if (!rc) rc = upload_zslices(sc, zs);
-        if (!rc) rc = upload_table(sc, table);
-        plan->subs.push_back(sc);
-    }
+    plan->desc3d = *d;
+    for (int i = 0; i < 3; i++) plan->in_dims3[i] = in_dims[i];
+    plan->w_canon = w;                                         // KVCRS: the launches are rebuilt from it when the plan changes kernels
     plan->is_deconv3d = 1; plan->c3d_C = C;
+    rc = build_deconv3d_subs(plan, false);
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, C);
@@ -1535,26 +1611,6 @@ extern "C" int rt_conv_plan_set_batch_strides(rtConvPlan* plan, int64_t x_bstrid
 }
 
 namespace {
-// fp16 operand slabs of conv_f16mma_kernel: [nblk][chunk of 16 ci][tap][h][co % 32][8 halfs], ci = chunk*16 + 8*h + e.
-// Appends one slab set (all nblk x chunks) and returns its offset in 16-byte slots.
-template <typename F>
-int64_t pack_f16_into(std::vector<uint16_t>& packed, const SubConv& sc, int cin_real, F wfun) {
-    const int64_t base = (int64_t)packed.size() / 8;
-    const int taps = sc.KH * sc.KW, nblk = (int)rt::cdiv(sc.Cout, 32), nch = sc.CinPad / 16;
-    packed.resize(packed.size() + (size_t)nblk * nch * taps * 2 * 32 * 8, 0);
-    for (int co = 0; co < sc.Cout; co++)
-        for (int ci = 0; ci < cin_real; ci++)
-            for (int u = 0; u < sc.KH; u++)
-                for (int v = 0; v < sc.KW; v++) {
-                    const _Float16 hv = (_Float16)wfun(co, ci, u, v);
-                    uint16_t bits;
-                    std::memcpy(&bits, &hv, 2);
-                    const int nb = co / 32, cc = co % 32, ch = ci / 16, h = (ci % 16) / 8, e = ci % 8;
-                    packed[(size_t)base * 8 + ((((((size_t)nb * nch + ch) * taps + (u * sc.KW + v)) * 2 + h) * 32 + cc) * 8) + e] = bits;
-                }
-    return base;
-}
-
 // Switches a 2-D plan to the fp16-arithmetic kernel: re-packs the weights it was created with.
 int repack_f16mma(rtConvPlan* plan) {
     SubConv& sc = plan->subs[0];
@@ -1721,6 +1777,8 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
         const bool both = x_dtype == RT_F16 && y_dtype == RT_F16;
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
+        if (plan->is_deconv3d && !plan->subs.empty() && plan->subs[0].f16mma)        // back to the split kernel and planar tensors first
+            if (int rc = build_deconv3d_subs(plan, false)) return rc;
         for (SubConv& sc : plan->subs) {
             // (an fp16 input with an fp32 output has no kernel: ADVICE r02 -- say so here, not at the first enqueue)
             const bool ok = sc.small3d ? (sc.small3d == 1 && y_dtype == RT_F32) : (sc.f16mma ? both : (sc.split3 && (y_dtype == RT_F16 || x_dtype == RT_F32)));
@@ -1797,19 +1855,28 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
         if (env_int("RT_NO_IL8", 0) != 0 || env_int("RT_NO_IL8_3D", 0) != 0 || plan->subs.empty()) return 0;
         const SubConv& sc = plan->subs[0];
         if (plan->is_conv3d && plan->subs.size() == 1) {
-            const int out = (plan->c3d_dchw && sc.Cout % 8 == 0) ? 2 : 0;
+            // the fused Transform's (D, K/8, H, W, 8), or -- fp16 operands only -- the plain (K/8, D, H, W, 8) a Conv3DTranspose then reads
+            const int out_dm = (plan->c3d_dchw && sc.Cout % 8 == 0) ? 2 : 0, out = sc.Cout % 8 == 0 ? 2 : 0;
             // both tensors fp16: conv_f16mma_kernel once the input is interleaved (its planar gathers move 4-byte pixel pairs, which the
             // odd plane sizes of dense 4-D tensors misalign) -- bit 3: an interleaved output needs an interleaved input
             const bool f16mma_ok = !sc.small3d && !sc.direct && (sc.split3 || sc.f16mma) && sc.KH == 3 && sc.KW == 3 &&
                                    (sc.S == 1 || sc.S == 2) && sc.TY == 4 && plan->c3d_C % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0;
             if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0)) : 0;
-            if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out;            // fp32 (feature maps) in, fp16 volume out
+            if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out_dm;         // fp32 (feature maps) in, fp16 volume out
             return 0;
         }
-        if (plan->is_deconv3d && plan->has_resid && plan->c3d_C % 8 == 0) {
+        if (plan->is_deconv3d) {
+            if (sc.small3d)      // last layer: (K/8, Dy, Hy, Wy, 8) fp16 in on the matrix cores (deconv3d_s2_il_kernel), fp32 volume out
+                return (sc.small3d == 1 && sc.x_f16 && !sc.y_f16 && sc.s3.K % 32 == 0 && !sc.small_w.empty() && env_int("RT_NO_SMALL_IL", 0) == 0) ? 1 : 0;
             for (const SubConv& q : plan->subs)
-                if (!q.split3 || !q.y_f16 || q.TY != 4) return 0;
-            return 4;
+                if (!(q.split3 || q.f16mma) || !q.y_f16 || q.TY != 4) return 0;
+            // fp16 in and out: an interleaved INPUT moves the plan to fp16 operands (conv_f16mma_kernel, 2x2 phase windows), which also
+            // writes interleaved outputs (bit 3: only then); the skip tensor may be interleaved with either kernel
+            const bool f16mma_ok = sc.x_f16 && sc.KH == 2 && sc.KW == 2 && plan->desc3d.K % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0 &&
+                                   env_int("RT_NO_DECONV_IL", 0) == 0;
+            int caps = (plan->has_resid && plan->c3d_C % 8 == 0) ? 4 : 0;
+            if (f16mma_ok) caps |= 1 | (plan->c3d_C % 8 == 0 ? 2 | 8 : 0);
+            return caps;
         }
         return 0;
     }
@@ -1847,6 +1914,11 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
     if (!x_il8 && !y_il8 && !r_il8) {
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
+        if (plan->is_deconv3d && !plan->subs.empty() && plan->subs[0].f16mma) {
+            const int xf = plan->subs[0].x_f16, yf = plan->subs[0].y_f16;
+            if (int rc = build_deconv3d_subs(plan, false)) return rc;
+            for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
+        }
         for (SubConv& sc : plan->subs) sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
         return 0;
     }
@@ -1857,6 +1929,41 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         if (int rc = switch_conv3d_f16mma(plan, x_il8 != 0)) return rc;           // interleaved input: fp16 operands; planar input: the split kernel
         SubConv& sc = plan->subs[0];
         sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = 0;
+        return 0;
+    }
+    if (plan->is_deconv3d && !plan->subs.empty()) {
+        if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)) || ((caps & 8) && y_il8 && !x_il8))
+            return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3DTranspose plan does not take that combination of interleaved tensors (caps %d)", caps);
+        RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
+        if (plan->subs[0].small3d) {
+            SubConv& sc = plan->subs[0];
+            if (x_il8 && !sc.small_il_dev) {
+                // A operands of deconv3d_s2_il_kernel: per neighbour j and block of 32 input channels a 16 x 32 tile [row = co * 8 + phase][k],
+                // stored as the MFMA's lane image: lane l holds row l % 16, channels 8 * (l / 16) .. + 7
+                const int K = sc.s3.K, CO = sc.Cout, KC = K / 32;
+                std::vector<uint16_t> slab((size_t)8 * KC * 64 * 8, 0);
+                for (int j = 0; j < 8; j++)
+                    for (int kc = 0; kc < KC; kc++)
+                        for (int l = 0; l < 64; l++)
+                            for (int e = 0; e < 8; e++) {
+                                const int row = l % 16, co = row / 8, f = row % 8, k = kc * 32 + 8 * (l / 16) + e;
+                                if (co >= CO) continue;
+                                const _Float16 h = (_Float16)sc.small_w[(((size_t)k * CO + co) * 8 + f) * 8 + j];
+                                std::memcpy(&slab[(((size_t)j * KC + kc) * 64 + l) * 8 + e], &h, 2);
+                            }
+                RT_HIP(hipMalloc(&sc.small_il_dev, slab.size() * 2));
+                RT_HIP(hipMemcpy(sc.small_il_dev, slab.data(), slab.size() * 2, hipMemcpyHostToDevice));
+            }
+            sc.x_il8 = x_il8 != 0;
+            return 0;
+        }
+        const bool want = x_il8 != 0;
+        if ((plan->subs[0].f16mma != 0) != want) {
+            const int xf = plan->subs[0].x_f16, yf = plan->subs[0].y_f16;
+            if (int rc = build_deconv3d_subs(plan, want)) return rc;
+            for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
+        }
+        for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }
         return 0;
     }
     if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)))
@@ -1949,6 +2056,12 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                     if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
                     else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, false, _Float16, float>), grid, dim3(256), 0, S(s), a);
                 }
+            } else if (sc.small3d == 1 && sc.x_f16 && sc.x_il8) {     // ... with a channel-interleaved (K/8, D, H, W, 8) input: on the matrix cores
+                a.w = static_cast<const float*>(sc.small_il_dev);
+                const int groups = (int)rt::cdiv((a.Wx + 1) / 2, 16);
+                RT_REQUIRE(batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
+                dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rt::cdiv((a.Hx + 1) / 2, 2), (unsigned)batch);
+                hipLaunchKernelGGL(rt::deconv3d_s2_il_kernel, g2, dim3(256), 0, S(s), a);
             } else if (sc.small3d == 1 && sc.x_f16) {   // 3-D last layer in half2 mode: fp16 (K,D,H,W) in, fp32 volume out
                 if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
                 else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
@@ -1966,6 +2079,8 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
             plan->opt_rb_tiles = exp_knob("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
+            plan->opt_zinner = env_int("RT_Z_INNER", 1);     // 3-D launches: depth slices fastest inside a tile (ConvArgs::z_inner); 0 = z outermost
+            plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
         });
         rt::ConvArgs a;
         a.x = static_cast<const float*>(x);
@@ -1991,6 +2106,8 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         a.xcd_order = plan->opt_xcd;
         a.x_bstride = plan->x_bstride; a.y_bstride = plan->y_bstride;
         a.y_cstride = sc.y_cstride; a.y_zstride = sc.y_zstride; a.y_off = sc.y_off;
+        // Conv3D writing a channel-major interleaved tensor (K/8, D, H, W, 8): a depth slice is 8 * H * W elements apart
+        if (plan->is_conv3d && !plan->c3d_dchw && sc.y_il8) a.y_zstride = 8 * sc.y_zstride;
         a.y_ystride = sc.y_ystride; a.y_xstride = sc.y_xstride;
         a.r_cstride = sc.r_cstride ? sc.r_cstride : sc.y_cstride;
         a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
@@ -1998,7 +2115,11 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         a.batch = batch; a.cin_real = sc.cin_real; a.x_cstride = (int64_t)sc.Hi * a.x_pitch;
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
-        RT_REQUIRE(gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
+        // split-fp16 / fp16-operand launches of 3-D plans fold the z-slices into grid.x, z fastest (conv_mfma.hip.h: ConvArgs::z_inner)
+        const bool zin = sc.nz > 1 && plan->opt_zinner != 0 && (sc.split3 || sc.f16mma) && (int64_t)rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Ho, sc.TY) * sc.nz < (1ll << 30);
+        a.z_inner = zin ? 1 : 0;
+        auto zfold = [&](dim3 g) { return zin ? dim3(g.x * (unsigned)sc.nz, g.y, (unsigned)batch) : g; };
+        RT_REQUIRE(zin ? batch <= 65535 : gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
         RT_REQUIRE(sc.y_cstride * (int64_t)sc.Cout < (1ll << 29), "rt_conv_enqueue: output sample exceeds 2 GB (32-bit buffer offsets)");
         if (sc.direct) {
             RT_REQUIRE(sc.Ho <= 65535, "rt_conv_enqueue: output too tall for the direct kernel");
@@ -2102,17 +2223,17 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (sc.x_f16 || sc.y_f16) {                 // fp16 storage (3-D tensors of half2 mode): planar, 4-row tiles
                 // (the residual's layout is a run-time flag of the kernel: r_il8; an interleaved fp16 OUTPUT exists for fp32 planar input)
                 if (!sc.x_f16 && sc.x_il8 && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 4 && sc.y_f16) {      // fp32 interleaved in (2-D tower tensor)
-                    if (sc.y_il8) launch_s3<3, 3, 1, true, true, 4, float, _Float16>(grid, ks, per_cu, S(s), a);
-                    else launch_s3<3, 3, 1, true, false, 4, float, _Float16>(grid, ks, per_cu, S(s), a);
+                    if (sc.y_il8) launch_s3<3, 3, 1, true, true, 4, float, _Float16>(zfold(grid), ks, per_cu, S(s), a);
+                    else launch_s3<3, 3, 1, true, false, 4, float, _Float16>(zfold(grid), ks, per_cu, S(s), a);
                     RT_LAUNCH_CHECK("conv_s3_kernel<float, f16>");
                     continue;
                 }
                 RT_REQUIRE(!sc.x_il8 && !(sc.y_il8 && sc.x_f16) && sc.TY == 4 && sc.y_f16, "rt_conv_enqueue: fp16-storage variant of the split kernel not instantiated");
 #define RT_S3H(kh, kw, st)                                                                                                         \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                                   \
-        if (sc.x_f16) launch_s3<kh, kw, st, false, false, 4, _Float16, _Float16>(grid, ks, per_cu, S(s), a); \
-        else if (sc.y_il8) launch_s3<kh, kw, st, false, true, 4, float, _Float16>(grid, ks, per_cu, S(s), a); \
-        else launch_s3<kh, kw, st, false, false, 4, float, _Float16>(grid, ks, per_cu, S(s), a);   \
+        if (sc.x_f16) launch_s3<kh, kw, st, false, false, 4, _Float16, _Float16>(zfold(grid), ks, per_cu, S(s), a); \
+        else if (sc.y_il8) launch_s3<kh, kw, st, false, true, 4, float, _Float16>(zfold(grid), ks, per_cu, S(s), a); \
+        else launch_s3<kh, kw, st, false, false, 4, float, _Float16>(zfold(grid), ks, per_cu, S(s), a);   \
         launched = true;                                                                                                           \
     }
                 RT_S3H(3, 3, 1) RT_S3H(3, 3, 2) RT_S3H(1, 1, 1) RT_S3H(1, 2, 1) RT_S3H(2, 1, 1) RT_S3H(2, 2, 1)
@@ -2120,19 +2241,19 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             }
 #ifdef RT_EXPERIMENTAL
             if (!launched && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.TY == 8) {          // 8-row tiles, 8 waves
-                if (sc.x_il8 && sc.y_il8) launch_s3<3, 3, 1, true, true, 8>(grid, ks, per_cu, S(s), a);
-                else if (sc.x_il8) launch_s3<3, 3, 1, true, false, 8>(grid, ks, per_cu, S(s), a);
-                else if (sc.y_il8) launch_s3<3, 3, 1, false, true, 8>(grid, ks, per_cu, S(s), a);
-                else launch_s3<3, 3, 1, false, false, 8>(grid, ks, per_cu, S(s), a);
+                if (sc.x_il8 && sc.y_il8) launch_s3<3, 3, 1, true, true, 8>(zfold(grid), ks, per_cu, S(s), a);
+                else if (sc.x_il8) launch_s3<3, 3, 1, true, false, 8>(zfold(grid), ks, per_cu, S(s), a);
+                else if (sc.y_il8) launch_s3<3, 3, 1, false, true, 8>(zfold(grid), ks, per_cu, S(s), a);
+                else launch_s3<3, 3, 1, false, false, 8>(zfold(grid), ks, per_cu, S(s), a);
                 launched = true;
             }
 #endif
 #define RT_S3(kh, kw, st)                                                                                                   \
     if (!launched && sc.KH == kh && sc.KW == kw && sc.S == st) {                                                            \
-        if (sc.x_il8 && sc.y_il8) launch_s3<kh, kw, st, true, true>(grid, ks, per_cu, S(s), a);        \
-        else if (sc.x_il8) launch_s3<kh, kw, st, true, false>(grid, ks, per_cu, S(s), a);              \
-        else if (sc.y_il8) launch_s3<kh, kw, st, false, true>(grid, ks, per_cu, S(s), a);              \
-        else launch_s3<kh, kw, st, false, false>(grid, ks, per_cu, S(s), a);                           \
+        if (sc.x_il8 && sc.y_il8) launch_s3<kh, kw, st, true, true>(zfold(grid), ks, per_cu, S(s), a);        \
+        else if (sc.x_il8) launch_s3<kh, kw, st, true, false>(zfold(grid), ks, per_cu, S(s), a);              \
+        else if (sc.y_il8) launch_s3<kh, kw, st, false, true>(zfold(grid), ks, per_cu, S(s), a);              \
+        else launch_s3<kh, kw, st, false, false>(zfold(grid), ks, per_cu, S(s), a);                           \
         launched = true;                                                                                                    \
     }
             RT_S3(3, 3, 1) RT_S3(3, 3, 2) RT_S3(1, 1, 1) RT_S3(1, 2, 1) RT_S3(2, 1, 1) RT_S3(2, 2, 1)
@@ -2152,10 +2273,20 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_f16mma %dx%d s%d rows %d il8 x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.TY, sc.x_il8,
                         sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
+            // Conv3D between interleaved fp16 tensors: four output rows per wave, operands reused from registers (conv_f16r4.hip.h) -- the
+            // 4 x 32-tile kernel below reads 2 KB of LDS per MFMA and is LDS-bound at 0.3 of the matrix peak on these layers
+            if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.x_il8 && sc.y_il8 && !sc.zs_dev && sc.TY == 4 && sc.y_xstride == 1 &&
+                (plan->opt_r4 > 0 || (plan->opt_r4 < 0 && plan->is_conv3d && sc.Ho >= 12))) {
+                dim3 g4 = zfold(dim3((unsigned)(a.tiles_x * (int)rt::cdiv(sc.Ho, rt::ConvF16R4Cfg::TY)), grid.y, grid.z));
+                if (plan->opt_trace) fprintf(stderr, "[rt] conv_f16r4 grid %u x %u x %u\n", g4.x, g4.y, g4.z);
+                hipLaunchKernelGGL(rt::conv_f16r4_kernel, g4, dim3(256), 0, S(s), a);
+                RT_LAUNCH_CHECK("conv_f16r4_kernel");
+                continue;
+            }
             if (sc.KH == 3 && sc.KW == 3 && sc.S == 1) {     // the tower layers: tensor layouts x rows per workgroup
 #define RT_F16_331(xi, yi, nw)                                                                                   \
     if (sc.x_il8 == xi && sc.y_il8 == yi && sc.TY == nw) {                                                       \
-        hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, xi != 0, yi != 0, nw>), grid, dim3(64 * nw), 0, S(s), a); \
+        hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 1, xi != 0, yi != 0, nw>), zfold(grid), dim3(64 * nw), 0, S(s), a); \
         RT_LAUNCH_CHECK("conv_f16mma_kernel<3,3,1>");                                                            \
         continue;                                                                                                \
     }
@@ -2163,16 +2294,22 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
 #undef RT_F16_331
             }
             if (sc.KH == 3 && sc.KW == 3 && sc.S == 2 && sc.TY == 4 && (sc.x_il8 || sc.y_il8)) {      // stride-2 Conv3D on interleaved 4-D tensors
-                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, true>), grid, dim3(256), 0, S(s), a);
-                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, false>), grid, dim3(256), 0, S(s), a);
-                else hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, false, true>), grid, dim3(256), 0, S(s), a);
+                if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, true>), zfold(grid), dim3(256), 0, S(s), a);
+                else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, true, false>), zfold(grid), dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::conv_f16mma_kernel<3, 3, 2, false, true>), zfold(grid), dim3(256), 0, S(s), a);
                 RT_LAUNCH_CHECK("conv_f16mma_kernel<3,3,2>");
+                continue;
+            }
+            if (sc.KH == 2 && sc.KW == 2 && sc.S == 1 && sc.TY == 4 && sc.x_il8) {      // phases of a transposed 3-D convolution on interleaved input
+                if (sc.y_il8) hipLaunchKernelGGL((rt::conv_f16mma_kernel<2, 2, 1, true, true>), zfold(grid), dim3(256), 0, S(s), a);
+                else hipLaunchKernelGGL((rt::conv_f16mma_kernel<2, 2, 1, true, false>), zfold(grid), dim3(256), 0, S(s), a);
+                RT_LAUNCH_CHECK("conv_f16mma_kernel<2,2,1,il>");
                 continue;
             }
             RT_REQUIRE(!(sc.x_il8 || sc.y_il8 || sc.r_il8) && sc.TY == 4, "rt_conv_enqueue: fp16-arithmetic variant not instantiated");
 #define RT_F16CASE(kh, kw, st)                                                                              \
     if (sc.KH == kh && sc.KW == kw && sc.S == st) {                                                         \
-        hipLaunchKernelGGL((rt::conv_f16mma_kernel<kh, kw, st>), grid, dim3(256), 0, S(s), a);              \
+        hipLaunchKernelGGL((rt::conv_f16mma_kernel<kh, kw, st>), zfold(grid), dim3(256), 0, S(s), a);              \
         RT_LAUNCH_CHECK("conv_f16mma_kernel<" #kh "," #kw "," #st ">");                                     \
         continue;                                                                                           \
     }

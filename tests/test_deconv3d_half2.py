@@ -1,0 +1,276 @@
+"""half2 mode of the 3-D decoder at the operator level (BASELINE config C5, NVSmall fp16): Conv3DTranspose on fp16 operands with a
+channel-interleaved input (K/8, Dy, Hy, Wy, 8) -- conv_f16mma_kernel over the stride-2 phases -- writing interleaved (D, C/8, H, W, 8) or,
+with the fused Transform, (C/8, D, H, W, 8) tensors; Conv3D writing the channel-major interleaved tensor such a layer reads; and the
+last layer (one or two output channels) on the matrix cores (deconv3d_s2_il_kernel).  Reference: the oracle on the same fp16-rounded
+operands (lib/conv3d_transpose_plugin.cpp:205-243 semantics: cuDNN backward-data of the forward convolution), fp32 accumulation, one
+rounding of the output.  The planar fp16 forms of the same plans must agree with the interleaved ones to that rounding as well."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stereo_oracle as O
+from redtail_amd import capi
+from test_ops_parity import T, rnd
+
+
+def q16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def h16(a):
+    return np.ascontiguousarray(a.astype(np.float16))
+
+
+def dev16(backend, a):
+    return torch.from_numpy(h16(a)).cuda() if backend.name == "gpu" else h16(a)
+
+
+def empty(backend, shape, f16):
+    if backend.name == "gpu":
+        return torch.full(tuple(shape), float("nan"), dtype=torch.float16 if f16 else torch.float32, device="cuda")
+    return np.full(shape, np.nan, np.float16 if f16 else np.float32)
+
+
+def host(backend, t):
+    if backend.name == "gpu":
+        torch.cuda.synchronize()
+        return t.cpu().numpy().astype(np.float32)
+    return np.asarray(t).astype(np.float32)
+
+
+def il_cm(a):
+    """channel-major (N, K, D, H, W) -> (N, K/8, D, H, W, 8)"""
+    n, k, d, h, w = a.shape
+    return np.ascontiguousarray(a.reshape(n, k // 8, 8, d, h, w).transpose(0, 1, 3, 4, 5, 2))
+
+
+def un_il_cm(a):
+    n, g, d, h, w, _ = a.shape
+    return a.transpose(0, 1, 5, 2, 3, 4).reshape(n, g * 8, d, h, w)
+
+
+def il_dm(a):
+    """depth-major (N, D, C, H, W) -> (N, D, C/8, H, W, 8)"""
+    n, d, c, h, w = a.shape
+    return np.ascontiguousarray(a.reshape(n, d, c // 8, 8, h, w).transpose(0, 1, 2, 4, 5, 3))
+
+
+def un_il_dm(a):
+    n, d, g, h, w, _ = a.shape
+    return a.transpose(0, 1, 2, 5, 3, 4).reshape(n, d, g * 8, h, w)
+
+
+DECONV_CASES = [
+    # K, C, (Dy, Hy, Wy), out depth computed (full), kept, pad_d, skip, cdhw
+    (16, 8, (3, 4, 19), 7, 6, 0, True, True),       # NVSmall's decoder pattern: depth pad 0, surplus slice dropped, fused Transform
+    (16, 8, (3, 4, 19), 7, 6, 0, True, False),      # ... without the Transform: (D, C/8, H, W, 8)
+    (8, 16, (3, 5, 9), 5, 5, 1, True, True),        # depth pad 1 (odd depth), K = 8: one half-empty chunk of 16 gathered channels
+    (24, 40, (2, 3, 17), 3, 3, 1, False, True),     # no skip tensor, channel counts that are not multiples of 16 / 32
+    (32, 32, (2, 6, 33), 5, 4, 0, True, True),      # two 32-pixel tiles across, 2 row tiles
+]
+
+
+@pytest.mark.parametrize("r_il", [1, 0])
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw", DECONV_CASES)
+def test_conv3d_transpose_f16_interleaved(backend, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw, r_il):
+    if r_il and not skip:
+        pytest.skip("no residual")
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y = q16(rnd(n, K, dy, hy, wy))
+    w = q16(rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)))
+    b = q16(rnd(C))
+    sk = q16(rnd(n, dkeep, C, hx, wx)) if skip else None
+    ps = (pad_d, 1, 1)
+    ref = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    if skip:
+        ref = ref + T(sk).double()
+    ref = O.elu(ref)
+    if cdhw:
+        ref = O.transform(ref)
+    ref = ref.numpy()
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
+
+    def make():
+        p = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
+                                     has_residual=skip, dtype=capi.RT_F16, transposed_in_dims=ydims, out_depth=dkeep)
+        p.set_io_types(capi.RT_F16, capi.RT_F16)
+        return p
+    # planar fp16 tensors (the split kernel), the skip tensor interleaved or not
+    plan = make()
+    caps = plan.il_caps()
+    assert caps & 1 and caps & 2 and caps & 8 and bool(caps & 4) == skip, caps
+    if r_il:
+        plan.set_layouts(0, 0, 1)
+    out = empty(backend, ref.shape, True)
+    plan.enqueue(dev16(backend, y), out, dev16(backend, il_dm(sk) if r_il else sk) if skip else None, n)
+    planar = host(backend, out)
+    assert np.abs(planar - ref).max() <= tol
+    with pytest.raises(capi.RtError):
+        plan.set_layouts(0, 1, r_il)                  # an interleaved output needs the interleaved input (fp16 operands)
+    # interleaved input: fp16 operands, interleaved output
+    plan.set_layouts(1, 1, r_il)
+    oshape = (n, C // 8, dkeep, hx, wx, 8) if cdhw else (n, dkeep, C // 8, hx, wx, 8)
+    out = empty(backend, oshape, True)
+    plan.enqueue(dev16(backend, il_cm(y)), out, dev16(backend, il_dm(sk) if r_il else sk) if skip else None, n)
+    got = host(backend, out)
+    assert not np.isnan(got).any()
+    got = un_il_cm(got) if cdhw else un_il_dm(got)
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    assert np.abs(got - planar).max() <= tol
+    # interleaved input, planar output
+    plan.set_layouts(1, 0, r_il)
+    out = empty(backend, ref.shape, True)
+    plan.enqueue(dev16(backend, il_cm(y)), out, dev16(backend, il_dm(sk) if r_il else sk) if skip else None, n)
+    assert np.abs(host(backend, out) - ref).max() <= tol
+    # and back: the plan returns to the split kernel on planar tensors with the same bits as before
+    plan.set_layouts(0, 0, r_il)
+    out = empty(backend, ref.shape, True)
+    plan.enqueue(dev16(backend, y), out, dev16(backend, il_dm(sk) if r_il else sk) if skip else None, n)
+    assert np.array_equal(host(backend, out), planar)
+    plan.destroy()
+
+
+@pytest.mark.parametrize("c,k,d,h,w,stride", [(16, 32, 5, 9, 35, 1), (16, 24, 6, 8, 37, 2), (32, 64, 3, 5, 33, 1)])
+def test_conv3d_writes_channel_major_interleaved(backend, c, k, d, h, w, stride):
+    """the last Conv3D of the encoder keeps (K, D, H, W) (no Transform, nvsmall_1025x321_net.cpp:287-300): with an interleaved input it
+    writes (K/8, D, H, W, 8) -- the tensor the first Conv3DTranspose reads"""
+    n = 2
+    x = q16(rnd(n, d, c, h, w))
+    wt, b = q16(rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * c))), q16(rnd(k))
+    even = stride == 2 and d % 2 == 0
+    pads = (0, 1, 1) if even else (1, 1, 1)
+    xin = O.pad_d(T(x).double(), 1) if even else T(x).double()
+    ref = O.elu(O.conv3d_tf(xin, T(wt).double(), T(b).double(), (stride,) * 3, pads, pads)).numpy()      # (N, K, Do, Ho, Wo)
+    plan = backend.klib.conv3d_plan(h16(wt), h16(b), c, k, (d + (1 if even else 0), h, w), (3, 3, 3), (stride,) * 3, pads, pads,
+                                    act=capi.RT_ACT_ELU, out_dchw=False, dtype=capi.RT_F16, in_pad_end=1 if even else 0)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    assert plan.il_caps() & 3 == 3
+    plan.set_layouts(1, 1, 0)
+    out = empty(backend, (n, k // 8) + ref.shape[2:] + (8,), True)
+    plan.enqueue(dev16(backend, il_dm(x)), out, None, n)
+    got = un_il_cm(host(backend, out))
+    assert np.abs(got - ref).max() <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+    plan.destroy()
+
+
+SMALL_CASES = [
+    # K, C, (Dy, Hy, Wy), out depth computed, kept, pad_d, act
+    (32, 1, (3, 4, 19), 7, 6, 0, capi.RT_ACT_NONE),        # NVSmall / ResNet-18 3D: 32 channels -> 1, depth pad 0, the surplus slice dropped
+    (32, 1, (2, 5, 40), 3, 3, 1, capi.RT_ACT_ELU),         # depth pad 1; 40 blocks across: three 16-block groups, the last one ragged
+    (64, 2, (2, 3, 9), 5, 4, 0, capi.RT_ACT_NONE),         # two output channels (rows 8..15 of the MFMA), two blocks of 32 input channels
+    (32, 2, (1, 1, 1), 1, 1, 1, capi.RT_ACT_SIGMOID),      # a single voxel
+]
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,act", SMALL_CASES)
+def test_last_deconv3d_on_interleaved_input(backend, K, C, ydims, dfull, dkeep, pad_d, act):
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y = q16(rnd(n, K, dy, hy, wy))
+    w = q16(rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)))
+    b = q16(rnd(C))
+    ps = (pad_d, 1, 1)
+    ref = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    ref = (O.elu(ref) if act == capi.RT_ACT_ELU else torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref).numpy()
+    plan = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=act, dtype=capi.RT_F16,
+                                    transposed_in_dims=ydims, out_depth=dkeep)
+    plan.set_io_types(capi.RT_F16, capi.RT_F32)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, y), out, None, n)
+    planar = host(backend, out)
+    tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(planar - ref).max() <= tol
+    assert plan.il_caps() == 1
+    plan.set_layouts(1, 0, 0)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), out, None, n)
+    got = host(backend, out)
+    assert not np.isnan(got).any()
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    plan.set_layouts(0, 0, 0)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, y), out, None, n)
+    assert np.array_equal(host(backend, out), planar)
+    plan.destroy()
+
+
+def il_2d(a):
+    """(N, C, H, W) -> (N, C/8, H, W, 8)"""
+    n, c, h, w = a.shape
+    return np.ascontiguousarray(a.reshape(n, c // 8, 8, h, w).transpose(0, 1, 3, 4, 2))
+
+
+R4_CASES = [
+    # c, k, d, h, w, channel-major output, residual (0 none, 1 interleaved, 2 planar)
+    (16, 32, 3, 20, 37, False, 0),      # two 16-row tiles (the second with 4 rows), two column tiles
+    (32, 64, 2, 17, 70, False, 1),      # two blocks of 32 output channels, skip tensor interleaved
+    (16, 24, 2, 33, 33, True, 0),       # Cout % 32 != 0, channel-major (K/8, D, H, W, 8) output, one pixel past a column tile
+    (8, 32, 4, 5, 9, False, 2),         # image smaller than a tile, one half-empty chunk, planar skip tensor
+]
+
+
+@pytest.mark.parametrize("c,k,d,h,w,cm,resid", R4_CASES)
+def test_conv3d_four_rows_per_wave(backend, monkeypatch, c, k, d, h, w, cm, resid):
+    """conv_f16r4_kernel (16 x 32 tiles, four output rows per wave, operands reused from registers) against the oracle and against the
+    4 x 32-tile kernel it replaces on the Conv3D layers between interleaved fp16 tensors"""
+    n = 2
+    x = q16(rnd(n, d, c, h, w))
+    wt, b = q16(rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * c))), q16(rnd(k))
+    ref = O.conv3d_tf(T(x).double(), T(wt).double(), T(b).double(), (1, 1, 1), (1, 1, 1), (1, 1, 1))      # (N, K, D, H, W)
+    if not cm:
+        ref = O.transform(ref)                                                                        # (N, D, K, H, W)
+    res = q16(rnd(*ref.shape)) if resid else None
+    if resid:
+        ref = ref + T(res).double()
+    ref = O.elu(ref).numpy()
+    outs = []
+    for r4 in ("1", "0"):
+        monkeypatch.setenv("RT_F16_R4", r4)
+        plan = backend.klib.conv3d_plan(h16(wt), h16(b), c, k, (d, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU,
+                                        out_dchw=not cm, has_residual=bool(resid), dtype=capi.RT_F16)
+        plan.set_io_types(capi.RT_F16, capi.RT_F16)
+        plan.set_layouts(1, 1, 0)
+        oshape = (n, k // 8, d, h, w, 8) if cm else (n, d, k // 8, h, w, 8)
+        out = empty(backend, oshape, True)
+        rin = None
+        if resid:
+            rin = dev16(backend, (il_cm(res) if cm else il_dm(res)) if resid == 1 else res)
+            if resid == 1:
+                plan.set_layouts(1, 1, 1) if plan.il_caps() & 4 else pytest.skip("no interleaved residual for this plan")
+        plan.enqueue(dev16(backend, il_dm(x)), out, rin, n)
+        got = host(backend, out)
+        assert not np.isnan(got).any()
+        outs.append(un_il_cm(got) if cm else un_il_dm(got))
+        plan.destroy()
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
+    assert np.abs(outs[1] - ref).max() <= tol
+    assert np.abs(outs[0] - outs[1]).max() <= tol
+
+
+@pytest.mark.parametrize("f,k,h,w,D", [(8, 16, 18, 37, 6), (32, 32, 13, 40, 12)])
+def test_conv3d_four_rows_per_wave_on_folded_cost_volume(backend, monkeypatch, f, k, h, w, D):
+    """the first Conv3D of the 3-D models in half2 mode: the two fp16 feature maps, channel-interleaved (2F/8, H, W, 8), the right one read
+    shifted by the slice's disparity (rtConv3dDesc::cv_fold), on the four-rows-per-wave kernel"""
+    n = 2
+    l, r = q16(rnd(n, f, h, w)), q16(rnd(n, f, h, w))
+    wt, b = q16(rnd(k, 3, 2 * f, 3, 3) * np.float32(1 / np.sqrt(27 * 2 * f))), q16(rnd(k))
+    cv = O.cost_volume(T(l).double(), T(r).double(), D)
+    ref = O.elu(O.transform(O.conv3d_tf(cv, T(wt).double(), T(b).double(), (1, 1, 1), (1, 1, 1), (1, 1, 1)))).numpy()
+    outs = []
+    for r4 in ("1", "0"):
+        monkeypatch.setenv("RT_F16_R4", r4)
+        plan = backend.klib.conv3d_plan(h16(wt), h16(b), 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU,
+                                        out_dchw=True, cv_fold=f, dtype=capi.RT_F16)
+        plan.set_io_types(capi.RT_F16, capi.RT_F16)
+        plan.set_layouts(1, 1, 0)
+        out = empty(backend, (n, D, k // 8, h, w, 8), True)
+        plan.enqueue(dev16(backend, il_2d(np.concatenate([l, r], axis=1))), out, None, n)
+        outs.append(un_il_dm(host(backend, out)))
+        plan.destroy()
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
+    assert np.abs(outs[1] - ref).max() <= tol

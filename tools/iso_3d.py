@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""A few passes of a 3-D model for rocprofv3 counter runs (tools/pmc_3d.sh): python tools/iso_3d.py [model] [passes] [--half2] [--batch=N]"""
+import os
+import sys
+os.environ.setdefault("RT_DEV_KNOBS", "1")
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redtail_amd import capi, synth  # noqa: E402
+
+CASES = {"nvtiny": (513, 161, synth.NVTINY_3D), "nvsmall": (1025, 321, synth.NVSMALL_3D), "resnet18": (1025, 321, synth.RESNET18_3D)}
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+model = args[0] if args else "nvsmall"
+passes = int(args[1]) if len(args) > 1 else 3
+half2 = "--half2" in sys.argv
+batch = max([int(a[8:]) for a in sys.argv if a.startswith("--batch=")] + [1])
+w, h, cfg = CASES[model]
+lib = capi.NetLib()
+net = lib.create(model, w, h, max_batch=batch, weights=synth.synth_weights_3d(cfg), fp16_weights=half2)
+net.set_streams(1)
+l, r = synth.synth_pair(h, w, 1234)
+L, R = torch.from_numpy(np.stack([l] * batch)).cuda(), torch.from_numpy(np.stack([r] * batch)).cuda()
+out = torch.empty(batch, 1, h, w, device="cuda")
+for _ in range(passes):
+    net.execute(L, R, out, batch)
+torch.cuda.synchronize()
+print("launches per pass:", [net.launch_name(i) for i in range(net.num_launches)])

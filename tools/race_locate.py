@@ -57,6 +57,17 @@ def describe(net_bad, net_good, k, name):
     info["runs"] = len(runs)
     info["run_lengths"] = sorted({int(len(r)) for r in runs})[:12]
     info["run_starts"] = [int(r[0]) for r in runs[:12]]
+    # where do the wrong bits come from?  every position of the GOOD tensor that holds exactly a wrong word's bit pattern
+    gb = good.view(np.uint32)
+    order = np.argsort(gb, kind="stable")
+    sorted_bits = gb[order]
+    src = []
+    for wd in neq[:16]:
+        bits = bad.view(np.uint32)[wd]
+        lo, hi = np.searchsorted(sorted_bits, bits, "left"), np.searchsorted(sorted_bits, bits, "right")
+        hits = [int(order[i]) for i in range(lo, min(hi, lo + 4))]
+        src.append({"word": int(wd), "at": decode(name, int(wd)), "same_bits_in_good_tensor_at": [{"word": h, "delta_words": h - int(wd), "pos": decode(name, h)} for h in hits]})
+    info["sources"] = src
     dec = [decode(name, int(w)) for w in neq[:64]]
     if dec and dec[0]:
         info["first"] = dec[0]
