@@ -657,13 +657,17 @@ def main():
         # abandoned in its daemon thread and the ranks agree on the fallback below -- a hang here would cost the whole scaling run
         import threading
         res = {}
+        # the 128-byte unique id travels over torch.distributed's group HERE, on the thread that owns that group; the thread
+        # below only touches the communicator of our own (rt_comm_init_rank / rt_net_create_broadcast), so abandoning it leaves the
+        # process group untouched and the fallback collectives below are safe
+        uid = parallel.exchange_unique_id(lib, rank, world, dist)
 
         def native_startup():
             try:
-                torch.cuda.set_device(dev)                      # the current device is per host thread: torch's (the id travels as a device tensor) ...
+                torch.cuda.set_device(dev)                      # the current device is per host thread: torch's ...
                 lib.kernels.check(lib.kernels.lib.rt_set_device(local_rank), "rt_set_device")      # ... and HIP's
                 res["nets"] = parallel.create_nets_native(lib, "resnet18_2D", W, H, args.contexts, blob, rank, world, dist, max_batch=args.batch,
-                                                          fp16_weights=args.half2)
+                                                          fp16_weights=args.half2, uid=uid)
             except Exception as e:                              # noqa: BLE001 -- any failure of the native entry must not cost the scaling run
                 res["error"] = e
 
@@ -1084,7 +1088,7 @@ def main():
             "config": {"workload": "ResNet-18 2D Stereo DNN %s, 1257x369, batch=%d per step, one MI355X per rank" % (
                            "half2 mode" if args.half2 else "fp32", b),
                        "pairs_per_step": b, "contexts": nctx, "streams_per_context": spc, "launches_per_step": net.num_launches, "layers": net.num_layers,
-                       "weights": weights_desc, "weights_transport": transport, "parallelism": "pairs sharded over %d GPU(s)" % world},
+                       "weights": weights_desc, "weights_transport": transport, "startup_degraded": bool(NATIVE_STARTUP_HUNG[0]), "parallelism": "pairs sharded over %d GPU(s)" % world},
             "parity_max_abs_err": parity, "contexts_max_abs_diff": ctx_diff,
             "parity_note": "max |disp - oracle| over the %d timed context(s), same pair(s), %s; budget %s" % (
                 nctx, "oracle on the fp16-rounded weights" if args.half2 else "fp32 oracle", "1e-2" if args.half2 else "1e-3"),

@@ -286,7 +286,9 @@ int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* 
 /* The same with launch hints (0 = rt_conv_enqueue).  RT_HINT_THROUGHPUT: the caller keeps several launches in flight on the device
  * (execution contexts with one stream each, TensorRT's `trtexec --streams` set-up; IExecutionContext::setExecutionStreams(1)): kernels
  * may then trade the duration of one launch for device time per result -- the streaming residual block walks 64-row instead of 32-row
- * segments (fewer pipeline fill / drain steps per row, half the workgroups per launch).  Results do not depend on hints. */
+ * segments (fewer pipeline fill / drain steps per row, half the workgroups per launch); without the hint, launches that would leave a
+ * SIMD a single wave split their contraction over wave groups (split-K: another fp32 summation order).  Results are deterministic for
+ * a given (hints, device CU count) and agree across hints to fp32 rounding (<= 1e-5 on the networks' outputs), not bit for bit. */
 #define RT_HINT_THROUGHPUT 1
 int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                          rtStream stream, int hints);

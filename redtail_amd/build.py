@@ -21,6 +21,12 @@ HOSTCXX = os.environ.get("RT_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 GXX = os.environ.get("CXX", "g++")
 
 HOST_SOURCES = ["host/plugins.cpp", "host/engine.cpp", "host/networks.cpp", "host/net_capi.cpp"]
+# Device code is built WITHOUT the SLP vectoriser (round 4, profiles/r04_race.txt): the packed fp32 instructions it forms from adjacent
+# scalar adds / multiplies (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32) (a) are slower than their scalar forms beside MFMAs on gfx950 (+4 %
+# on the headline without them) and (b) were the trigger of the one run-to-run deviation ever located in this code base -- the exact-fp32
+# Winograd kernel's interleaved epilogue beside co-resident fp16-MFMA waves; with -fno-slp-vectorize 0 of 8000 launches deviate, with it
+# 40 %.  Packed math that is WRITTEN as such in the kernels (f32x2 types) is unaffected.
+DEVICE_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _newer(target, sources):
@@ -49,7 +55,7 @@ def build_hip(force=False):
     deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
     if force or _newer(out, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-              "-Wno-unused-function", os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+              "-Wno-unused-function"] + DEVICE_FLAGS + [os.path.join(CSRC, "rt_capi.hip"), "-o", out])
     return out
 
 
@@ -60,8 +66,8 @@ def build_hip_timing(force=False):
     out = os.path.join(outdir, "librt_stereo_hip_timing.so")
     deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
     if force or _newer(out, deps):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRT_KERNEL_TIMING", "-w",
-              os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRT_KERNEL_TIMING", "-w"] + DEVICE_FLAGS +
+             [os.path.join(CSRC, "rt_capi.hip"), "-o", out])
     return out
 
 
@@ -74,13 +80,13 @@ def build_hip_ablation(mask, force=False, timing=False):
     if force or _newer(out, deps):
         # mask >= 10000: no ablation, conv_f16mma_kernel compiled for (mask - 10000) waves per SIMD
         defs = ["-DRT_ABLATE=0", "-DRT_F16_WAVES=%d" % (mask - 10000)] if mask >= 10000 else ["-DRT_ABLATE=%d" % mask]
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + defs +
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + DEVICE_FLAGS + defs +
              (["-DRT_KERNEL_TIMING"] if timing else []) + [
               os.path.join(CSRC, "rt_capi.hip"), "-o", out])
     return out
 
 
-def build_variant(name, defines, force=False):
+def build_variant(name, defines, force=False, device_flags=None):
     """Another build of the two product libraries side by side in tools/build/<name>/ (probes: RT_EXPERIMENTAL kernel families, hazard
     probes ...; never the product).  Tools take the directory through RT_VARIANT_DIR."""
     outdir = os.path.join(ROOT, "tools", "build", name)
@@ -89,8 +95,8 @@ def build_variant(name, defines, force=False):
     host = os.path.join(outdir, "libnvstereo_inference.so")
     deps = [os.path.join(CSRC, "rt_capi.hip"), os.path.join(CSRC, "kernels"), os.path.join(ROOT, "include")]
     if force or _newer(kern, deps):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + list(defines) +
-             [os.path.join(CSRC, "rt_capi.hip"), "-o", kern])
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + (DEVICE_FLAGS if device_flags is None else list(device_flags)) +
+             list(defines) + [os.path.join(CSRC, "rt_capi.hip"), "-o", kern])
     if force or _newer(host, [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]):
         _build_host_against(kern, host)
     return outdir

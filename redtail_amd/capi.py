@@ -9,8 +9,10 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIP_LIB = os.path.join(ROOT, "redtail_amd", "lib", "librt_stereo_hip.so")
-HOST_LIB = os.path.join(ROOT, "redtail_amd", "lib", "libnvstereo_inference.so")
+# RT_LIB_DIR: another build of the two libraries (redtail_amd/build.py: build_variant) for A/B measurements with bench.py / tools
+_LIB_DIR = os.environ.get("RT_LIB_DIR") or os.path.join(ROOT, "redtail_amd", "lib")
+HIP_LIB = os.path.join(_LIB_DIR, "librt_stereo_hip.so")
+HOST_LIB = os.path.join(_LIB_DIR, "libnvstereo_inference.so")
 
 RT_F32, RT_F16 = 0, 1
 RT_NCHW, RT_NC2HW2 = 0, 1
@@ -431,6 +433,13 @@ class NetLib:
         h = c_void_p()
         self.kernels.check(self.kernels.lib.rt_comm_init_rank(ctypes.byref(h), world, rank, unique_id), "rt_comm_init_rank")
         return h
+
+    def comm_init_all(self, ndev, devices=None):
+        """ncclCommInitAll: one communicator per device of THIS process (apps/stereo_throughput.cpp: one thread per device)"""
+        comms = (c_void_p * ndev)()
+        devs = (c_int * ndev)(*devices) if devices is not None else None
+        self.kernels.check(self.kernels.lib.rt_comm_init_all(ctypes.cast(comms, POINTER(c_void_p)), ndev, devs), "rt_comm_init_all")
+        return [c_void_p(comms[i]) for i in range(ndev)]
 
     def comm_destroy(self, comm):
         self.kernels.check(self.kernels.lib.rt_comm_destroy(comm), "rt_comm_destroy")

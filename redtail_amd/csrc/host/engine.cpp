@@ -1427,9 +1427,13 @@ void EngineImpl::assignHalf3D() {
 // as a 2-D proxy, tools/dev/il_probe_f16.py); the folded-cost-volume Conv3D writes one; a fused Conv3DTranspose reads its skip
 // tensor that way.  Which tensors qualify follows from the launches' own capabilities (IStereoPlugin::ilCaps).
 void EngineImpl::assignInterleaved3D() {
-    if (!half2_ || knob("RT_NO_F16") || knob("RT_NO_F16_3D") || knob("RT_NO_IL8") || knob("RT_NO_IL8_3D")) return;
+    if (knob("RT_NO_IL8") || knob("RT_NO_IL8_3D")) return;
+    // half2 mode: the fp16 4-D tensors, groups of 8 channels.  fp32 engines (round 4): the fp32 4-D tensors between Conv3D launches,
+    // groups of 4 -- (D, C/4, H, W, 4), the layout of the 2-D tower tensors (assignPitch) -- and the skip tensors the decoder reads.
+    const bool f16_mode = half2_ && !knob("RT_NO_F16") && !knob("RT_NO_F16_3D");
+    if (!f16_mode && (exact_fp32_ || knob("RT_NO_IL8_3D_F32"))) return;
     std::vector<char> il(tensors_.size(), 0);
-    for (auto& t : tensors_) il[t->id] = t->f16 && t->dims.nbDims == 4 && !t->is_input && !t->is_output && t->alias_of < 0 && t->twin_of < 0 && !t->has_twin;
+    for (auto& t : tensors_) il[t->id] = t->f16 == f16_mode && t->dims.nbDims == 4 && !t->is_input && !t->is_output && t->alias_of < 0 && t->twin_of < 0 && !t->has_twin;
     for (auto& op : ops_) {
         if (op.kind == OpKind::kConv3D) continue;
         for (int i : op.in) il[root(i)] = 0;
@@ -1476,7 +1480,8 @@ void EngineImpl::assignInterleaved3D() {
     if (!ok_) return;
     for (auto& t : tensors_)
         if (il[t->id]) t->il8 = true;
-    if (n) log_.log(ILogger::Severity::kINFO, ("half2 mode: " + std::to_string(n) + " Conv3D launches write channel-interleaved (D, C/8, H, W, 8) tensors").c_str());
+    if (n) log_.log(ILogger::Severity::kINFO, (std::string(f16_mode ? "half2 mode: " : "fp32: ") + std::to_string(n) + " Conv3D launches write channel-interleaved " +
+                                               (f16_mode ? "(D, C/8, H, W, 8)" : "(D, C/4, H, W, 4)") + " tensors").c_str());
 }
 
 // Channel concatenation without copies (the reference concatenates left_conv1_act and the soft-argmax map into the

@@ -45,6 +45,7 @@ struct ZSlice {
     int64_t r_off;         // like y_off, for the residual tensor (differs when the output layout is transposed)
     int64_t r_off_il8;     // r_off for a channel-interleaved fp16 residual (C/8, H, W, 8): the pixel part of the offset counts 8 elements
     int64_t y_off_il8;     // y_off for a channel-interleaved fp16 output: (D, C/8, H, W, 8), or (C/8, D, H, W, 8) when the layout is transposed
+    int64_t r_off_il4;     // r_off for a channel-interleaved fp32 residual, groups of 4 channels: plane part + 4 * pixel part
 };
 
 struct ConvArgs {

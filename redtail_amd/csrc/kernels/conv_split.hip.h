@@ -361,11 +361,16 @@ __global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_W
     const int nchunks = p.CinPad / CC;
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;
     int64_t y_off = p.y_off + (int64_t)zi * p.y_zstride, w_off = 0, r_off = y_off, r_off_il8 = y_off;
+    // interleaved fp32 tensors (groups of 4 channels, 16-byte pixel slots): the PIXEL part of an offset counts 4 elements, the plane part
+    // (depth slice of a 3-D tensor) is what it is.  p.y_off is a pixel offset (2-D plans), zi * y_zstride a plane offset (Conv3D).
+    int64_t y_off_il4 = 4 * p.y_off + (int64_t)zi * p.y_zstride, r_off_il4 = y_off_il4;
     unsigned tap_mask = ~0u;
     if (p.zs) {
         const ZSlice z = p.zs[zi];
         pad_y = z.pad_y; pad_x = z.pad_x; Ho = z.Ho; Wo = z.Wo; ch_row = z.ch_row; y_off = z.y_off; w_off = z.w_off;
         r_off = z.r_off; r_off_il8 = z.r_off_il8;
+        y_off_il4 = 4 * z.y_off;                   // phases of a 2-D transposed convolution (interleaved 3-D outputs of phase launches: fp16 only)
+        r_off_il4 = z.r_off_il4;
         tap_mask = z.tap_mask;
     }
     const int act = p.act;
@@ -454,7 +459,7 @@ __global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_W
     if (p.resid != nullptr && kgi == 0) {
         // interleaved tensors (2-D plans only): pixel offsets -- r_off / y_off of a transposed-convolution phase -- count
         // 16-byte slots, i.e. 4 elements
-        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + (YF16 ? r_off_il8 : 4 * r_off) : rbase, ESY));
+        const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, r_il ? (int64_t)n * p.r_bstride + (YF16 ? r_off_il8 : r_off_il4) : rbase, ESY));
         if (r_il && YF16) {
             // fp16 residual, (C/8, H, W, 8): the lane's 4 consecutive channels of a pixel are 8 bytes (the skip tensor of a fused
             // Conv3DTranspose + skip + ELU launch in half2 mode, written by conv_f16mma_kernel)
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_W
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
-    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (YIL && !YF16) ? (int64_t)n * p.y_bstride + 4 * y_off : ybase, ESY));
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (YIL && !YF16) ? (int64_t)n * p.y_bstride + y_off_il4 : ybase, ESY));
     auto epilogue = [&](auto ACT) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {

@@ -48,7 +48,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 3 = every LDS operand of a k-step is in registers before its first MFMA issues (no LDS return lands while MFMAs execute),
 // 4 = 32 idle cycles before each 16-byte store of the interleaved epilogue,
 // 5 = the interleaved residual is read with four 4-byte loads per pixel instead of one 16-byte load,
-// 6 = s_waitcnt vmcnt(0) after each 16-byte residual load (the four loads of a lane do not overlap).   0 = the kernel as measured in rounds 1-3.
+// 6 = s_waitcnt vmcnt(0) after each 16-byte residual load (the four loads of a lane do not overlap),
+// 7 = 256 idle cycles between the last MFMA of the main loop and the epilogue's first read of an accumulator.   0 = the kernel as measured.
 #ifndef RT_WINO_PROBE
 #define RT_WINO_PROBE 0
 #endif
@@ -353,6 +354,11 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #endif
     }
 
+#if RT_WINO_PROBE == 7 && !defined(HIPEMU)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, ybase, ESY));
     asm volatile("" ::: "memory");     // keep the recomputation below the loop

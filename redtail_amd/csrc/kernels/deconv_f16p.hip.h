@@ -1,0 +1,234 @@
+// Stride-2 transposed 3x3(x3) convolution on fp16 operands, channel-interleaved tensors, ALL FOUR output phases per workgroup (round 4).
+//
+// The ZSlice form (conv_f16mma_kernel<2,2,1> with one slice per output phase, rt_capi.hip: build_deconv3d_subs) launches a workgroup
+// per (tile, depth, PHASE): every phase gathers the same 5 x 33 input patch again and runs 1, 2, 2 or 4 of the 9 kernel taps on it --
+// 37.5 KB staged and eight barriers per 36 MFMAs.  Conv3DTranspose layers of the 3-D decoders (reference
+// lib/conv3d_transpose_plugin.cpp:205-243; NVSmall deconv3D_2: 55 GFLOP for 572 MB of tensors) are memory-bound: what counts is bytes
+// and launches of work per byte.  Here a workgroup owns a 4 x 32 tile of the INPUT grid = an 8 x 64 tile of the output:
+//   * the patch (5 x 33 pixels, 16 gathered channels per chunk) is staged ONCE and serves the 9 taps of the full 3 x 3 window;
+//   * tap (ry, rx) contributes to exactly one phase: per dimension r = 1 -> even outputs from input m, r = 2 -> odd outputs from input m,
+//     r = 0 -> odd outputs from input m + 1 (stride 2, pad 1: o = 2 i + r - 1) -- 9 MFMAs per wave and chunk into 4 accumulators
+//     (one per phase), 4 patch operands (the 2 x 2 input offsets) + 9 weight operands from LDS;
+//   * the weights are packed in KERNEL order [nblk][chunk][tap 9][h][co][8] -- no per-phase slabs padded with zero taps;
+//   * chunks are double-buffered in LDS (2 x 14.7 KB) with one barrier per chunk, as in conv_f16r4.hip.h.
+// Depth taps are merged into the gathered channel axis by the plan (one launch per output-depth class); bias, skip tensor
+// (interleaved or planar), ELU and the optional fused Transform (ZSlice::y_off_il8) as in the ZSlice form.
+#pragma once
+#include "common.hip.h"
+#include "conv_mfma.hip.h"
+#include "conv_f16.hip.h"
+
+namespace rt {
+
+struct DeconvF16PCfg {
+    static constexpr int TY = 4, TX = 32, CC = 16;
+    static constexpr int PR = TY + 1, PC = TX + 1, PCA = PC + 1;    // patch rows / columns (+1 halo), LDS slots per (row, group)
+    static constexpr int GSLOTS = PR * PC;
+    static constexpr int NKG = (GSLOTS + 255) / 256;
+    static constexpr int IN_SLOTS = PR * 2 * PCA;
+    static constexpr int W_SLOTS = 9 * 2 * 32;
+    static constexpr int NK_W = (W_SLOTS + 255) / 256;
+    static constexpr int BUF_SLOTS = IN_SLOTS + W_SLOTS;
+};
+
+// p.zs: one ZSlice per output depth of the launch's class (phase (0, 0) of that depth: offsets, gather-table row); p.Ho / p.Wo: the
+// FULL output plane (Hx, Wx); p.Hi / p.Wi: the input plane; p.y_ystride = 2 * Wx, p.y_xstride = 2.
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16p_kernel(ConvArgs p) {
+    using Cfg = DeconvF16PCfg;
+    constexpr int PCA = Cfg::PCA, NKG = Cfg::NKG, NK_W = Cfg::NK_W;
+    constexpr unsigned ES = 2;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[2 * Cfg::BUF_SLOTS];
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RT_WG_TILE(p, tile, zi, n)
+    const int tx0 = (tile % p.tiles_x) * Cfg::TX;
+    const int ty0 = (tile / p.tiles_x) * Cfg::TY;
+    const int nblk = blockIdx.y;
+    const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
+    const int nchunks = p.CinPad / Cfg::CC;
+    const ZSlice z = p.zs[zi];
+
+    const int* __restrict__ tab = p.ch_off + (int64_t)z.ch_row * p.CinPad;
+    unsigned voff[NKG];
+    int lidx[NKG];
+#pragma unroll
+    for (int k = 0; k < NKG; k++) {
+        const int s = tid + 256 * k;
+        const int pr = s / Cfg::PC, pc = s - pr * Cfg::PC;
+        const int iy = ty0 + pr, ix = tx0 + pc;
+        const bool own = s < Cfg::GSLOTS;
+        voff[k] = (own && iy < p.Hi && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB;
+        lidx[k] = own ? pr * 2 * PCA + pc : -1;
+    }
+    const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS * 16;
+    const buf_rsrc rs_w = make_buf(wsrc);
+    f32x4 rin[2][NKG], rw[NK_W];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int off = tab[ch * Cfg::CC + 8 * g];            // element offset of the group's slot plane; -1 = zeros (depth tap out of range)
+            const buf_rsrc rs = make_buf(xb, off >= 0);
+#pragma unroll
+            for (int k = 0; k < NKG; k++) rin[g][k] = buf_load4(rs, voff[k], (unsigned)off * ES);
+        }
+        const unsigned so = (unsigned)ch * (unsigned)(Cfg::W_SLOTS * 16);
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + 256 * k;
+            rw[k] = buf_load4(rs_w, idx < Cfg::W_SLOTS ? (unsigned)idx * 16u : kBufOOB, so);
+        }
+    };
+    auto stage = [&](int buf) {
+        f32x4* sIn = smem + buf * Cfg::BUF_SLOTS;
+        f32x4* sW = sIn + Cfg::IN_SLOTS;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int k = 0; k < NKG; k++)
+                if (lidx[k] >= 0) sIn[lidx[k] + g * PCA] = rin[g][k];
+#pragma unroll
+        for (int k = 0; k < NK_W; k++) {
+            const int idx = tid + 256 * k;
+            if (idx < Cfg::W_SLOTS) sW[idx] = rw[k];
+        }
+    };
+
+    f32x16 acc[4];                                 // phase 2 * py + px
+    {
+        const float* bsrc = p.bias + nblk * 32 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bsrc + 8 * q);
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[f][4 * q + e] = bv[e];
+        }
+    }
+    const int a_base = half * 32 + l31;
+    const int b_base = (wv * 2 + half) * PCA + l31;
+    auto compute = [&](int buf) {
+        const f32x4* sIn = smem + buf * Cfg::BUF_SLOTS;
+        const f32x4* sW = sIn + Cfg::IN_SLOTS;
+        f16x8_t b[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) b[dy][dx] = __builtin_bit_cast(f16x8_t, sIn[b_base + dy * 2 * PCA + dx]);
+#pragma unroll
+        for (int ry = 0; ry < 3; ry++)
+#pragma unroll
+            for (int rx = 0; rx < 3; rx++) {
+                // kernel tap r: 1 -> even output from input m; 2 -> odd output from m; 0 -> odd output from m + 1
+                const int py = ry == 1 ? 0 : 1, dy = ry == 0 ? 1 : 0, px = rx == 1 ? 0 : 1, dx = rx == 0 ? 1 : 0;
+                const f16x8_t a = __builtin_bit_cast(f16x8_t, sW[a_base + (ry * 3 + rx) * 64]);
+                acc[2 * py + px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[dy][dx], acc[2 * py + px], 0, 0, 0);
+            }
+    };
+
+    // ---- output addressing.  The two x-phases of a lane are neighbouring pixels, and the two half-waves of a pixel hold its channels 0-3
+    // and 4-7 of a group: one v_permlane32_swap per dword gives the lower half-wave the whole 16-byte slot of pixel 2 mx and the upper one
+    // that of pixel 2 mx + 1, so a wave's store (and its skip-tensor load) covers 64 consecutive slots = 1 KB of whole cache lines instead
+    // of 8-byte pieces every 32 bytes.
+    const bool r_il8 = p.r_il8 != 0, has_r = p.resid != nullptr;
+    const int64_t ybase = (int64_t)n * p.y_bstride + z.y_off_il8;
+    const int64_t rbase = (int64_t)n * p.r_bstride + (r_il8 ? z.r_off_il8 : z.r_off);
+    const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
+    const int my = ty0 + wv, mx = tx0 + l31;
+    const int Wx = p.y_ystride >> 1;
+    const int act = p.act;
+    unsigned slot_off[2];                          // byte offset of this lane's 16-byte slot (pixel 2 mx + half) in output row 2 my + py
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        const int oy = 2 * my + py, ox = 2 * mx + half;
+        const bool inb = my < p.Hi && mx < p.Wi && oy < p.Ho && ox < p.Wo;
+        slot_off[py] = inb ? (unsigned)(my * p.y_ystride + py * Wx + ox) * 16u : kBufOOB;
+    }
+    u32x4_t skip[2][4];                            // interleaved skip tensor: [py][q] = the slot's 8 channels
+    auto load_skip = [&]() {
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cs = nblk * 32 + 8 * q;
+                const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), has_r & r_il8 & (cs < p.Cout));
+                skip[py][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, slot_off[py], (unsigned)(cs * rs32) * ES, 0);
+            }
+    };
+
+    prefetch(0);
+    stage(0);
+    wg_barrier();
+    for (int ch = 0; ch < nchunks; ch++) {
+        const bool more = ch + 1 < nchunks;
+        if (more) prefetch(ch + 1);
+        else load_skip();                          // the skip tensor arrives under the last chunk's MFMAs
+        compute(ch & 1);
+        if (more) stage((ch + 1) & 1);
+        wg_barrier();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------------------------
+    auto h2f = [](unsigned u, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> (16 * hi))); };
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        if (has_r && !r_il8) {                     // planar skip tensor (not what the executor uses): per-element loads at the lane's own pixels
+#pragma unroll
+            for (int px = 0; px < 2; px++) {
+                const int oy = 2 * my + py, ox = 2 * mx + px;
+                const bool inb = my < p.Hi && mx < p.Wi && oy < p.Ho && ox < p.Wo;
+                const unsigned pv = inb ? ((unsigned)(my * p.y_ystride + py * Wx + ox) + (unsigned)(4 * half * rs32)) * ES : kBufOOB;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cs = nblk * 32 + 8 * q;
+                    const buf_rsrc rs = make_buf(elem_ptr(p.resid, rbase, ES), cs < p.Cout);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        acc[2 * py + px][4 * q + e] += Io<_Float16>::load(rs, (cs + 4 * half + e < p.Cout) ? pv : kBufOOB, (unsigned)((cs + e) * rs32) * ES);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cs = nblk * 32 + 8 * q;
+            // the lane's 4 channels (4 half .. 4 half + 3 of the group) of pixel 2 mx (px = 0) and of pixel 2 mx + 1 (px = 1)
+            float v[2][4];
+#pragma unroll
+            for (int px = 0; px < 2; px++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[px][e] = acc[2 * py + px][4 * q + e];
+            if (has_r && r_il8) {
+                // the loaded slot is pixel 2 mx + half, channels 0-7: bring the pieces to the lanes that hold the matching accumulators
+                unsigned s0 = skip[py][q][0], s1 = skip[py][q][1], s2 = skip[py][q][2], s3 = skip[py][q][3];
+                // lower half-wave has pixel 2mx (ch 0-3 in s0,s1; ch 4-7 in s2,s3), upper pixel 2mx+1: swap(lower's ch4-7, upper's ch0-3)
+                const auto w0 = __builtin_amdgcn_permlane32_swap(s0, s2, false, false);   // -> {a: low lanes s0 (px0 ch0-1), high lanes <- low s2? see below
+                const auto w1 = __builtin_amdgcn_permlane32_swap(s1, s3, false, false);
+                // after swap(a = s0, b = s2): a' = [s0 low | s2 low], b' = [s0 high | s2 high]:
+                //   lanes 0-31 (half 0): a' = px0 ch0-1, b' = px1 ch0-1 (came from the upper half-wave's s0)
+                //   lanes 32-63 (half 1): a' = px0 ch4-5 (the lower half-wave's s2), b' = px1 ch4-5
+                const unsigned px0_lo = w0[0], px1_lo = w0[1], px0_hi = w1[0], px1_hi = w1[1];
+                v[0][0] += h2f(px0_lo, 0); v[0][1] += h2f(px0_lo, 1); v[0][2] += h2f(px0_hi, 0); v[0][3] += h2f(px0_hi, 1);
+                v[1][0] += h2f(px1_lo, 0); v[1][1] += h2f(px1_lo, 1); v[1][2] += h2f(px1_hi, 0); v[1][3] += h2f(px1_hi, 1);
+            }
+            unsigned o[2][2];
+#pragma unroll
+            for (int px = 0; px < 2; px++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float x0 = apply_act_fast(v[px][2 * e], act), x1 = apply_act_fast(v[px][2 * e + 1], act);
+                    o[px][e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x0) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)x1) << 16);
+                }
+            // inverse exchange: a = px0 pieces, b = px1 pieces -> lower half-wave: (a', b') = px0's (own ch 0-3, upper's ch 4-7) ...
+            const auto t0 = __builtin_amdgcn_permlane32_swap(o[0][0], o[1][0], false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(o[0][1], o[1][1], false, false);
+            // t0 = {[px0 e0 of half0 | px1 e0 of half0], [px0 e0 of half1 | px1 e0 of half1]}: lanes 0-31 hold pixel 2mx: ch0-1 (t0[0]), ch4-5 (t0[1]);
+            // lanes 32-63 hold pixel 2mx+1: ch0-1 (t0[0]), ch4-5 (t0[1]).  Same for t1 with channels 2-3 / 6-7.
+            const u32x4_t slot = {t0[0], t1[0], t0[1], t1[1]};
+            const buf_rsrc rs = make_buf(elem_ptr(p.y, ybase, ES), cs < p.Cout);
+            __builtin_amdgcn_raw_buffer_store_b128(slot, rs, slot_off[py] + (unsigned)(cs * cs32) * ES, 0u, 0);
+        }
+    }
+}
+
+}  // namespace rt

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@
 #include "kernels/conv_f16.hip.h"
 #include "kernels/conv_f16_first.hip.h"
 #include "kernels/conv_f16r4.hip.h"
+#include "kernels/deconv_f16p.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
 #include "kernels/cost_volume.hip.h"
@@ -522,6 +524,7 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int x_f16 = 0, y_f16 = 0;           // storage type of input / output + residual (half2 mode), set by rt_conv_plan_set_io_types
     int f16mma = 0;                     // conv_f16mma_kernel: fp16 operands on the matrix cores (both tensors fp16)
     int x_il8 = 0, y_il8 = 0, r_il8 = 0; // ... with channel-interleaved (C/8,H,pitch,8) input / output / residual tensors
+    int dp4 = 0;                        // deconv_f16p_kernel: all four output phases of a stride-2 transposed 3x3 window per workgroup (f16mma, interleaved in / out)
     int f16first = 0;                   // conv_f16_first_kernel: 5x5 stride-2 first layer, fp32 image -> fp16 tensor on fp16 operands
     int split3 = 0;                     // conv_s3_kernel: fp32 tensors, 3-term fp16 split on the fp16 matrix pipe (general form)
     int rb = 0;                         // conv_s3rb_kernel: fused residual block (two 3x3 convolutions), rtConvPlan::rb_*
@@ -914,23 +917,28 @@ void launch_s3(dim3 grid, int ks, int64_t per_cu, hipStream_t st, const rt::Conv
     ks = Cfg::max_groups(ks);                                  // per_cu: a sample's workgroups per CU; co-resident ones share 160 KB
     while (ks > 1 && std::min<int64_t>(per_cu, 4) * ks * Cfg::GRP_BYTES > 160 * 1024) ks = Cfg::max_groups(ks - 1);
 #ifndef HIPEMU
-    static const bool once = [] {        // dynamic LDS beyond the default limit
+    // dynamic LDS beyond the default limit: a function attribute is per device (the one-process multi-GPU app), set once each
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !((done.load(std::memory_order_acquire) >> dev) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rt::conv_s3_kernel<KH, KW, S, XIL, YIL, NW, TIN, TOUT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::KS_MAX * Cfg::GRP_BYTES);
-        return true;
-    }();
-    (void)once;
+        done.fetch_or(1ull << dev, std::memory_order_release);
+    }
 #endif
     hipLaunchKernelGGL((rt::conv_s3_kernel<KH, KW, S, XIL, YIL, NW, TIN, TOUT>), grid, dim3(64 * NW * ks), (size_t)ks * Cfg::GRP_BYTES, st, a);
 }
 
+// compute units of the CALLING THREAD's current device (the one-process, one-thread-per-device app runs plans of several devices)
 int device_cus() {
-    static int n = 0;
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
     if (!n) {
         hipDeviceProp_t prop;
-        int dev = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                ? prop.multiProcessorCount : 256;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -1230,6 +1238,7 @@ extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, 
             z.y_off = (int64_t)py * Wo + px;
             z.r_off = z.y_off;
             z.r_off_il8 = 8 * z.y_off;                 // 2-D phases: the offset is a pixel offset
+            z.r_off_il4 = 4 * z.y_off;
             z.tap_mask = 0;
             for (int u = 0; u < ay.K; u++)
                 for (int v = 0; v < ax.K; v++) z.tap_mask |= 1u << (u * sc.KW + v);
@@ -1355,7 +1364,14 @@ namespace {
 // eight 2-byte ones, one MFMA per tap instead of two -- which then also writes interleaved outputs, (D, C/8, H, W, 8) or, with the fused
 // Transform, (C/8, D, H, W, 8) (ZSlice::y_off_il8).  Rebuilds plan->subs from plan->desc3d / in_dims3 / w_canon; storage types and layouts
 // of the old launches are carried over by the caller.
-int build_deconv3d_subs(rtConvPlan* plan, bool f16mma) {
+// dp4 (with f16mma): the four-phases-per-workgroup kernel (deconv_f16p.hip.h) -- 3x3 window, stride 2, pad 1 in H and W, interleaved output.
+bool deconv3d_dp4_ok(const rtConvPlan* plan) {
+    const rtConv3dDesc& d = plan->desc3d;
+    return d.kernel[1] == 3 && d.kernel[2] == 3 && d.stride[1] == 2 && d.pad_start[1] == 1 && d.pad_start[2] == 1 && d.H == 2 * plan->in_dims3[1] - 1 &&
+           d.W == 2 * plan->in_dims3[2] - 1 && d.H >= 2 && d.W >= 2 && d.C % 8 == 0 && d.K % 8 == 0 && env_int("RT_NO_DECONV_P4", 0) == 0;
+}
+
+int build_deconv3d_subs(rtConvPlan* plan, bool f16mma, bool dp4 = false) {
     const rtConv3dDesc* d = &plan->desc3d;
     const std::vector<float>& w = plan->w_canon;
     const int Dlim = d->out_depth > 0 ? d->out_depth : d->D;
@@ -1399,6 +1415,42 @@ int build_deconv3d_subs(rtConvPlan* plan, bool f16mma) {
             if (!sc.split3 || sc.direct) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: no fp16-operand form for this window"); break; }
             sc.split3 = 0; sc.f16mma = 1; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
         }
+        if (f16mma && dp4) {
+            // one workgroup = a 4 x 32 tile of the input grid, all four phases: weights in kernel order (3 x 3 taps), one ZSlice per output depth
+            sc.dp4 = 1; sc.KH = sc.KW = 3; sc.nz = nzd;
+            sc.Ho = Hx; sc.Wo = Wx;                               // the FULL output plane
+            sc.CinPad = rt::round_up(cin_real, sc.CC);
+            if (sc.CinPad > 512) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
+            std::vector<uint16_t> p16;
+            pack_f16_into(p16, sc, cin_real, [&](int co, int ci, int u, int v) {
+                if (az.K == 0) return 0.f;
+                const int j = ci / K, k = ci % K;
+                return w[((((size_t)k * V + az.tap[j]) * C + co) * R + u) * Sk + v];            // KVCRS, kernel taps as they are
+            });
+            std::vector<rt::ZSlice> zs;
+            for (int m = 0; m < nzd; m++) {
+                rt::ZSlice z{};
+                const int64_t dx = cls + m * sd;
+                z.ch_row = m;
+                z.r_off = dx * C * out_plane; z.r_off_il8 = z.r_off; z.r_off_il4 = z.r_off;
+                z.y_off = cdhw ? dx * out_plane : z.r_off;
+                z.y_off_il8 = cdhw ? 8 * dx * out_plane : z.r_off;
+                zs.push_back(z);
+            }
+            std::vector<int> table((size_t)nzd * sc.CinPad, -1);
+            for (int m = 0; m < nzd; m++)
+                for (int j = 0; j < az.K; j++) {
+                    const int dy = m + j - az.pad;
+                    if (dy < 0 || dy >= Dy) continue;
+                    for (int k = 0; k < K; k++) table[(size_t)m * sc.CinPad + j * K + k] = (int)((((int64_t)(k / 8) * Dy + dy) * in_plane) * 8 + k % 8);
+                }
+            if (hipMalloc((void**)&sc.w_dev, p16.size() * 2) != hipSuccess || hipMemcpy(sc.w_dev, p16.data(), p16.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(RT_E_NOMEM, "conv3d_transpose: device allocation failed");
+            if (!rc) rc = upload_zslices(sc, zs);
+            if (!rc) rc = upload_table(sc, table);
+            plan->subs.push_back(sc);
+            continue;
+        }
         sc.CinPad = sc.direct ? cin_real : rt::round_up(cin_real, sc.CC);
         if (sc.CinPad > 512 || !window_supported(sc.KH, sc.KW, 1)) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
         std::vector<float> packed;
@@ -1432,6 +1484,7 @@ int build_deconv3d_subs(rtConvPlan* plan, bool f16mma) {
                     const int64_t pix = (int64_t)py * Wx + px, dx = cls + m * sd;
                     z.r_off = dx * C * out_plane + pix;
                     z.r_off_il8 = dx * C * out_plane + 8 * pix;                                 // (D, C/8, H, W, 8) fp16 skip tensor
+                    z.r_off_il4 = dx * C * out_plane + 4 * pix;                                 // (D, C/4, H, W, 4) fp32 skip tensor
                     z.y_off = cdhw ? dx * out_plane + pix : z.r_off;
                     z.y_off_il8 = cdhw ? 8 * (dx * out_plane + pix) : z.r_off_il8;              // (C/8, D, H, W, 8) / (D, C/8, H, W, 8)
                     z.w_off = w_offs[iph++];
@@ -1492,7 +1545,6 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     plan->x_bstride = (int64_t)K * Dy * Hy * Wy;
     plan->y_bstride = (int64_t)Dlim * C * Hx * Wx;
     const std::vector<float> w = to_f32(weights, (size_t)K * V * C * R * Sk, d->dtype);
-    const int64_t in_plane = (int64_t)Hy * Wy, out_plane = (int64_t)Hx * Wx;
     int rc = 0;
     // Last layer of the 3-D models: one or two output channels, 3x3x3, stride 2 -> 2x2x2-block kernel
     if (C <= 2 && !cdhw && V == 3 && R == 3 && Sk == 3 && sd == 2 && sh == 2 && env_int("RT_NO_DECONV3D_SMALL", 0) == 0) {
@@ -1583,7 +1635,7 @@ extern "C" int rt_conv_plan_set_pitch(rtConvPlan* plan, int in_pitch, int out_pi
         sc.y_cstride = (int64_t)Hout * op;
         sc.y_off = repitch(sc.y_off);
         if (!sc.zs_host.empty()) {
-            for (auto& z : sc.zs_host) { z.y_off = repitch(z.y_off); z.r_off = z.y_off; z.r_off_il8 = 8 * z.y_off; }
+            for (auto& z : sc.zs_host) { z.y_off = repitch(z.y_off); z.r_off = z.y_off; z.r_off_il8 = 8 * z.y_off; z.r_off_il4 = 4 * z.y_off; }
             RT_HIP(hipMemcpy(sc.zs_dev, sc.zs_host.data(), sc.zs_host.size() * sizeof(rt::ZSlice), hipMemcpyHostToDevice));
         }
     }
@@ -1863,16 +1915,26 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
                                    (sc.S == 1 || sc.S == 2) && sc.TY == 4 && plan->c3d_C % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0;
             if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0)) : 0;
             if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out_dm;         // fp32 (feature maps) in, fp16 volume out
+            // fp32 tensors (round 4): the split kernel takes (D, C/4, H, W, 4) on either side -- one 16-byte load per pixel and group of 4
+            // channels instead of four 4-byte ones, 16-byte stores.  Not the folded cost volume's input (no x-shift in the interleaved gather).
+            if (sc.split3 && !sc.x_f16 && !sc.y_f16 && sc.TY == 4 && sc.KH == 3 && sc.KW == 3 && env_int("RT_NO_IL8_3D_F32", 0) == 0) {
+                const int o4 = (plan->c3d_dchw && sc.Cout % 4 == 0) ? 2 : 0;
+                return ((!plan->c3d_fold && plan->c3d_C % 4 == 0) ? 1 : 0) | o4 | ((o4 && plan->has_resid) ? 4 : 0);
+            }
             return 0;
         }
         if (plan->is_deconv3d) {
             if (sc.small3d)      // last layer: (K/8, Dy, Hy, Wy, 8) fp16 in on the matrix cores (deconv3d_s2_il_kernel), fp32 volume out
                 return (sc.small3d == 1 && sc.x_f16 && !sc.y_f16 && sc.s3.K % 32 == 0 && !sc.small_w.empty() && env_int("RT_NO_SMALL_IL", 0) == 0) ? 1 : 0;
+            bool all_f32 = true;
+            for (const SubConv& q : plan->subs) all_f32 = all_f32 && q.split3 && !q.x_f16 && !q.y_f16 && q.TY == 4;
+            if (all_f32)           // fp32 tensors: the skip tensor (D, C/4, H, W, 4) only (ZSlice::r_off_il4); input and output stay planar
+                return (plan->has_resid && plan->c3d_C % 4 == 0 && env_int("RT_NO_IL8_3D_F32", 0) == 0) ? 4 : 0;
             for (const SubConv& q : plan->subs)
                 if (!(q.split3 || q.f16mma) || !q.y_f16 || q.TY != 4) return 0;
             // fp16 in and out: an interleaved INPUT moves the plan to fp16 operands (conv_f16mma_kernel, 2x2 phase windows), which also
             // writes interleaved outputs (bit 3: only then); the skip tensor may be interleaved with either kernel
-            const bool f16mma_ok = sc.x_f16 && sc.KH == 2 && sc.KW == 2 && plan->desc3d.K % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0 &&
+            const bool f16mma_ok = sc.x_f16 && ((sc.KH == 2 && sc.KW == 2) || sc.dp4) && plan->desc3d.K % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0 &&
                                    env_int("RT_NO_DECONV_IL", 0) == 0;
             int caps = (plan->has_resid && plan->c3d_C % 8 == 0) ? 4 : 0;
             if (f16mma_ok) caps |= 1 | (plan->c3d_C % 8 == 0 ? 2 | 8 : 0);
@@ -1895,13 +1957,11 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
     if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
     if (sc.x_f16 || sc.y_f16) return 0;
-    // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three -- but exact-fp32 engines do not
-    // use it that way any more (round 3): with 2+ execution contexts in flight, tools/race_hunt.py saw about one output in 3000
-    // of the exact engine deviate from the others in a tile-sized region (up to 1e-3 on the disparity; 8 of 24 000 outputs), never with
-    // planar tensors (0 of 24 000), never without the Winograd kernel (0 of 12 000), never in the split-fp16 engine, and never with the
-    // kernel alone (tools/race_kernel.py: 80 000 launches per layout mix on 4 streams).  Unexplained; the instantiations stay for the
-    // kernel-level tests behind the development knob RT_WINO_IL8=1 of RT_EXPERIMENTAL builds.
-    if (sc.wino) return (exp_knob("RT_WINO_IL8", 0) != 0 && sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
+    // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three.  (Round 3 took the interleaved
+    // instantiations out of the product after tools/race_hunt.py saw one output in ~3000 of the exact engine deviate beside other contexts;
+    // round 4 located it -- compiler-formed packed fp32 math in the interleaved epilogue beside co-resident fp16-MFMA waves -- and the
+    // library is built without the SLP vectoriser since: profiles/r04_race.txt.  RT_NO_WINO_IL8=1: planar exact engines, for A/B runs.)
+    if (sc.wino) return (env_int("RT_NO_WINO_IL8", 0) == 0 && sc.TY == 4 && plan->cin % 4 == 0 && sc.Cout % 4 == 0) ? 7 : 0;
     // (the direct-form kernel had an interleaved-output form for the first layer and the stride-2 layers behind RT_IL_DIRECT in round 1;
     //  whole networks were wrong with it on the GPU only -- tools/race_hunt.py reproduced that in round 2 even with one stream and one
     //  context -- and the split-fp16 kernels that now serve those layers write interleaved tensors themselves, so the form was removed)
@@ -1957,10 +2017,10 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
             sc.x_il8 = x_il8 != 0;
             return 0;
         }
-        const bool want = x_il8 != 0;
-        if ((plan->subs[0].f16mma != 0) != want) {
+        const bool want = x_il8 != 0, want_dp = want && y_il8 && deconv3d_dp4_ok(plan);
+        if ((plan->subs[0].f16mma != 0) != want || (plan->subs[0].dp4 != 0) != want_dp) {
             const int xf = plan->subs[0].x_f16, yf = plan->subs[0].y_f16;
-            if (int rc = build_deconv3d_subs(plan, want)) return rc;
+            if (int rc = build_deconv3d_subs(plan, want, want_dp)) return rc;
             for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
         }
         for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }
@@ -2113,10 +2173,25 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
         a.r_il8 = sc.r_il8;
         a.batch = batch; a.cin_real = sc.cin_real; a.x_cstride = (int64_t)sc.Hi * a.x_pitch;
+        if (sc.dp4) {          // transposed 3-D convolution, four phases per workgroup (deconv_f16p.hip.h): tiles of the INPUT grid, one z per output depth
+            a.tiles_x = (int)rt::cdiv(sc.Wi, 32);
+            const int tiles = a.tiles_x * (int)rt::cdiv(sc.Hi, 4), nblk = (int)rt::cdiv(sc.Cout, 32);
+            RT_REQUIRE(sc.x_il8 && sc.y_il8 && sc.x_f16 && sc.y_f16, "rt_conv_enqueue: the four-phase transposed kernel takes interleaved fp16 tensors");
+            a.z_inner = plan->opt_zinner != 0 ? 1 : 0;
+            RT_REQUIRE(batch <= 65535 && (int64_t)batch * sc.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
+            dim3 g = a.z_inner ? dim3((unsigned)(tiles * sc.nz), (unsigned)nblk, (unsigned)batch) : dim3((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * sc.nz));
+            if (plan->opt_trace) fprintf(stderr, "[rt] deconv_f16p grid %u x %u x %u\n", g.x, g.y, g.z);
+            hipLaunchKernelGGL(rt::deconv_f16p_kernel, g, dim3(256), 0, S(s), a);
+            RT_LAUNCH_CHECK("deconv_f16p_kernel");
+            continue;
+        }
         const int tiles_y = (int)rt::cdiv(sc.Ho, sc.TY);
         const int64_t gz = (int64_t)batch * sc.nz;
         // split-fp16 / fp16-operand launches of 3-D plans fold the z-slices into grid.x, z fastest (conv_mfma.hip.h: ConvArgs::z_inner)
-        const bool zin = sc.nz > 1 && plan->opt_zinner != 0 && (sc.split3 || sc.f16mma) && (int64_t)rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Ho, sc.TY) * sc.nz < (1ll << 30);
+        // (fp16-operand launches on interleaved tensors only: measured on ResNet-18 3D fp32 the planar split kernel is 3 % SLOWER with z fastest,
+        //  8.56 vs 8.27 ms per pair -- RT_Z_INNER=2 folds those too)
+        const bool zin = sc.nz > 1 && plan->opt_zinner != 0 && (sc.f16mma || (sc.split3 && plan->opt_zinner == 2)) &&
+                         (int64_t)rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Ho, sc.TY) * sc.nz < (1ll << 30);
         a.z_inner = zin ? 1 : 0;
         auto zfold = [&](dim3 g) { return zin ? dim3(g.x * (unsigned)sc.nz, g.y, (unsigned)batch) : g; };
         RT_REQUIRE(zin ? batch <= 65535 : gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
@@ -2327,14 +2402,14 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             else if (sc.NW == 8) {
                 RT_REQUIRE(!(sc.x_il8 || sc.y_il8 || sc.r_il8), "rt_conv_enqueue: interleaved tensors need the 4-wave Winograd tile");
                 hipLaunchKernelGGL((rt::conv_wino_f32_kernel<8>), grid, dim3(512), 0, S(s), a);
-            } else if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, true>), grid, dim3(256), 0, S(s), a);
+            }
+#else
+            else if (sc.NW != 4) return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue: Winograd kernel: 4-wave tile (8 waves: RT_EXPERIMENTAL builds)");
+#endif
+            else if (sc.x_il8 && sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, true>), grid, dim3(256), 0, S(s), a);
             else if (sc.x_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, true, false>), grid, dim3(256), 0, S(s), a);
             else if (sc.y_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, true>), grid, dim3(256), 0, S(s), a);
             else if (sc.r_il8) hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4, float, float, false, false, true>), grid, dim3(256), 0, S(s), a);
-#else
-            else if (sc.NW != 4 || sc.x_il8 || sc.y_il8 || sc.r_il8)
-                return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue: Winograd kernel: planar tensors, 4-wave tile (other forms: RT_EXPERIMENTAL builds)");
-#endif
             else hipLaunchKernelGGL((rt::conv_wino_f32_kernel<4>), grid, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("conv_wino_f32_kernel");
             continue;
@@ -2362,6 +2437,7 @@ struct rtComm {
     void* nccl = nullptr;      // ncclComm_t
     bool owned = false;
     int world = 1, rank = 0, device = 0;
+    void* fabric = nullptr;    // emulator build: the in-process stand-in for RCCL that the communicators of one rt_comm_init_all share
 };
 
 #ifndef HIPEMU
@@ -2513,7 +2589,21 @@ extern "C" int rt_comm_destroy(rtComm* comm) {
     return rc;
 }
 #else
-// SIMT-emulator build (CPU test tier): a world of one rank, so that the host-side flow (rt_net_create_broadcast) runs without RCCL
+// SIMT-emulator build (CPU test tier): no RCCL.  rt_comm_init_rank serves a world of one rank; rt_comm_init_all -- the one-process,
+// one-thread-per-device model of apps/stereo_throughput.cpp (ncclCommInitAll) -- returns communicators that share an in-process
+// "fabric": rt_comm_broadcast then really is a collective (the root's bytes reach every rank, every rank must call it, the call returns
+// when all have), so the threading of the native multi-GPU start-up can be exercised without a GPU (tests/test_multi_gpu.py).
+#include <condition_variable>
+namespace {
+struct EmuFabric {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 1, arrived = 0, refs = 0;
+    unsigned long long gen = 0;
+    bool ready = false;
+    std::vector<char> data;
+};
+}  // namespace
 extern "C" int rt_comm_unique_id(void* id_bytes) {
     RT_REQUIRE(id_bytes, "rt_comm_unique_id: null pointer");
     std::memset(id_bytes, 0x5a, RT_COMM_ID_BYTES);
@@ -2526,19 +2616,52 @@ extern "C" int rt_comm_init_rank(rtComm** comm, int world, int rank, const void*
     return 0;
 }
 extern "C" int rt_comm_init_all(rtComm** comms, int ndev, const int*) {
-    RT_REQUIRE(comms && ndev == 1, "rt_comm_init_all: the emulator build has no RCCL (one device only)");
-    comms[0] = new rtComm();
-    comms[0]->owned = true;
+    RT_REQUIRE(comms && ndev >= 1 && ndev <= 64, "rt_comm_init_all: bad arguments");
+    EmuFabric* fab = ndev > 1 ? new EmuFabric() : nullptr;
+    if (fab) { fab->world = ndev; fab->refs = ndev; }
+    for (int i = 0; i < ndev; i++) {
+        comms[i] = new rtComm();
+        comms[i]->owned = true; comms[i]->world = ndev; comms[i]->rank = i; comms[i]->fabric = fab;
+    }
     return 0;
 }
 extern "C" int rt_comm_adopt(rtComm**, void*) { return fail(RT_E_UNSUPPORTED, "rt_comm_adopt: the emulator build has no RCCL"); }
 extern "C" int rt_comm_broadcast(rtComm* comm, void* host_buf, size_t bytes, int root, rtStream) {
-    RT_REQUIRE(comm && (host_buf || !bytes) && root == 0, "rt_comm_broadcast: bad arguments");
-    return 0;
+    RT_REQUIRE(comm && (host_buf || !bytes) && root >= 0 && root < comm->world, "rt_comm_broadcast: bad arguments");
+    auto* fab = static_cast<EmuFabric*>(comm->fabric);
+    if (!fab || !bytes) return 0;
+    std::unique_lock<std::mutex> lk(fab->m);
+    const unsigned long long gen = fab->gen;
+    int rc = 0;
+    if (comm->rank == root) {
+        fab->data.assign(static_cast<const char*>(host_buf), static_cast<const char*>(host_buf) + bytes);
+        fab->ready = true;
+        fab->cv.notify_all();
+    } else {
+        fab->cv.wait(lk, [&] { return fab->ready && fab->gen == gen; });
+        if (fab->data.size() != bytes) rc = fail(RT_E_BADARG, "rt_comm_broadcast: rank %d expects %zu bytes, the root sent %zu", comm->rank, bytes, fab->data.size());
+        else std::memcpy(host_buf, fab->data.data(), bytes);
+    }
+    if (++fab->arrived == fab->world) {                      // the last rank to arrive releases everybody (and the buffer)
+        fab->arrived = 0; fab->ready = false; fab->gen++;
+        fab->cv.notify_all();
+    } else {
+        fab->cv.wait(lk, [&] { return fab->gen != gen; });
+    }
+    return rc;
 }
 extern "C" int rt_comm_group_start(void) { return 0; }
 extern "C" int rt_comm_group_end(void) { return 0; }
-extern "C" int rt_comm_destroy(rtComm* comm) { delete comm; return 0; }
+extern "C" int rt_comm_destroy(rtComm* comm) {
+    if (comm && comm->fabric) {
+        auto* fab = static_cast<EmuFabric*>(comm->fabric);
+        bool last;
+        { std::lock_guard<std::mutex> lk(fab->m); last = --fab->refs == 0; }
+        if (last) delete fab;
+    }
+    delete comm;
+    return 0;
+}
 #endif
 
 extern "C" int rt_comm_info(const rtComm* comm, int* world, int* rank) {

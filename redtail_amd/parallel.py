@@ -22,24 +22,32 @@ def shard(n_items, rank, world):
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def native_comm(lib, rank, world, dist=None):
-    """An RCCL communicator of our own through the C ABI (include/rt_stereo.h: rt_comm_unique_id / rt_comm_init_rank) -- what a host
-    without torch does.  The 128-byte unique id travels from rank 0 to the others through `dist` (any initialised torch.distributed
-    backend; its store, not a data path).  Call after rt_set_device."""
+def exchange_unique_id(lib, rank, world, dist=None):
+    """The 128-byte RCCL unique id of a communicator of our own: rank 0 makes it (rt_comm_unique_id), the others receive it through `dist`
+    (any initialised torch.distributed backend; its store, not a data path).  A collective on `dist`'s process group: call it on the
+    thread that owns that group (not from a watchdog thread that may be abandoned while the main thread uses the group)."""
     uid = [lib.comm_unique_id() if rank == 0 else None]
     if world > 1:
         kw = {}
-        if dist.get_backend() == "nccl":        # the pickled id travels as a tensor on THIS thread's current device (bench.py calls from a worker thread)
+        if dist.get_backend() == "nccl":        # the pickled id travels as a tensor on this thread's current device
             kw["device"] = torch.device("cuda", torch.cuda.current_device())
         dist.broadcast_object_list(uid, src=0, **kw)
-    return lib.comm_init_rank(world, rank, uid[0])
+    return uid[0]
 
 
-def create_nets_native(lib, model, width, height, n_contexts, blob, rank, world, dist=None, max_batch=1, fp16_weights=False, max_disp=0):
+def native_comm(lib, rank, world, dist=None, uid=None):
+    """An RCCL communicator of our own through the C ABI (include/rt_stereo.h: rt_comm_unique_id / rt_comm_init_rank) -- what a host
+    without torch does.  `uid`: the id from exchange_unique_id (otherwise exchanged here).  Call after rt_set_device."""
+    if uid is None:
+        uid = exchange_unique_id(lib, rank, world, dist)
+    return lib.comm_init_rank(world, rank, uid)
+
+
+def create_nets_native(lib, model, width, height, n_contexts, blob, rank, world, dist=None, max_batch=1, fp16_weights=False, max_disp=0, uid=None):
     """bench.py's multi-GPU start-up on the native entry: rank 0 passes the weight-file image, rt_net_create_broadcast ships it over
     RCCL (ncclBroadcast) and builds the first engine of every rank; the rank's other contexts are built from the image that arrived.
     Returns (nets, crc32 of the image on this rank)."""
-    comm = native_comm(lib, rank, world, dist)
+    comm = native_comm(lib, rank, world, dist, uid)
     try:
         first = lib.create_broadcast(model, width, height, comm, 0, max_batch=max_batch, blob=blob if rank == 0 else None,
                                      fp16_weights=fp16_weights, max_disp=max_disp)

@@ -97,6 +97,19 @@ static inline float __shfl_up(float v, unsigned d, int width = 64) {
 static inline int __shfl(int v, int src, int width = 64) {
     float f; std::memcpy(&f, &v, 4); f = hipemu::shfl(f, src, width); std::memcpy(&v, &f, 4); return v;
 }
+// v_permlane32_swap (gfx950): lanes 32..63 of `a` are exchanged with lanes 0..31 of `b`; returns {a', b'}
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2 hipemu_permlane32_swap(unsigned a, unsigned b) {
+    const int l = hipemu::lane_id();
+    float fa, fb;
+    std::memcpy(&fa, &a, 4); std::memcpy(&fb, &b, 4);
+    const float b_from_low = hipemu::shfl(fb, l & 31, 64);       // upper lanes of a' take b's lower half
+    const float a_from_high = hipemu::shfl(fa, 32 + (l & 31), 64);   // lower lanes of b' take a's upper half
+    unsigned ub, ua;
+    std::memcpy(&ub, &b_from_low, 4); std::memcpy(&ua, &a_from_high, 4);
+    return hipemu_u32x2{l < 32 ? a : ub, l < 32 ? ua : b};
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu_permlane32_swap(a, b)
 static inline unsigned long long __ballot(int p) { return hipemu::ballot(p); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }

@@ -70,11 +70,15 @@ DECONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("p4", [1, 0])
 @pytest.mark.parametrize("r_il", [1, 0])
 @pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw", DECONV_CASES)
-def test_conv3d_transpose_f16_interleaved(backend, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw, r_il):
+def test_conv3d_transpose_f16_interleaved(backend, monkeypatch, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw, r_il, p4):
+    """p4 = 1: interleaved in AND out runs on deconv_f16p_kernel (all four output phases per workgroup); 0: the ZSlice form, one phase per
+    workgroup (what interleaved-in / planar-out always uses)"""
     if r_il and not skip:
         pytest.skip("no residual")
+    monkeypatch.setenv("RT_NO_DECONV_P4", "0" if p4 else "1")
     n = 2
     dy, hy, wy = ydims
     hx, wx = 2 * hy - 1, 2 * wy - 1

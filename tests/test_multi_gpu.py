@@ -94,6 +94,52 @@ def test_native_broadcast_entry_world_of_one_on_emulator():
         lib.comm_init_rank(2, 0, b"\0" * 128)            # the emulator build refuses a world it cannot serve
 
 
+def test_native_broadcast_entry_two_threads_on_emulator():
+    """The threading model of apps/stereo_throughput.cpp -- one process, one thread per device, rt_comm_init_all (ncclCommInitAll), every
+    thread calls rt_net_create_broadcast on its own communicator -- on the emulator build, whose rt_comm_init_all returns communicators
+    joined by an in-process stand-in for RCCL (a real collective: every rank must call, the root's bytes reach all).  Two ranks: rank 1
+    passes no image and receives rank 0's; both engines hold the same bytes (crc32), answer like the oracle, and a rank that skips the
+    collective would hang -- so the test also bounds the time."""
+    import threading
+    import zlib
+    from oracle import stereo_oracle as O
+    from redtail_amd import build, capi, synth
+    lib = capi.NetLib(build.build_host_emu(), build.build_emu())
+    weights = synth.synth_weights_resnet18_2d()
+    blob = capi.pack_weights(weights)
+    comms = lib.comm_init_all(2)
+    nets, errors = [None, None], []
+
+    def rank_main(rank):
+        try:
+            nets[rank] = lib.create_broadcast("resnet18_2D", 33, 17, comms[rank], 0, blob=blob if rank == 0 else None, max_disp=6)
+        except Exception as e:                     # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, e))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in (1, 0)]      # the receiving rank first
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "the broadcast start-up did not finish: a rank is stuck in the collective"
+    assert not errors, errors
+    crc = zlib.crc32(blob) & 0xffffffff
+    assert nets[0].weights_crc32() == crc and nets[1].weights_crc32() == crc
+    assert nets[1].weights_image() == blob
+    l, r = synth.synth_pair(17, 33, 7)
+    outs = []
+    for net in nets:                               # (the emulator runs one kernel at a time: the passes are sequential)
+        o = np.full((1, 1, 17, 33), np.nan, np.float32)
+        net.execute(l[None].copy(), r[None].copy(), o, 1)
+        outs.append(o)
+        net.destroy()
+    for c in comms:
+        lib.comm_destroy(c)
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l)[None], torch.from_numpy(r)[None], weights, max_disp=6).numpy()
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0] - ref).max() <= 1e-3
+
+
 # ---- GPU tier: the same code over RCCL (torch.distributed backend "nccl") ------------------------------------------------
 def _native_worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -16,7 +16,6 @@ def _winograd_only(monkeypatch):
     """these tests are about the fp32 Winograd / direct-form kernels: keep small layers off the split-fp16 kernel
     (tests/test_split_parity.py covers that one)"""
     monkeypatch.setenv("RT_NO_S3", "1")
-    monkeypatch.setenv("RT_WINO_IL8", "1")       # the interleaved instantiations are off in engines since round 3 (rt_capi.hip: rt_conv_plan_supports_il8)
 
 
 WINO_CASES = [
@@ -117,8 +116,6 @@ IL_CASES = [
 def test_wino_interleaved(backend, cin, cout, h, w, act, resid, batch, pitch, x_il, y_il, r_il):
     """fp32 Winograd kernel on channel-interleaved (C/4, H, pitch, 4) tensors, every mix with planar ones; results
     must equal the planar form bit for bit (same operands, same order of operations)"""
-    if not backend.klib.has_experimental():
-        pytest.skip("the interleaved Winograd instantiations are compiled with RT_EXPERIMENTAL only (the emulator build of the CPU tier)")
     if r_il and not resid:
         pytest.skip("no residual")
     from test_pitch_parity import pitched
@@ -170,8 +167,6 @@ def _il_fuzz_cases(n=20, seed=424242):
 def test_wino_interleaved_fuzz(backend, cin, cout, h, w, resid, x_il, y_il, r_il, act, batch, align):
     """seeded random shapes (single pixels and rows, widths below a tile, channel counts that are multiples of 4 only),
     layout mixes, epilogues and row pitches for the fp32 Winograd kernel on channel-interleaved tensors"""
-    if not backend.klib.has_experimental():
-        pytest.skip("the interleaved Winograd instantiations are compiled with RT_EXPERIMENTAL only (the emulator build of the CPU tier)")
     from test_pitch_parity import pitched
     x, wt, b = rnd(batch, cin, h, w), rnd(cout, cin, 3, 3) * np.float32(1 / np.sqrt(cin * 9)), rnd(cout)
     res = rnd(batch, cout, h, w) if resid else None

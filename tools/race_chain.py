@@ -6,7 +6,6 @@ What tools/race_kernel.py cannot see: a consumer that reads its input before the
 import os
 import sys
 os.environ.setdefault("RT_DEV_KNOBS", "1")
-os.environ.setdefault("RT_WINO_IL8", "1")
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -5,7 +5,6 @@ nondeterminism (tools/race_hunt.py) down to a kernel.   python tools/race_kernel
 import os
 import sys
 os.environ.setdefault("RT_DEV_KNOBS", "1")
-os.environ.setdefault("RT_WINO_IL8", "1")     # the interleaved Winograd instantiations are off in engines since round 3
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

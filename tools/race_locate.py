@@ -8,6 +8,7 @@ differing elements are described (how many, where in the tensor, how large, what
     python tools/race_locate.py <passes> <contexts> [exact|split] [streams]
       RT_VARIANT_DIR=<dir>   another build of the two libraries (librt_stereo_hip.so + libnvstereo_inference.so side by side)
       RACE_NO_TRACE=1        trace off: only the disparity maps are compared (does the trace's own launches change the rate?)
+      RACE_NEIGHBOURS=split  contexts 1.. run the DEFAULT (split-fp16) engine instead of the observed one: which co-runners does it take?
 """
 import json
 import os
@@ -91,7 +92,8 @@ def main():
     l, r = synth.synth_pair(H, W, 1234)
     L, R = torch.from_numpy(l)[None].cuda(), torch.from_numpy(r)[None].cuda()
     flags = capi.RT_CONV_EXACT_FP32 if mode == "exact" else 0
-    nets = [lib.create("resnet18_2D", W, H, weights_path=path, flags=flags) for _ in range(nctx)]
+    nb = os.environ.get("RACE_NEIGHBOURS", "same")
+    nets = [lib.create("resnet18_2D", W, H, weights_path=path, flags=flags if (c == 0 or nb == "same") else 0) for c in range(nctx)]
     trace = os.environ.get("RACE_NO_TRACE", "0") == "0"
     for n in nets:
         n.set_streams(streams)
@@ -117,8 +119,11 @@ def main():
         traces = [net.read_launch_trace() for net in nets]
         if ref is None:
             ref = traces[0]
+            ref_nb = traces[1] if nctx > 1 else None
+        if nb != "same":                        # only context 0 is the observed engine; the neighbours are compared among themselves
+            stats["neighbour_deviations"] = stats.get("neighbour_deviations", 0) + sum(1 for c in range(1, nctx) if traces[c] != ref_nb)
         good = [c for c in range(nctx) if traces[c] == ref]
-        for c in range(nctx):
+        for c in range(nctx if nb == "same" else 1):
             stats["outputs"] += 1
             if traces[c] == ref:
                 continue
