@@ -278,3 +278,87 @@ def test_conv3d_four_rows_per_wave_on_folded_cost_volume(backend, monkeypatch, f
     tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
     assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
     assert np.abs(outs[1] - ref).max() <= tol
+
+
+# ---- fp32 engines (config C4): the 3-D tensors between Conv3D launches in groups of FOUR channels, (D, C/4, H, W, 4) --------------------
+def il4_dm(a):
+    n, d, c, h, w = a.shape
+    return np.ascontiguousarray(a.reshape(n, d, c // 4, 4, h, w).transpose(0, 1, 2, 4, 5, 3))
+
+
+def un_il4_dm(a):
+    n, d, g, h, w, _ = a.shape
+    return a.transpose(0, 1, 2, 5, 3, 4).reshape(n, d, g * 4, h, w)
+
+
+def dev32(backend, a):
+    a = np.ascontiguousarray(a.astype(np.float32))
+    return torch.from_numpy(a).cuda() if backend.name == "gpu" else a
+
+
+@pytest.mark.parametrize("c,k,d,h,w,stride,resid", [(16, 32, 3, 9, 35, 1, True), (8, 12, 5, 6, 37, 1, False), (32, 64, 4, 7, 33, 2, False),
+                                                       (4, 32, 2, 5, 70, 1, True)])
+def test_conv3d_fp32_on_interleaved_tensors(backend, c, k, d, h, w, stride, resid):
+    """Conv3D of an fp32 engine (split-fp16 arithmetic) with any of input / output / skip tensor as (D, C/4, H, W, 4): the same arithmetic
+    in the same order as on planar tensors, so the results must be the SAME BITS; and near the oracle as the planar form is"""
+    n = 2
+    x = rnd(n, d, c, h, w)
+    wt, b = rnd(k, 3, c, 3, 3) * np.float32(1 / np.sqrt(27 * c)), rnd(k)
+    even = stride == 2 and d % 2 == 0
+    pads = (0, 1, 1) if even else (1, 1, 1)
+    xin = O.pad_d(T(x).double(), 1) if even else T(x).double()
+    ref = O.transform(O.conv3d_tf(xin, T(wt).double(), T(b).double(), (stride,) * 3, pads, pads))           # (N, Do, K, Ho, Wo)
+    res = rnd(*ref.shape) if resid else None
+    if resid:
+        ref = ref + T(res).double()
+    ref = O.elu(ref).numpy()
+    plan = backend.klib.conv3d_plan(wt, b, c, k, (d + (1 if even else 0), h, w), (3, 3, 3), (stride,) * 3, pads, pads, act=capi.RT_ACT_ELU,
+                                    out_dchw=True, has_residual=resid, in_pad_end=1 if even else 0)
+    caps = plan.il_caps()
+    assert caps & 1 and caps & 2 and bool(caps & 4) == resid, caps
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, x), out, dev32(backend, res) if resid else None, n)
+    planar = host(backend, out)
+    assert np.abs(planar - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    for xi, yi, ri in [(1, 0, 0), (0, 1, 0), (1, 1, 0)] + ([(0, 1, 1), (1, 1, 1)] if resid else []):
+        plan.set_layouts(xi, yi, ri)
+        out = empty(backend, il4_dm(ref).shape if yi else ref.shape, False)
+        plan.enqueue(dev32(backend, il4_dm(x) if xi else x), out, dev32(backend, il4_dm(res) if ri else res) if resid else None, n)
+        got = host(backend, out)
+        assert not np.isnan(got).any(), (xi, yi, ri)
+        assert np.array_equal(un_il4_dm(got) if yi else got, planar), (xi, yi, ri)
+    plan.destroy()
+
+
+def test_conv3d_fp32_folded_cost_volume_keeps_its_planar_input(backend):
+    """the first Conv3D of an fp32 3-D engine reads the two feature maps through the x-shift table: interleaved OUTPUT only"""
+    f, k, h, w, D = 8, 16, 9, 37, 4
+    plan = backend.klib.conv3d_plan(rnd(k, 3, 2 * f, 3, 3), rnd(k), 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1),
+                                    act=capi.RT_ACT_ELU, out_dchw=True, cv_fold=f)
+    assert plan.il_caps() & 3 == 2
+    with pytest.raises(capi.RtError):
+        plan.set_layouts(1, 1, 0)
+    plan.destroy()
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d", [(16, 8, (3, 4, 19), 7, 6, 0), (8, 16, (3, 5, 9), 5, 5, 1)])
+def test_conv3d_transpose_fp32_reads_an_interleaved_skip_tensor(backend, K, C, ydims, dfull, dkeep, pad_d):
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y, w, b = rnd(n, K, dy, hy, wy), rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)), rnd(C)
+    sk = rnd(n, dkeep, C, hx, wx)
+    ps = (pad_d, 1, 1)
+    plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=False,
+                                    has_residual=True, transposed_in_dims=ydims, out_depth=dkeep)
+    assert plan.il_caps() == 4
+    out = empty(backend, (n, dkeep, C, hx, wx), False)
+    plan.enqueue(dev32(backend, y), out, dev32(backend, sk), n)
+    planar = host(backend, out)
+    ref = O.elu(O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep] + T(sk).double()).numpy()
+    assert np.abs(planar - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    plan.set_layouts(0, 0, 1)
+    out = empty(backend, (n, dkeep, C, hx, wx), False)
+    plan.enqueue(dev32(backend, y), out, dev32(backend, il4_dm(sk)), n)
+    assert np.array_equal(host(backend, out), planar)
+    plan.destroy()

@@ -258,6 +258,19 @@ def test_nvtiny_unfused_equals_fused(rt, monkeypatch):
     assert np.abs(fused - unfused).max() <= 1e-4
 
 
+@pytest.mark.parametrize("model,cfg,disp", [("nvtiny", "NVTINY_3D", 8), ("nvsmall", "NVSMALL_3D", 8)])
+def test_3d_fp32_interleaved_equals_planar(rt, monkeypatch, model, cfg, disp):
+    """fp32 engines keep the 3-D tensors between Conv3D launches (and the decoder's skip tensors) as (D, C/4, H, W, 4): the same arithmetic
+    in the same order as on planar tensors, hence the same bits"""
+    w = O.synth_weights_3d(getattr(O, cfg))
+    l, r = pairs(1, 17, 33) if rt.kind == "emu" else pairs(2, 33, 65)
+    il, _ = run_net(rt, model, w, l, r, max_disp=disp)
+    monkeypatch.setenv("RT_NO_IL8_3D_F32", "1")
+    planar, _ = run_net(rt, model, w, l, r, max_disp=disp)
+    assert not np.isnan(il).any()
+    assert np.array_equal(il, planar)
+
+
 def test_resnet18_2d_half2_mode(rt, monkeypatch):
     """fp16 weight file = half2 mode (sample_app/main.cpp:256-262): activations between the fused launches are stored
     as fp16, arithmetic stays fp32.  Error against the fp32 oracle with the same (fp16-rounded) weights must stay inside
