@@ -116,6 +116,11 @@ int rt_corr_softargmax_pitched(const void* left, const void* right, void* out, i
  * internal layout between 3x3 convolutions -- computed on the matrix cores (C a multiple of 4 up to 32, D <= 64). */
 int rt_corr_softargmax_il(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
                           int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream stream);
+/* ... with the map written as lane 0 of the 16-byte pixel slots of a channel-interleaved group, (H, out_pitch, 4) with zeros in
+ * lanes 1..3 (out_slot = 4; 1 = the plane above): the disparity channel of conv2D_1's 33-channel input when the executor keeps
+ * that concatenation interleaved (sample_app/resnet18_2D_513x257_net.cpp:601-615). */
+int rt_corr_softargmax_il_slot(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
+                               int is_min, int in_pitch, int out_pitch, int64_t out_bstride, int out_slot, rtStream stream);
 
 /* ---- layout glue of the 3-D models ------------------------------------------------------- */
 /* 4-D permute of a (N, d0,d1,d2,d3) tensor: out dim i = in dim order[i].  Replaces
@@ -216,7 +221,9 @@ int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
  * cache lines with a quarter of the memory instructions; the executor
  * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic (and, as output, the first layer)
  * touch.  rt_conv_plan_supports_il8: which tensors of the plan may be interleaved (bit 0 input, bit 1 output, bit 2
- * residual; call it after rt_conv_plan_set_io_types); rt_conv_plan_set_layouts: layout (0 planar, 1 interleaved) of
+ * residual, bit 3: an interleaved output only together with an interleaved input, bit 4: an interleaved input whose channel
+ * count is padded up to a whole group -- the pad channels must hold finite values; call it after
+ * rt_conv_plan_set_io_types); rt_conv_plan_set_layouts: layout (0 planar, 1 interleaved) of
  * the input, the output and the residual tensor. */
 int rt_conv_plan_supports_il8(const rtConvPlan* plan);
 int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8);

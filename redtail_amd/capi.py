@@ -69,6 +69,7 @@ KERNEL_SYMBOLS = {
     "rt_corr_softargmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int64, c_int, c_void_p]),
     "rt_corr_softargmax_pitched": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_corr_softargmax_il": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_void_p]),
+    "rt_corr_softargmax_il_slot": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
     "rt_convert_format": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
@@ -191,9 +192,10 @@ class KernelLib:
                                                        in_pitch, out_pitch, out_bstride, dtype, stream),
                    "rt_corr_softargmax_pitched")
 
-    def corr_softargmax_il(self, l, r, out, batch, C, H, W, D, is_min, in_pitch=0, out_pitch=0, out_bstride=0, stream=None):
-        self.check(self.lib.rt_corr_softargmax_il(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min), in_pitch, out_pitch,
-                                                  out_bstride, stream), "rt_corr_softargmax_il")
+    def corr_softargmax_il(self, l, r, out, batch, C, H, W, D, is_min, in_pitch=0, out_pitch=0, out_bstride=0, stream=None, out_slot=1):
+        """out_slot = 4: the map as lane 0 of the 16-byte slots of an interleaved group, (H, out_pitch, 4), zeros in lanes 1..3"""
+        self.check(self.lib.rt_corr_softargmax_il_slot(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min), in_pitch, out_pitch,
+                                                       out_bstride, out_slot, stream), "rt_corr_softargmax_il_slot")
 
     def cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, stream=None):
         self.check(self.lib.rt_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, stream),
@@ -277,6 +279,10 @@ class ConvPlan:
     def set_pitch(self, in_pitch, out_pitch):
         self.klib.check(self.klib.lib.rt_conv_plan_set_pitch(self.handle, in_pitch, out_pitch), "rt_conv_plan_set_pitch")
 
+    def set_batch_strides(self, x_bstride, y_bstride, r_bstride=0):
+        """per-sample strides in elements of input / output / residual (0 = leave as it is)"""
+        self.klib.check(self.klib.lib.rt_conv_plan_set_batch_strides(self.handle, x_bstride, y_bstride, r_bstride), "rt_conv_plan_set_batch_strides")
+
     def set_io_types(self, x_dtype, y_dtype):
         self.klib.check(self.klib.lib.rt_conv_plan_set_io_types(self.handle, x_dtype, y_dtype), "rt_conv_plan_set_io_types")
 
@@ -290,7 +296,8 @@ class ConvPlan:
         return bool(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
 
     def il_caps(self):
-        """which tensors may be channel-interleaved: bit 0 input, bit 1 output, bit 2 residual"""
+        """which tensors may be channel-interleaved: bit 0 input, bit 1 output, bit 2 residual, bit 3 output only with an interleaved input,
+        bit 4 input with its channel count padded to a whole group"""
         return int(self.klib.lib.rt_conv_plan_supports_il8(self.handle))
 
     def set_layouts(self, x_il8, y_il8, r_il8=False):

@@ -68,7 +68,9 @@ struct TensorImpl : public ITensor {
     int stream = 0;             // which of the two execution streams produces it
     int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
     bool f16 = false;           // stored as fp16 (half2 mode); only tensors that only layout-aware launches touch
-    bool il8 = false;           // fp16 and channel-interleaved, (C/8, H, pitch, 8): only fp16-arithmetic 3x3 plans touch it
+    bool il8 = false;           // channel-interleaved, (C/8, H, pitch, 8) in fp16, (C/4, H, pitch, 4) in fp32: only layout-aware launches touch it
+    int cpad = 0;               // channels ALLOCATED per sample when > dims.d[0]: an interleaved tensor that hosts a folded concatenation
+                                // (its own channels, then the other members' groups); the sample stride of everything that touches it
     // siamese towers (mergeSiamese): this right-tower tensor lives in the second half of its left-tower twin's buffer -- `batch`
     // samples after the twin's first sample, so that one launch over 2 * batch samples serves both towers
     int twin_of = -1;
@@ -322,6 +324,7 @@ struct Op {
     IStereoPlugin* splugin = nullptr;  // kConv3D
     int max_disp = 0, is_min = 0;      // kCorrSoftargmax
     bool il_in = false;                // kCorrSoftargmax: channel-interleaved feature maps -> matrix-core kernel
+    bool il_out = false;               // kCorrSoftargmax: the map is lane 0 of an interleaved group (member of an interleaved concatenation)
     int half_kind = 0;                 // kPlugin created for kHALF: 1 = fp16 NCHW, 2 = fp16 NC2HW2 (tensors are converted around it)
     int stream = 0;
     std::vector<int> wait_on;          // tensors produced on the other stream that this op consumes
@@ -442,11 +445,19 @@ public:
     std::vector<size_t> issue_sync_;   // op indices in the issue order of execute() (two streams alternating); empty = ops_ order
     ILogger& log_;
 
+    // elements of one sample as the tensor lies in memory (row pitch, channels padded for a hosted concatenation)
+    static int64_t sampleElems(const TensorImpl& t) {
+        if (t.dims.nbDims != 3) return (int64_t)volume(t.dims);
+        return (int64_t)(t.cpad ? t.cpad : t.dims.d[0]) * t.dims.d[1] * (t.pitch ? t.pitch : t.dims.d[2]);
+    }
+
 private:
     int root(int t) const {
         while (tensors_[t]->alias_of >= 0) t = tensors_[t]->alias_of;
         return t;
     }
+    bool concatFoldable(size_t ci) const;
+    void applySampleStrides();
     int consumers(int t) const {
         int n = 0;
         for (auto& l : layers_)
@@ -524,6 +535,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
             auto it = std::find(half_plugins_.begin(), half_plugins_.end(), op.plugin);
             if (it != half_plugins_.end()) op.half_kind = half_kinds_[it - half_plugins_.begin()];
         }
+    if (ok_) assignStreams();           // preliminary: assignPitch asks whether a concatenation will fold (same-stream producers)
     if (ok_) assignPitch();
     if (ok_) fuseResBlocks();           // after the layouts are known: the streaming kernel serves interleaved tensors
     if (ok_) assignStreams();           // preliminary: foldConcats wants to know which stream an op is on
@@ -532,6 +544,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) assignHalf3D();
     if (ok_) assignInterleaved3D();
     if (ok_) mergeSiamese();
+    if (ok_) applySampleStrides();
     if (ok_) assignStreams();           // final: the passes above removed and merged ops (waits and publish flags are recomputed)
     if (ok_) planIssueOrder();
 }
@@ -866,21 +879,64 @@ void EngineImpl::assignPitch() {
     // cache lines with a quarter of the memory instructions (conv_wino.hip.h, conv_f16.hip.h).  A plan takes any mix
     // of planar and interleaved tensors, so the layout is a per-tensor property and nothing is converted anywhere.
     std::vector<char> il(tensors_.size(), 0);
-    for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 == f16 && t->dims.d[0] % (f16 ? 8 : 4) == 0;
     auto corr_takes_il = [&](const Op& op) {        // fused correlation + soft-argmax on the matrix cores (corr_mfma.hip.h)
         const Dims& f = tensors_[op.in[0]]->dims;
         return op.kind == OpKind::kCorrSoftargmax && !f16 && f.d[0] % 4 == 0 && f.d[0] <= 32 && op.max_disp <= 64 &&
                !knob("RT_NO_CORR_MFMA") && !knob("RT_NO_IL8");
     };
-    for (auto& op : ops_) {
-        int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual
-        if (corr_takes_il(op)) caps = 1;
-        if (!(caps & 1)) for (int i : op.in) il[root(i)] = 0;
+    // A concatenation that foldConcats() will fold can stay interleaved (fp32): every member but the last holds whole groups of 4
+    // channels, the last one is padded to a group -- the 33-channel input of conv2D_1 is the 8 groups of left_conv1_act and a ninth
+    // with the soft-argmax map in lane 0 (resnet18_2D_513x257_net.cpp:601-615).  The first member then serves the left tower's first
+    // residual block in the layout the streaming kernel wants, and that block merges with the right tower's (round 3: two extra launches).
+    std::vector<char> catpad(tensors_.size(), 0), cat_il(ops_.size(), 0);
+    for (size_t ci = 0; ci < ops_.size(); ci++) {
+        const Op& op = ops_[ci];
+        if (op.kind != OpKind::kConcat || f16 || knob("RT_NO_IL8") || knob("RT_NO_IL_CONCAT") || !concatFoldable(ci)) continue;
+        bool cand = ok[op.out] != 0;
+        for (size_t k = 0; k < op.in.size(); k++) {
+            const TensorImpl& t = *tensors_[op.in[k]];
+            cand = cand && ok[t.id] && (t.dims.d[0] % 4 == 0 || k + 1 == op.in.size());
+            if (t.dims.d[0] % 4 != 0)                                   // written as lane 0 of a group: the matrix-core correlation does that
+                for (const Op& pr : ops_)
+                    if (pr.out == t.id) cand = cand && t.dims.d[0] == 1 && corr_takes_il(pr);
+        }
+        for (const Op& rd : ops_)                                       // readers of the whole: plans that take a padded interleaved input
+            for (int x : rd.in)
+                if (x == op.out && &rd != &op) cand = cand && rd.kind == OpKind::kConv && (rt_conv_plan_supports_il8(rd.plan) & (1 | 16)) != 0;
+        if (!cand) continue;
+        cat_il[ci] = 1;
+        catpad[op.out] = 1;
+        catpad[op.in.back()] = 1;
+    }
+    for (auto& t : tensors_) il[t->id] = ok[t->id] && t->f16 == f16 && (t->dims.d[0] % (f16 ? 8 : 4) == 0 || catpad[t->id]);
+    for (size_t oi = 0; oi < ops_.size(); oi++) {
+        const Op& op = ops_[oi];
+        if (cat_il[oi]) continue;
+        int caps = op.kind == OpKind::kConv ? rt_conv_plan_supports_il8(op.plan) : 0;     // bit 0 input, 1 output, 2 residual, 4 padded input
+        if (corr_takes_il(op)) caps = 1 | (catpad[op.out] ? 2 : 0);
+        if (!(caps & 1)) for (int i : op.in) il[root(i)] = (caps & 16) && catpad[root(i)] ? il[root(i)] : 0;
         if (!(caps & 2)) il[root(op.out)] = 0;
         if (op.resid >= 0 && !(caps & 4)) il[root(op.resid)] = 0;
     }
-    for (auto& op : ops_)                            // both feature maps or neither
-        if (op.kind == OpKind::kCorrSoftargmax && il[root(op.in[0])] != il[root(op.in[1])]) il[root(op.in[0])] = il[root(op.in[1])] = 0;
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (auto& op : ops_)                            // both feature maps or neither
+            if (op.kind == OpKind::kCorrSoftargmax) {
+                if (il[root(op.in[0])] != il[root(op.in[1])]) { il[root(op.in[0])] = il[root(op.in[1])] = 0; changed = true; }
+                if (il[op.out] && !il[root(op.in[0])]) { il[op.out] = 0; changed = true; }     // no interleaved map without the matrix-core kernel
+            }
+        for (size_t ci = 0; ci < ops_.size(); ci++) {    // a concatenation and all its members, or none of them
+            if (!cat_il[ci]) continue;
+            const Op& op = ops_[ci];
+            bool all = il[op.out] != 0;
+            for (int i : op.in) all = all && il[i];
+            if (all) continue;
+            il[op.out] = 0;
+            for (int i : op.in) il[i] = 0;
+            cat_il[ci] = 0;
+            changed = true;
+        }
+    }
     for (auto& op : ops_) {
         if (op.kind != OpKind::kConv) continue;
         const int xi = il[root(op.in[0])], yi = il[root(op.out)], ri = op.resid >= 0 ? il[root(op.resid)] : 0;
@@ -893,7 +949,7 @@ void EngineImpl::assignPitch() {
         }
     }
     for (auto& op : ops_)
-        if (op.kind == OpKind::kCorrSoftargmax) op.il_in = il[root(op.in[0])] != 0;
+        if (op.kind == OpKind::kCorrSoftargmax) { op.il_in = il[root(op.in[0])] != 0; op.il_out = op.il_in && il[op.out] != 0; }
     int n_il = 0;
     for (auto& t : tensors_) t->il8 = il[t->id] != 0;
     for (auto& op : ops_) n_il += il[root(op.out)] != 0;         // tensors that launches really write
@@ -1151,7 +1207,7 @@ void EngineImpl::mergeSiamese() {
     auto pairable = [&](int l, int r) {
         if (l < 0 || r < 0 || l == r) return false;
         const TensorImpl &a = *tensors_[l], &b = *tensors_[r];
-        return plain(a) && plain(b) && same_dims(a.dims, b.dims) && a.pitch == b.pitch && a.f16 == b.f16 && a.il8 == b.il8;
+        return plain(a) && plain(b) && same_dims(a.dims, b.dims) && a.pitch == b.pitch && a.f16 == b.f16 && a.il8 == b.il8 && b.cpad == 0;
     };
     // 3. op pairs: convolution plans covering twin layers, all of whose tensors pair up
     int merged = 0;
@@ -1178,6 +1234,7 @@ void EngineImpl::mergeSiamese() {
         auto place = [&](int l, int r) {
             tensors_[r]->twin_of = l;
             tensors_[l]->has_twin = true;
+            tensors_[r]->cpad = tensors_[l]->cpad;         // same sample size as its twin (the host of an interleaved concatenation)
         };
         place(a.in[0], b.in[0]);
         place(a.out, b.out);
@@ -1209,12 +1266,23 @@ void EngineImpl::mergeSiamese() {
             if (op.twin_out >= 0) w.push_back(op.twin_out);
             return w;
         };
-        auto above = [&](int a, int b) {         // a == b or a is reached from b along alias_of
-            for (int t = b; t >= 0; t = tensors_[t]->alias_of)
-                if (t == a) return true;
-            return false;
+        // ... i.e. when their element ranges inside the root buffer overlap (first sample; the other samples repeat the picture).  The
+        // host of an interleaved concatenation and the members placed behind its own channels are the SAME buffer and different data.
+        auto range = [&](int t, int& r, int64_t& lo, int64_t& hi) {
+            const TensorImpl& x = *tensors_[t];
+            int64_t n = (int64_t)volume(x.dims);
+            lo = 0;
+            for (r = t; tensors_[r]->alias_of >= 0; r = tensors_[r]->alias_of) lo += tensors_[r]->alias_off;
+            if (x.dims.nbDims == 3 && tensors_[r]->pitch) n = (int64_t)x.dims.d[0] * x.dims.d[1] * tensors_[r]->pitch;
+            hi = lo + n;
         };
-        auto same_data = [&](int a, int b) { return above(a, b) || above(b, a); };
+        auto same_data = [&](int a, int b) {
+            int ra, rb;
+            int64_t la, ha, lb, hb;
+            range(a, ra, la, ha);
+            range(b, rb, lb, hb);
+            return ra == rb && la < hb && lb < ha;
+        };
         std::vector<std::vector<int>> rd(n), wr(n);
         for (size_t i = 0; i < n; i++) { rd[i] = reads(ops_[i]); wr[i] = writes(ops_[i]); }
         std::vector<char> placed(n, 0);
@@ -1489,49 +1557,91 @@ void EngineImpl::assignInterleaved3D() {
 // by a launch that takes an output batch stride (2-D convolution plans, the fused correlation) and read only by
 // convolution plans, the inputs BECOME channel ranges of the concatenated buffer -- same planar layout and row pitch, a
 // per-sample stride of the whole buffer -- and the copy launches disappear.
+// Will foldConcats() fold concatenation ops_[ci]?  (Layouts aside: the caller compares those.)
+bool EngineImpl::concatFoldable(size_t ci) const {
+    if (knob("RT_NO_CONCAT_FOLD") || knob("RT_NO_FUSION")) return false;
+    const Op& cat = ops_[ci];
+    const TensorImpl& out = *tensors_[cat.out];
+    if (out.is_input || out.is_output || out.alias_of >= 0 || out.dims.nbDims != 3) return false;
+    bool ok = true;
+    for (int i : cat.in) {
+        const TensorImpl& t = *tensors_[i];
+        ok = ok && !t.is_input && !t.is_output && t.alias_of < 0 && t.dims.nbDims == 3 && t.bstride == 0;
+        int producers = 0;
+        for (size_t oi = 0; oi < ops_.size() && ok; oi++) {
+            const Op& op = ops_[oi];
+            if (oi == ci) continue;
+            if (op.out == i) {
+                producers++;
+                ok = ok && (op.kind == OpKind::kConv || op.kind == OpKind::kCorrSoftargmax) && op.stream == cat.stream && oi < ci;
+            }
+            if (op.resid == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
+            for (int x : op.in)
+                if (x == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
+            if (op.kind == OpKind::kConcat)
+                for (int x : op.in) ok = ok && x != i;               // member of one concatenation only
+        }
+        ok = ok && producers == 1;
+    }
+    return ok;
+}
+
 void EngineImpl::foldConcats() {
-    if (knob("RT_NO_CONCAT_FOLD") || knob("RT_NO_FUSION")) return;
     for (size_t ci = 0; ci < ops_.size(); ci++) {
         if (ops_[ci].kind != OpKind::kConcat) continue;
         const Op cat = ops_[ci];
         TensorImpl& out = *tensors_[cat.out];
-        if (out.is_input || out.is_output || out.alias_of >= 0 || out.dims.nbDims != 3 || out.il8) continue;
-        const int64_t P = out.pitch ? out.pitch : out.dims.d[2], plane = (int64_t)out.dims.d[1] * P;
-        bool ok = true;
+        bool ok = concatFoldable(ci);
         for (int i : cat.in) {
             const TensorImpl& t = *tensors_[i];
-            ok = ok && !t.is_input && !t.is_output && t.alias_of < 0 && t.dims.nbDims == 3 && !t.il8 && t.f16 == out.f16 &&
-                 t.pitch == out.pitch && t.bstride == 0;
-            int producers = 0;
-            for (size_t oi = 0; oi < ops_.size() && ok; oi++) {
-                const Op& op = ops_[oi];
-                if (oi == ci) continue;
-                if (op.out == i) {
-                    producers++;
-                    ok = ok && (op.kind == OpKind::kConv || op.kind == OpKind::kCorrSoftargmax) && op.stream == cat.stream && oi < ci;
-                }
-                if (op.resid == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
-                for (int x : op.in)
-                    if (x == i) ok = ok && op.kind == OpKind::kConv && op.stream == cat.stream;
-                if (op.kind == OpKind::kConcat)
-                    for (int x : op.in) ok = ok && x != i;               // member of one concatenation only
-            }
-            ok = ok && producers == 1;
+            ok = ok && t.il8 == out.il8 && t.f16 == out.f16 && t.pitch == out.pitch;
         }
         // readers of the concatenated tensor must come after the concatenation (they do: it is their producer)
-        if (!ok) continue;
-        int coff = 0;
+        if (!ok) {
+            if (out.il8) {          // assignPitch() only keeps a concatenation interleaved when this pass folds it (same predicate)
+                log_.log(ILogger::Severity::kERROR, (cat.name + ": interleaved concatenation that cannot be folded").c_str());
+                ok_ = false;
+                return;
+            }
+            continue;
+        }
+        const int64_t P = out.pitch ? out.pitch : out.dims.d[2], plane = (int64_t)out.dims.d[1] * P;
         bool failed = false;
-        for (int i : cat.in) {
-            TensorImpl& t = *tensors_[i];
-            t.alias_of = out.id;
-            t.alias_off = (int64_t)coff * plane;
-            t.bstride = (int64_t)out.dims.d[0] * plane;
-            coff += t.dims.d[0];
-            for (auto& op : ops_) {
-                if (op.kind != OpKind::kConv) continue;
-                const int64_t xb = op.in[0] == i ? t.bstride : 0, yb = op.out == i ? t.bstride : 0, rb = op.resid == i ? t.bstride : 0;
-                if ((xb || yb || rb) && rt_conv_plan_set_batch_strides(op.plan, xb, yb, rb) != 0) failed = true;
+        if (out.il8) {
+            // interleaved: the FIRST member hosts the whole -- its buffer is allocated for the padded channel count, its own groups come
+            // first, the other members are further groups of it.  It stays a plain tensor (so that the siamese merge can pair it with
+            // its right-tower twin); the concatenated tensor is the same memory under its own name.  Sample strides: applySampleStrides().
+            TensorImpl& host = *tensors_[cat.in[0]];
+            const int G = out.f16 ? 8 : 4;
+            host.cpad = (out.dims.d[0] + G - 1) / G * G;
+            out.alias_of = host.id;
+            out.alias_off = 0;
+            int coff = host.dims.d[0];
+            for (size_t k = 1; k < cat.in.size(); k++) {
+                TensorImpl& t = *tensors_[cat.in[k]];
+                t.alias_of = out.id;                        // (through the whole: a reader of the whole depends on this member's producer)
+                t.alias_off = (int64_t)coff * plane;        // group g of (C/4, H, pitch, 4) starts where planar channel 4 g would
+                t.bstride = (int64_t)host.cpad * plane;
+                coff += t.dims.d[0];
+                for (auto& op : ops_) {
+                    if (op.kind != OpKind::kConv) continue;
+                    const int64_t xb = op.in[0] == t.id ? t.bstride : 0, yb = op.out == t.id ? t.bstride : 0, rb = op.resid == t.id ? t.bstride : 0;
+                    if ((xb || yb || rb) && rt_conv_plan_set_batch_strides(op.plan, xb, yb, rb) != 0) failed = true;
+                }
+            }
+        } else {
+            int coff = 0;
+            for (int i : cat.in) {
+                TensorImpl& t = *tensors_[i];
+                t.alias_of = out.id;
+                t.alias_off = (int64_t)coff * plane;
+                t.bstride = (int64_t)out.dims.d[0] * plane;
+                coff += t.dims.d[0];
+                for (auto& op : ops_) {
+                    if (op.kind != OpKind::kConv) continue;
+                    const int64_t xb = op.in[0] == i ? t.bstride : 0, yb = op.out == i ? t.bstride : 0, rb = op.resid == i ? t.bstride : 0;
+                    if ((xb || yb || rb) && rt_conv_plan_set_batch_strides(op.plan, xb, yb, rb) != 0) failed = true;
+                }
             }
         }
         if (failed) {
@@ -1541,7 +1651,28 @@ void EngineImpl::foldConcats() {
         }
         ops_.erase(ops_.begin() + ci);
         ci--;
-        log_.log(ILogger::Severity::kINFO, (cat.name + ": concatenation folded into its producers (no copy launch)").c_str());
+        log_.log(ILogger::Severity::kINFO, (cat.name + ": concatenation folded into its producers (no copy launch)" +
+                                            (out.il8 ? ", interleaved: the first member hosts the whole" : "")).c_str());
+    }
+}
+
+// Launches that touch a tensor with padded channels (the host of an interleaved concatenation, its right-tower twin, the concatenated
+// tensor itself) step from sample to sample by the PADDED size.
+void EngineImpl::applySampleStrides() {
+    auto stride = [&](int t) -> int64_t {
+        if (t < 0 || tensors_[t]->bstride) return 0;               // (a member placed inside another buffer: set where it was folded)
+        while (tensors_[t]->alias_of >= 0 && tensors_[t]->alias_off == 0 && tensors_[t]->bstride == 0) t = tensors_[t]->alias_of;
+        const TensorImpl& r = *tensors_[t];
+        return r.cpad ? sampleElems(r) : 0;
+    };
+    for (auto& op : ops_) {
+        if (op.kind != OpKind::kConv) continue;
+        const int64_t xb = stride(op.in[0]), yb = stride(op.out), rb = stride(op.resid);
+        if ((xb || yb || rb) && rt_conv_plan_set_batch_strides(op.plan, xb, yb, rb) != 0) {
+            log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+            ok_ = false;
+            return;
+        }
     }
 }
 
@@ -1712,11 +1843,13 @@ bool ContextImpl::ensureBuffers(int batch) {
             for (int i : op.in) used |= i == t->id;
         }
         if (!used) continue;
-        const size_t elems = t->pitch ? (size_t)t->dims.d[0] * t->dims.d[1] * t->pitch : (size_t)volume(t->dims);
-        if (rt_malloc(&buffers_[t->id], elems * (t->f16 ? 2 : 4) * (size_t)batch * (t->has_twin ? 2 : 1)) != 0) {
+        const size_t bytes = (size_t)EngineImpl::sampleElems(*t) * (t->f16 ? 2 : 4) * (size_t)batch * (t->has_twin ? 2 : 1);
+        if (rt_malloc(&buffers_[t->id], bytes) != 0) {
             eng_.log_.log(ILogger::Severity::kERROR, (std::string("engine: device allocation failed: ") + rt_last_error_string()).c_str());
             return false;
         }
+        // padded channels are read (16-byte groups) and meet zero weights: they must be finite from the first pass on
+        if (t->cpad && (rt_memset(buffers_[t->id], 0, bytes, nullptr) != 0 || rt_stream_sync(nullptr) != 0)) return false;
     }
     if (eng_.workspace_bytes_ && !workspace_) {
         if (rt_malloc(&workspace_, eng_.workspace_bytes_) != 0) return false;
@@ -1732,7 +1865,7 @@ void* ContextImpl::addr(int tensor, int batch, void** bindings) const {
     while (eng_.tensors_[t]->alias_of >= 0) { off += eng_.tensors_[t]->alias_off; t = eng_.tensors_[t]->alias_of; }
     if (eng_.tensors_[t]->twin_of >= 0) {      // right-tower twin: `batch` samples behind the left tensor's first sample
         const TensorImpl& r = *eng_.tensors_[t];
-        off += (int64_t)batch * (r.pitch ? (int64_t)r.dims.d[0] * r.dims.d[1] * r.pitch : (int64_t)volume(r.dims));
+        off += (int64_t)batch * EngineImpl::sampleElems(r);
         t = r.twin_of;
     }
     const TensorImpl& ti = *eng_.tensors_[t];
@@ -1782,9 +1915,19 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
         const int C = ti.dims.d[0], H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W, G = ti.il8 ? (ti.f16 ? 8 : 4) : 1;
         float mx = 0.f;
         int64_t bad = 0;
-        if (rt_check_range(addr(tin, batch, bindings), (int64_t)batch * (C / G) * H, (int64_t)G * W, (int64_t)G * P, ti.f16 ? RT_F16 : RT_F32, limit, &mx, &bad, st) != 0) {
-            eng_.log_.log(ILogger::Severity::kERROR, (op.name + ": range check failed: " + rt_last_error_string()).c_str());
-            return false;
+        // (the host of an interleaved concatenation: its own channels sample by sample -- the groups behind them belong to other members)
+        const int calls = ti.cpad ? batch : 1;
+        const int64_t rows = (int64_t)(ti.cpad ? 1 : batch) * (C / G) * H;
+        for (int n = 0; n < calls; n++) {
+            float m1 = 0.f;
+            int64_t b1 = 0;
+            const char* px = static_cast<const char*>(addr(tin, batch, bindings)) + (size_t)n * EngineImpl::sampleElems(ti) * (ti.f16 ? 2 : 4);
+            if (rt_check_range(px, rows, (int64_t)G * W, (int64_t)G * P, ti.f16 ? RT_F16 : RT_F32, limit, &m1, &b1, st) != 0) {
+                eng_.log_.log(ILogger::Severity::kERROR, (op.name + ": range check failed: " + rt_last_error_string()).c_str());
+                return false;
+            }
+            mx = std::max(mx, m1);
+            bad += b1;
         }
         if (bad) {
             char msg[256];
@@ -1946,8 +2089,9 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
             case OpKind::kCorrSoftargmax: {
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
                 if (op.il_in)
-                    rc = rt_corr_softargmax_il(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
-                                               f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride, st);
+                    rc = rt_corr_softargmax_il_slot(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
+                                                    f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride,
+                                                    op.il_out ? 4 : 1, st);
                 else
                     rc = rt_corr_softargmax_pitched(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0],
                                                     f.d[1], f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch,
@@ -2015,7 +2159,7 @@ size_t ContextImpl::outBytes(const Op& op, int batch) const {
     const size_t elems = t.pitch ? (size_t)t.dims.d[0] * t.dims.d[1] * t.pitch : (size_t)volume(t.dims);
     const size_t es = (t.f16 && !t.is_output && !t.is_input) ? 2 : 4;
     size_t n = elems * es;
-    if (t.bstride == 0 && t.alias_of < 0) n *= (size_t)batch * (op.twin ? 2 : 1);
+    if (t.bstride == 0 && t.alias_of < 0 && t.cpad == 0) n *= (size_t)batch * (op.twin ? 2 : 1);
     return n & ~(size_t)3;
 }
 

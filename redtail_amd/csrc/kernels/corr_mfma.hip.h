@@ -16,6 +16,7 @@
 // MFMA operand of a lane -- 8 consecutive channels of one pixel -- is two 16-byte loads.  One wave per (row, 32-pixel
 // block); R blocks are shared with the neighbouring waves through L1/L2 only.
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 #include "conv_split.hip.h"
 
@@ -30,6 +31,8 @@ struct CorrMfmaArgs {
     int64_t in_bstride, out_bstride;     // elements
     int blocks_x;                        // ceil(W / 32)
     int batch;
+    int out_slot;                        // 1: out is a plane (H, out_pitch); 4: lane 0 of the 16-byte pixel slots of a channel-interleaved
+                                         // group (H, out_pitch, 4) -- the other three lanes are written as zeros
 };
 
 __device__ static __forceinline__ void corr_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
@@ -80,7 +83,15 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_k
 #pragma unroll
     for (int c = 0; c < 2; c++) corr_split8(lraw[c][0], lraw[c][1], lh[c], ll[c]);
 
-    // online soft-argmax state of this lane (its 16 of the 32 R pixels of each block)
+    // online soft-argmax state of this lane (its 16 of the 32 R pixels of each block), in base 2: e = 2^((v - m) log2 e).
+    // VALU is what bounds this kernel (round 3: 55 VALU instructions per MFMA), so per element there is one fma for the split's
+    // correction term, one compare + select for the disparity range, one fma + v_exp_f32 for the weight and two accumulations:
+    //   * accumulator register r holds R pixel m = c_r + 4 kg, c_r = (r & 3) + 8 (r >> 2), i.e. disparity d = dj - c_r with the LANE
+    //     value dj = l31 + 64 - 32 j - 4 kg: sum e d = dj sum e - sum e c_r, c_r a literal -- no int -> float conversion per element;
+    //   * a masked element is -1e30 BEFORE the exponential, which makes its weight exactly 0 (2^-huge) without a second select;
+    //   * d >= 0 can only fail in the last block (j = 2: d <= 31), d < D only in the first two when D >= 32 (j = 0: d >= 33).
+    constexpr float kL2E = 1.44269504088896341f;
+    const bool d_ge32 = p.D >= 32;                                  // wave-uniform
     float m_run = -1e30f, s_run = 0.f, w_run = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -95,29 +106,43 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_k
             acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl, lh[c], acc_c, 0, 0, 0);
             acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, ll[c], acc_c, 0, 0, 0);
         }
-        // accumulator register r = R pixel x0 - 64 + 32 j + m, m = (r & 3) + 8 (r >> 2) + 4 kg; column = L pixel x0 + l31
+        const int dj = l31 + 64 - 32 * j - 4 * kg;
         float v[16];
         float bm = -1e30f;
+        auto gather = [&](auto lo_check, auto hi_check) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            const int d = l31 + 64 - 32 * j - m;                    // x - x'
-            const float val = fmaf(acc_c[r], kSplitInv, acc_m[r]);
-            v[r] = (d >= 0 && d < p.D) ? (ISMIN ? -val : val) : -1e30f;
-            bm = fmaxf(bm, v[r]);
+            for (int r = 0; r < 16; r++) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const float val = fmaf(acc_c[r], ISMIN ? -kSplitInv : kSplitInv, ISMIN ? -acc_m[r] : acc_m[r]);
+                bool ok = true;
+                if constexpr (decltype(lo_check)::value) ok = ok && cr <= dj;             // d >= 0
+                if constexpr (decltype(hi_check)::value) ok = ok && dj - cr < p.D;        // d < D
+                v[r] = ok ? val : -1e30f;
+                bm = fmaxf(bm, v[r]);
+            }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (j == 2) {
+            if (d_ge32) gather(T_{}, F_{}); else gather(T_{}, T_{});
+        } else {
+            gather(F_{}, T_{});
         }
         const float m_new = fmaxf(m_run, bm);
-        const float sc = fast_exp(m_run - m_new);
-        s_run *= sc;
-        w_run *= sc;
+        const float sc = __builtin_amdgcn_exp2f((m_run - m_new) * kL2E);
+        // (nothing valid yet: m_new is the mask value, and the ROUNDED product -m_new log2 e differs from the exact one inside the fma by
+        // up to 1e23 -- an exponent of 0 instead keeps every masked weight at exactly 0)
+        const float mL = m_new < -1e29f ? 0.f : -m_new * kL2E;
+        float s_blk = 0.f, c_blk = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            const int d = l31 + 64 - 32 * j - m;
-            const float e = (d >= 0 && d < p.D) ? fast_exp(v[r] - m_new) : 0.f;
-            s_run += e;
-            w_run = fmaf(e, (float)d, w_run);
+            const float cr = (float)((r & 3) + 8 * (r >> 2));
+            const float e = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, mL));
+            s_blk += e;
+            c_blk = fmaf(e, cr, c_blk);
         }
+        s_run = fmaf(s_run, sc, s_blk);
+        w_run = fmaf(w_run, sc, fmaf((float)dj, s_blk, -c_blk));
         m_run = m_new;
     }
     // the other half-wave holds the other 16 R pixels of every block for the same output pixel
@@ -126,7 +151,11 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_k
     const float e1 = fast_exp(m_run - M), e2 = fast_exp(m2 - M);
     const float s = s_run * e1 + s2 * e2, w = w_run * e1 + w2 * e2;
     const int x = x0 + l31;
-    if (kg == 0 && x < p.W) p.out[(int64_t)n * p.out_bstride + (int64_t)y * p.out_pitch + x] = w / s;
+    if (kg == 0 && x < p.W) {
+        float* o = p.out + (int64_t)n * p.out_bstride;
+        if (p.out_slot == 4) *reinterpret_cast<f32x4*>(o + ((int64_t)y * p.out_pitch + x) * 4) = f32x4{w / s, 0.f, 0.f, 0.f};
+        else o[(int64_t)y * p.out_pitch + x] = w / s;
+    }
 }
 
 }  // namespace rt

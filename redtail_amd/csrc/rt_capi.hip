@@ -335,7 +335,15 @@ extern "C" int rt_corr_softargmax_pitched(const void* left, const void* right, v
 // Correlation + soft-argmax on channel-interleaved (C/4, H, pitch, 4) fp32 feature maps, on the matrix cores (corr_mfma.hip.h)
 extern "C" int rt_corr_softargmax_il(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
                                      int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream s) {
+    return rt_corr_softargmax_il_slot(left, right, out, batch, C, H, W, D, is_min, in_pitch, out_pitch, out_bstride, 1, s);
+}
+// ... writing the map as lane 0 of the 16-byte pixel slots of a channel-interleaved group (out_slot = 4): the 33rd channel of
+// conv2D_1's input when the concatenation it belongs to is kept interleaved (resnet18_2D_513x257_net.cpp:601-615)
+extern "C" int rt_corr_softargmax_il_slot(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
+                                          int is_min, int in_pitch, int out_pitch, int64_t out_bstride, int out_slot, rtStream s) {
     RT_REQUIRE(left && right && out, "rt_corr_softargmax_il: null pointer");
+    RT_REQUIRE(out_slot == 1 || out_slot == 4, "rt_corr_softargmax_il_slot: out_slot is 1 (plane) or 4 (lane 0 of an interleaved group)");
+    RT_REQUIRE(out_slot == 1 || (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_bstride % 4 == 0), "rt_corr_softargmax_il_slot: 16-byte slots need a 16-byte aligned output");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax_il: bad dims");
     if (C % 4 != 0 || C > 32 || D > 64) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_il: C must be a multiple of 4 up to 32 and max_disp <= 64 (C %d, D %d)", C, D);
     RT_REQUIRE((in_pitch == 0 || in_pitch >= W) && (out_pitch == 0 || out_pitch >= W), "rt_corr_softargmax_il: pitch smaller than the row");
@@ -344,7 +352,8 @@ extern "C" int rt_corr_softargmax_il(const void* left, const void* right, void* 
     a.C = C; a.H = H; a.W = W; a.D = D;
     a.in_pitch = in_pitch ? in_pitch : W; a.out_pitch = out_pitch ? out_pitch : W;
     a.in_bstride = (int64_t)C * H * a.in_pitch;
-    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch;
+    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch * out_slot;
+    a.out_slot = out_slot;
     RT_REQUIRE(a.in_bstride < (1ll << 29), "rt_corr_softargmax_il: sample exceeds 2 GB (32-bit buffer offsets)");
     a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
     const int64_t tasks = (int64_t)a.blocks_x * H * batch;
@@ -1946,7 +1955,10 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     // the general split-fp16 kernel (any 2-D window, transposed phases included) takes and writes them freely
     if (plan->subs[0].split3 && env_int("RT_NO_IL8", 0) == 0) {
         if (plan->subs[0].y_f16) return (plan->cin % 4 == 0 ? 1 : 0) | (plan->subs[0].Cout % 8 == 0 ? 2 : 0);      // fp16 output: groups of 8, no residual
-        return (plan->cin % 4 == 0 ? 1 : 0) | (plan->subs[0].Cout % 4 == 0 ? 6 : 0);
+        // bit 4 (16): an interleaved input whose channel count is PADDED to a multiple of 4 -- the gather reads whole 16-byte groups and
+        // the pad channels meet zero weights, so they must hold finite values (the 33-channel input of conv2D_1: 32 feature channels
+        // and the soft-argmax map in lane 0 of a ninth group)
+        return (plan->cin % 4 == 0 ? 1 : 16) | (plan->subs[0].Cout % 4 == 0 ? 6 : 0);
     }
     if (plan->is_deconv) return 0;
     const SubConv& sc = plan->subs[0];
@@ -2026,10 +2038,10 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }
         return 0;
     }
-    if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)))
+    if ((x_il8 && !(caps & (1 | 16))) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)))
         return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this plan does not take an interleaved %s tensor (3x3 stride-1 plans take all three; "
                     "the first layer and stride-2 3x3 layers write one; channel counts must be multiples of 4 in fp32, 8 in fp16)",
-                    x_il8 && !(caps & 1) ? "input" : (y_il8 && !(caps & 2) ? "output" : "residual"));
+                    x_il8 && !(caps & (1 | 16)) ? "input" : (y_il8 && !(caps & 2) ? "output" : "residual"));
     RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
     SubConv& sc = plan->subs[0];
     RT_REQUIRE(!sc.rb || (x_il8 != 0) == (r_il8 != 0), "rt_conv_plan_set_layouts: a residual block's residual is its input tensor");

@@ -83,20 +83,19 @@ def test_resnet18_2d_tiny(rt):
 
 
 def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
-    """RT_RB=1: every residual block of the two towers as ONE launch (streaming kernel where the tensors are interleaved, per-tile
-    kernel for the left tower's first block, whose input is written straight into a concatenation); 73 x 41 image = two strips
+    """RT_RB=1: every residual block of the two towers as ONE launch of the streaming kernel (round 4: also the left tower's first block,
+    whose input -- a member of conv2D_1's concatenation -- now stays interleaved as the host of that concatenation); 73 x 41 image = two strips
     and two segments at half resolution (37 x 21) with 16-row segments, one with 32.  Same numbers as layer by layer."""
     w = O.synth_weights_resnet18_2d()
     l, r = pairs(1 if rt.kind == "emu" else 2, 41, 73)          # (one pair on the emulator: CPU tier time)
     base, (_, launches0) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-    assert launches0 == 48 - 15                            # siamese merge: 14 block convolutions + encoder2D_out of the two towers pair up
+    assert launches0 == 48 - 17                            # siamese merge: 16 block convolutions + encoder2D_out of the two towers pair up
     monkeypatch.setenv("RT_RB", "1")
     for seg in ("16", "32"):
         monkeypatch.setenv("RT_RBS_SEG", seg)
         out, (layers, launches) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-        # 16 blocks, two launches -> one; blocks 2-8 + encoder2D_out: two towers -> one.  The left tower's first block reads a planar
-        # tensor (written straight into the concatenation): the per-tile form, which only RT_EXPERIMENTAL kernel libraries carry
-        assert launches == 48 - 16 - 8 + (0 if rt.lib.kernels.has_experimental() else 1)
+        # 16 blocks, two launches -> one; blocks 1-8 + encoder2D_out: two towers -> one
+        assert launches == 48 - 16 - 9
         assert not np.isnan(out).any()
         assert np.abs(out - base).max() <= 2e-5, np.abs(out - base).max()
     with torch.no_grad():
@@ -141,7 +140,7 @@ def test_resnet18_2d_siamese_merge_is_bit_identical(rt, monkeypatch):
     with torch.no_grad():
         ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w2, max_disp=8).numpy()
     assert np.abs(out - ref).max() <= 2e-4
-    assert launches == 48 - 2                              # only block 2 (before the differing layer) pairs up: twins need twin inputs
+    assert launches == 48 - 4                              # only blocks 1 and 2 (before the differing layer) pair up: twins need twin inputs
 
 
 @pytest.mark.parametrize("ksplit", [None, "0"])
@@ -603,7 +602,7 @@ def test_resnet18_2d_interleaved_equals_planar(rt, monkeypatch):
     il, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
     monkeypatch.setenv("RT_NO_IL8", "1")
     planar, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-    assert n1 == n2
+    assert n1 == n2 - 2       # (interleaved, the first member of conv2D_1's concatenation is a plain tensor: the left tower's first block merges too)
     assert np.abs(il - planar).max() <= 2e-6         # bit-identical convolutions; the correlation kernel differs (see above)
 
 
@@ -622,7 +621,7 @@ def test_development_knobs_need_opt_in(tmp_path):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         counts[dev] = int(out.stdout.split("LAUNCHES")[1].split()[0])
-    assert counts["0"] == 48 - 15 and counts["1"] > 100, counts      # ignored / honoured (one launch per layer)
+    assert counts["0"] == 48 - 17 and counts["1"] > 100, counts      # ignored / honoured (one launch per layer)
 
 
 def test_exact_fp32_is_an_api_option(rt, monkeypatch):

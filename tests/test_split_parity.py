@@ -316,6 +316,49 @@ def test_corr_softargmax_mfma(backend, shape, D, is_min, pitch):
         assert np.isnan(got[..., w:]).all(), "padding columns were written"
 
 
+def test_corr_softargmax_writes_the_ninth_group_and_conv_reads_33_interleaved_channels(backend):
+    """the concatenation in front of conv2D_1 kept interleaved (resnet18_2D_513x257_net.cpp:601-615): one buffer of 9 groups of 4
+    channels per sample -- 8 groups of the left feature map and a ninth whose lane 0 is the soft-argmax map (rt_corr_softargmax_il_slot,
+    zeros in lanes 1..3) -- read by a 33 -> 32 convolution as a PADDED interleaved input (rt_conv_plan_supports_il8 bit 4).  Same bits
+    as the planar concatenation."""
+    n, c, h, w, D, P = 2, 32, 7, 45, 12, 64
+    l, r = rnd(n, c, h, w) * np.float32(0.5), rnd(n, c, h, w) * np.float32(0.5)
+    feat = rnd(n, 32, h, w)                                            # left_conv1_act's stand-in
+    wt, b = rnd(32, 33, 3, 3) * np.float32(1 / np.sqrt(33 * 9)), rnd(32)
+    lil, ril = backend.dev(to_il(pitched(l, P), 4)), backend.dev(to_il(pitched(r, P), 4))
+    # planar reference of the same kernels: the map as a plane, the 33 channels planar
+    disp = backend.empty((n, 1, h, P))
+    backend.klib.corr_softargmax_il(lil, ril, disp, n, c, h, w, D, False, P, P)
+    dmap = backend.host(disp).copy()
+    cat = np.concatenate([pitched(feat, P), np.nan_to_num(dmap)], axis=1)           # (n, 33, h, P)
+    plan = backend.klib.conv2d_plan(wt, b, 33, 32, h, w, 3, 1, 1, act=capi.RT_ACT_ELU)
+    plan.set_pitch(P, P)
+    caps = plan.il_caps()
+    assert caps & 16 and not caps & 1, caps
+    y = backend.empty((n, 32, h, P))
+    plan.enqueue(backend.dev(cat), y, None, n)
+    planar = backend.host(y).copy()
+    # interleaved: (n, 9, h, P, 4), the ninth group written by the correlation kernel
+    buf = np.full((n, 9, h, P, 4), np.nan, np.float32)
+    buf[:, :8] = to_il(pitched(feat, P), 4)
+    buf[:, 8] = 7.0                                                    # stale values: lanes 1..3 must be overwritten with zeros
+    dbuf = backend.dev(buf)
+    if backend.name == "gpu":
+        slot = dbuf[:, 8]
+        backend.klib.corr_softargmax_il(lil, ril, slot, n, c, h, w, D, False, P, P, out_bstride=9 * h * P * 4, out_slot=4)
+    else:
+        backend.klib.corr_softargmax_il(lil, ril, dbuf[:, 8], n, c, h, w, D, False, P, P, out_bstride=9 * h * P * 4, out_slot=4)
+    got = backend.host(dbuf)
+    assert np.array_equal(got[:, 8, :, :w, 0], dmap[:, 0, :, :w])
+    assert (got[:, 8, :, :w, 1:] == 0).all() and (got[:, 8, :, w:] == 7.0).all()      # zeros beside the map, padding columns untouched
+    plan.set_layouts(1, 0, 0)
+    plan.set_batch_strides(9 * h * P * 4, 0, 0)
+    y = backend.empty((n, 32, h, P))
+    plan.enqueue(dbuf, y, None, n)
+    assert np.array_equal(backend.host(y)[..., :w], planar[..., :w])
+    plan.destroy()
+
+
 # ---- default cost volume folded into the first Conv3D's gather (never materialised) ----------------------------------------
 @pytest.mark.parametrize("f,k,h,w,D,batch", [(8, 16, 9, 37, 6, 2), (32, 32, 5, 40, 12, 1), (4, 8, 7, 33, 5, 1)])
 def test_conv3d_on_folded_cost_volume(backend, f, k, h, w, D, batch):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few passes of a 3-D model for rocprofv3 counter runs (tools/pmc_3d.sh): python tools/iso_3d.py [model] [passes] [--half2] [--batch=N]"""
+"""A few passes of a 3-D model for rocprofv3 counter runs (tools/pmc_3d.sh): python tools/iso_3d.py [model] [passes] [--half2] [--batch=N] [--mark]"""
 import os
 import sys
 os.environ.setdefault("RT_DEV_KNOBS", "1")
@@ -18,6 +18,8 @@ w, h, cfg = CASES[model]
 lib = capi.NetLib()
 net = lib.create(model, w, h, max_batch=batch, weights=synth.synth_weights_3d(cfg), fp16_weights=half2)
 net.set_streams(1)
+if "--mark" in sys.argv:       # the launch trace hashes every launch's output on the launch's stream: one rt::hash_words_kernel dispatch
+    net.set_launch_trace(True)  # after each launch, which is what tools/pmc_3d.sh segments the dispatch list by
 l, r = synth.synth_pair(h, w, 1234)
 L, R = torch.from_numpy(np.stack([l] * batch)).cuda(), torch.from_numpy(np.stack([r] * batch)).cuda()
 out = torch.empty(batch, 1, h, w, device="cuda")

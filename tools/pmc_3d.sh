@@ -11,7 +11,7 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -o p -- python $ROOT/tools/iso_3d.py "$@" > $OUT/g$i.log 2>&1      # (iso_3d.py: 3 passes)
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -o p -- python $ROOT/tools/iso_3d.py "$@" --mark > $OUT/g$i.log 2>&1      # (iso_3d.py: 3 passes)
 done <<'GRPS'
 FETCH_SIZE
 WRITE_SIZE
@@ -40,16 +40,29 @@ for f in sorted(glob.glob(out + "/g*/p_counter_collection.csv")):
             dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
     except Exception:
         pass
-    ids = [d for d in disp if "rt::" in disp[d]["kernel"]]
-    ids = ids[-(len(ids) // 3):]                # the last of the 3 passes (a Conv3DTranspose launch is two dispatches: one per depth class)
-    for pos, d in enumerate(ids):
-        key = (pos, "")
-        e = rows.setdefault(key, {"kernel": disp[d]["kernel"].split("(")[0][:60]})
-        for k, v in disp[d].items():
-            if k != "kernel":
-                e[k] = v
-        if d in dur:
-            e.setdefault("us", []).append(dur[d])
+    # iso_3d.py --mark: every launch is followed by one rt::hash_words_kernel dispatch (the executor's launch trace), so the dispatches
+    # between two of them are ONE launch (a Conv3DTranspose of the phase form is two: one per depth class)
+    segs, cur = [], []
+    for d in disp:
+        if "rt::" not in disp[d]["kernel"]:
+            continue
+        if "hash_words_kernel" in disp[d]["kernel"]:
+            segs.append(cur); cur = []
+        else:
+            cur.append(d)
+    assert names and len(segs) % len(names) == 0, (len(segs), names)
+    segs = segs[-len(names):]                   # the last pass
+    for pos, ds in enumerate(segs):
+        key = (pos, names[pos])
+        e = rows.setdefault(key, {"kernel": " + ".join(sorted(set(disp[d]["kernel"].split("(")[0].split("<")[0].replace("void ", "") for d in ds)))})
+        acc = {}
+        for d in ds:
+            for k, v in disp[d].items():
+                if k != "kernel":
+                    acc[k] = acc.get(k, 0.0) + v
+        e.update(acc)
+        if all(d in dur for d in ds) and ds:
+            e.setdefault("us", []).append(sum(dur[d] for d in ds))
 res = []
 for (pos, name), e in rows.items():
     us = sum(e["us"]) / len(e["us"]) if e.get("us") else None
