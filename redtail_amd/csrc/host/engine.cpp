@@ -1508,6 +1508,31 @@ void EngineImpl::assignInterleaved3D() {
         il[root(op.out)] = 0;
         if (op.resid >= 0) il[root(op.resid)] = 0;
     }
+    // fp32 engines: the two feature maps of a folded cost volume ((2F, H, W) buffer, foldCostVolumes) join the negotiation when the two
+    // tower launches that write them can store (2F/4, H, W, 4): the first Conv3D then gathers 16-byte slots instead of 4-byte planes
+    struct Feat { int tensor; std::vector<size_t> producers; };
+    std::vector<Feat> feats;
+    if (!f16_mode && !knob("RT_NO_IL_FEAT_F32"))
+        for (size_t ci = 0; ci < ops_.size(); ci++) {
+            const Op& cv = ops_[ci];
+            if (cv.kind != OpKind::kConv3D || !cv.splugin->fusion().cv_fold) continue;
+            const int x = root(cv.in[0]);
+            const TensorImpl& ft = *tensors_[x];
+            if (ft.dims.nbDims != 3 || ft.f16 || ft.il8 || ft.pitch || ft.dims.d[0] % 8 != 0) continue;
+            Feat f{x, {}};
+            bool ok = true;
+            for (size_t i = 0; i < ops_.size() && ok; i++) {
+                const Op& op = ops_[i];
+                if (i == ci) continue;
+                bool reads = op.resid >= 0 && root(op.resid) == x;
+                for (int t : op.in) reads = reads || root(t) == x;
+                if (reads) ok = false;                                  // only the Conv3D reads the maps
+                if (root(op.out) == x) { ok = ok && op.kind == OpKind::kConv && !op.twin && (rt_conv_plan_supports_il8(op.plan) & 2) != 0; f.producers.push_back(i); }
+            }
+            if (!ok || f.producers.size() != 2) continue;
+            il[x] = 1;
+            feats.push_back(f);
+        }
     std::vector<char> fixed(tensors_.size(), 0);        // fp16 interleaved feature maps of a folded cost volume (assignHalf3D): decided already
     for (auto& op : ops_)
         if (op.kind == OpKind::kConv3D && op.splugin->fusion().cv_fold) {
@@ -1546,6 +1571,21 @@ void EngineImpl::assignInterleaved3D() {
         n += yi;
     }
     if (!ok_) return;
+    for (const Feat& f : feats) {
+        if (!il[f.tensor]) continue;
+        for (size_t i : f.producers) {
+            Op& p = ops_[i];
+            const TensorImpl& pin = *tensors_[root(p.in[0])];
+            if (rt_conv_plan_set_layouts(p.plan, pin.il8, 1, p.resid >= 0 && tensors_[root(p.resid)]->il8) != 0) {
+                log_.log(ILogger::Severity::kERROR, (p.name + ": " + rt_last_error_string()).c_str());
+                ok_ = false;
+                return;
+            }
+        }
+        for (auto& t : tensors_)                                         // the maps are interleaved: so are the tensors that alias into them
+            if (t->alias_of >= 0 && root(t->id) == f.tensor) t->il8 = true;
+        log_.log(ILogger::Severity::kINFO, "fp32: the first Conv3D reads the two feature maps channel-interleaved (2F/4, H, W, 4)");
+    }
     for (auto& t : tensors_)
         if (il[t->id]) t->il8 = true;
     if (n) log_.log(ILogger::Severity::kINFO, (std::string(f16_mode ? "half2 mode: " : "fp32: ") + std::to_string(n) + " Conv3D launches write channel-interleaved " +

@@ -421,9 +421,13 @@ __global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_W
     auto prefetch = [&](int ch) {
         if constexpr (XIL) {
             const int off = tab[ch * CC];                          // group offset == planar offset of its first channel
+            const int sh = shtab ? shtab[ch * CC] : 0;             // folded cost volume: 16-byte slots, sh pixels to the left
             const buf_rsrc rs = make_buf(xb, off >= 0);
 #pragma unroll
-            for (int k = 0; k < NKP; k++) rin[k] = buf_load4(rs, voff[k], (unsigned)off * 4u);
+            for (int k = 0; k < NKP; k++) {
+                const unsigned vo = sh == 0 ? voff[k] : ((voff[k] != kBufOOB && xcol[k] >= sh) ? voff[k] - (unsigned)sh * 16u : kBufOOB);
+                rin[k] = buf_load4(rs, vo, (unsigned)off * 4u);
+            }
         } else {
             // folded cost volume: the 4 channels of the group share one shift (right-image channels of depth slice d: d)
             const int sh = shtab ? shtab[ch * CC] : 0;             // wave-uniform

@@ -1925,10 +1925,11 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
             if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0)) : 0;
             if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out_dm;         // fp32 (feature maps) in, fp16 volume out
             // fp32 tensors (round 4): the split kernel takes (D, C/4, H, W, 4) on either side -- one 16-byte load per pixel and group of 4
-            // channels instead of four 4-byte ones, 16-byte stores.  Not the folded cost volume's input (no x-shift in the interleaved gather).
+            // channels instead of four 4-byte ones, 16-byte stores.  The folded cost volume's two feature maps: (2F/4, H, W, 4), the right
+            // half read shifted by the slice's disparity in whole 16-byte slots.
             if (sc.split3 && !sc.x_f16 && !sc.y_f16 && sc.TY == 4 && sc.KH == 3 && sc.KW == 3 && env_int("RT_NO_IL8_3D_F32", 0) == 0) {
                 const int o4 = (plan->c3d_dchw && sc.Cout % 4 == 0) ? 2 : 0;
-                return ((!plan->c3d_fold && plan->c3d_C % 4 == 0) ? 1 : 0) | o4 | ((o4 && plan->has_resid) ? 4 : 0);
+                return ((plan->c3d_C % 4 == 0 && plan->c3d_fold % 4 == 0) ? 1 : 0) | o4 | ((o4 && plan->has_resid) ? 4 : 0);
             }
             return 0;
         }

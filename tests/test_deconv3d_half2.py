@@ -330,14 +330,30 @@ def test_conv3d_fp32_on_interleaved_tensors(backend, c, k, d, h, w, stride, resi
     plan.destroy()
 
 
-def test_conv3d_fp32_folded_cost_volume_keeps_its_planar_input(backend):
-    """the first Conv3D of an fp32 3-D engine reads the two feature maps through the x-shift table: interleaved OUTPUT only"""
-    f, k, h, w, D = 8, 16, 9, 37, 4
-    plan = backend.klib.conv3d_plan(rnd(k, 3, 2 * f, 3, 3), rnd(k), 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1),
-                                    act=capi.RT_ACT_ELU, out_dchw=True, cv_fold=f)
-    assert plan.il_caps() & 3 == 2
-    with pytest.raises(capi.RtError):
-        plan.set_layouts(1, 1, 0)
+@pytest.mark.parametrize("f,k,h,w,D", [(8, 16, 9, 37, 6), (32, 32, 5, 40, 12), (4, 8, 7, 33, 5)])
+def test_conv3d_fp32_folded_cost_volume_on_interleaved_feature_maps(backend, f, k, h, w, D):
+    """the first Conv3D of an fp32 3-D engine reads the two feature maps [left | right] as (2F/4, H, W, 4): the right half shifted by the
+    slice's disparity in whole 16-byte slots.  Same bits as on planar maps."""
+    n = 2
+    l, r = rnd(n, f, h, w), rnd(n, f, h, w)
+    wt, b = rnd(k, 3, 2 * f, 3, 3) * np.float32(1 / np.sqrt(27 * 2 * f)), rnd(k)
+    cv = O.cost_volume(T(l).double(), T(r).double(), D)
+    ref = O.elu(O.transform(O.conv3d_tf(cv, T(wt).double(), T(b).double(), (1, 1, 1), (1, 1, 1), (1, 1, 1)))).numpy()
+    plan = backend.klib.conv3d_plan(wt, b, 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU,
+                                    out_dchw=True, cv_fold=f)
+    assert plan.il_caps() & 3 == 3
+    x = np.concatenate([l, r], axis=1)                                   # (N, 2F, H, W)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    planar = host(backend, out)
+    assert np.abs(planar - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    xil = np.ascontiguousarray(x.reshape(n, 2 * f // 4, 4, h, w).transpose(0, 1, 3, 4, 2))
+    for yi in (0, 1):
+        plan.set_layouts(1, yi, 0)
+        out = empty(backend, il4_dm(ref).shape if yi else ref.shape, False)
+        plan.enqueue(dev32(backend, xil), out, None, n)
+        got = host(backend, out)
+        assert np.array_equal(un_il4_dm(got) if yi else got, planar), yi
     plan.destroy()
 
 
