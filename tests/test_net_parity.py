@@ -376,10 +376,10 @@ def test_resnet18_2d_full_size(w, h, batch):
     err = (out.cpu() - ref).abs().max().item()
     print("ResNet-18 2D %dx%d batch %d, real weights: max |disp - oracle| = %.3g, %d launches" % (w, h, batch, err, net.num_launches))
     assert err <= 1e-3, err
-    # at 1257x369 the executor runs 15 of the 16 residual blocks as one (streaming) launch each (48 -> 33) and blocks 2-8 + encoder2D_out of
-    # the two towers as one launch over both images (siamese merge: 33 -> 25); at 513x257 no block is fused (too few strips) and the 14
-    # block convolutions + encoder2D_out pair up (48 -> 33)
-    assert net.num_launches == (25 if w >= 1241 else 33), net.num_launches
+    # at 1257x369 the executor runs the 16 residual blocks as one (streaming) launch each (48 -> 32) and blocks 1-8 + encoder2D_out of
+    # the two towers as one launch over both images (siamese merge: 32 -> 23; round 3: 25, the left tower's first block read a planar member
+    # of conv2D_1's concatenation); at 513x257 no block is fused (too few strips) and the 16 block convolutions + encoder2D_out pair up (48 -> 31)
+    assert net.num_launches == (23 if w >= 1241 else 31), net.num_launches
     net.destroy()
 
 
