@@ -49,10 +49,9 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16R4_WAVES) conv_f16r
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    RT_WG_TILE(p, tile, zi, n)
+    RT_WG_TILE_NB(p, tile, zi, n, nblk)
     const int tx0 = (tile % p.tiles_x) * Cfg::TX;
     const int ty0 = (tile / p.tiles_x) * Cfg::TY;
-    const int nblk = blockIdx.y;
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
     const int nchunks = p.CinPad / Cfg::CC;
     const int Ho = p.Ho, Wo = p.Wo;

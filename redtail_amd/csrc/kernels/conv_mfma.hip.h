@@ -90,19 +90,26 @@ struct ConvArgs {
     // of the same image tile: the slices a 3x3x3 window shares are served by that XCD's L2 instead of being fetched three times
     // (round 4, PMC: conv3D_2 of NVSmall fetched 836 MB for a 254 MB input with z outermost).
     int z_inner;
+    // > 0: the blocks of 32 output channels are folded into grid.x as well and run fastest of all -- the nb_inner workgroups that read
+    // the SAME input patch follow each other on one XCD, so that patch comes from HBM once instead of once per block (round 4, PMC:
+    // the stride-2 Conv3D 32 -> 64 of NVSmall half2 fetched 839 MB for a 254 MB input at 6.6 TB/s of fabric traffic).  0: grid.y.
+    int nb_inner;
 };
 
 // workgroup -> (tile of the output plane, z-slice, sample)
-#define RT_WG_TILE(p, tile, zi, n)                                                                  \
+#define RT_WG_TILE_NB(p, tile, zi, n, nblk)                                                         \
     int tile = blockIdx.x;                                                                          \
     if ((p).xcd_order) {                          /* contiguous range per XCD (see conv_mfma_f32_kernel) */ \
         const int nwg_ = gridDim.x, q_ = nwg_ >> 3, r_ = nwg_ & 7;                                  \
         const int xcd_ = blockIdx.x & 7, idx_ = blockIdx.x >> 3;                                    \
         tile = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + idx_;             \
     }                                                                                               \
+    int nblk = blockIdx.y;                                                                          \
+    if ((p).nb_inner > 0) { nblk = tile % (p).nb_inner; tile /= (p).nb_inner; }                     \
     int zi, n;                                                                                      \
     if ((p).z_inner) { zi = tile % (p).nz; tile /= (p).nz; n = blockIdx.z; }                        \
     else { zi = blockIdx.z % (p).nz; n = blockIdx.z / (p).nz; }
+#define RT_WG_TILE(p, tile, zi, n) RT_WG_TILE_NB(p, tile, zi, n, nblk_unused_); (void)nblk_unused_;
 
 // Optional in-kernel phase timing (tools/time_phases.py builds a separate library with
 // -DRT_KERNEL_TIMING): thread 0 stamps s_memtime at phase boundaries.  Compiles to nothing otherwise.

@@ -373,10 +373,9 @@ __global__ void __launch_bounds__(64 * NW * (S3Cfg<KH, KW, S, NW>::KS_MAX)) RT_W
     const int kg = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    RT_WG_TILE(p, tile, zi, n)
+    RT_WG_TILE_NB(p, tile, zi, n, nblk)
     const int tx0 = (tile % p.tiles_x) * TX;
     const int ty0 = (tile / p.tiles_x) * TY;
-    const int nblk = blockIdx.y;
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ESX);
     const int nchunks = p.CinPad / CC;
     int pad_y = p.pad_y, pad_x = p.pad_x, Ho = p.Ho, Wo = p.Wo, ch_row = zi;

@@ -552,7 +552,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -2153,9 +2153,11 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             plan->opt_rb_tiles = exp_knob("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
             plan->opt_zinner = env_int("RT_Z_INNER", 1);     // 3-D launches: depth slices fastest inside a tile (ConvArgs::z_inner); 0 = z outermost
+            plan->opt_nbinner = env_int("RT_NB_INNER", 1);  // 3-D launches: blocks of 32 output channels fastest (ConvArgs::nb_inner); 0 = grid.y
             plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
         });
         rt::ConvArgs a;
+        a.z_inner = 0; a.nb_inner = 0;
         a.x = static_cast<const float*>(x);
         a.y = static_cast<float*>(y);
         a.w = sc.w_dev;
@@ -2206,7 +2208,12 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         const bool zin = sc.nz > 1 && plan->opt_zinner != 0 && (sc.f16mma || (sc.split3 && plan->opt_zinner == 2)) &&
                          (int64_t)rt::cdiv(sc.Wo, 32 * sc.TXW) * rt::cdiv(sc.Ho, sc.TY) * sc.nz < (1ll << 30);
         a.z_inner = zin ? 1 : 0;
-        auto zfold = [&](dim3 g) { return zin ? dim3(g.x * (unsigned)sc.nz, g.y, (unsigned)batch) : g; };
+        // ... and 3-D launches with several blocks of 32 output channels fold those in as well, fastest of all (ConvArgs::nb_inner)
+        int nb_fold = 0;
+        auto zfold = [&](dim3 g) {
+            if (zin) g = dim3(g.x * (unsigned)sc.nz, g.y, (unsigned)batch);
+            return nb_fold ? dim3(g.x * g.y, 1u, g.z) : g;
+        };
         RT_REQUIRE(zin ? batch <= 65535 : gz <= 65535, "rt_conv_enqueue: batch * depth = %lld exceeds the grid limit", (long long)gz);
         RT_REQUIRE(sc.y_cstride * (int64_t)sc.Cout < (1ll << 29), "rt_conv_enqueue: output sample exceeds 2 GB (32-bit buffer offsets)");
         if (sc.direct) {
@@ -2243,6 +2250,10 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         }
 #endif
         dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)rt::cdiv(sc.Cout, 32 * sc.NBW), (unsigned)gz);
+        if (!plan->is2d && grid.y > 1 && plan->opt_nbinner != 0 && (sc.f16mma || sc.split3) && !sc.rb && sc.NBW == 1 &&
+            (int64_t)grid.x * grid.y * (zin ? sc.nz : 1) < (1ll << 30))
+            nb_fold = (int)grid.y;
+        a.nb_inner = nb_fold;
         if (sc.rb) {
             rt::RBArgs ra;
             ra.c = a;
