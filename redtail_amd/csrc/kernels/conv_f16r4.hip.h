@@ -2,13 +2,15 @@
 //
 // conv_f16mma_kernel (conv_f16.hip.h) gives every wave one row of a 4 x 32 tile: per tap and 16-channel chunk it reads its A operand
 // (weights) AND its B operand (patch pixels) from LDS for ONE v_mfma_f32_32x32x16_f16 -- 2 KB of LDS reads per 32-cycle MFMA and wave,
-// i.e. 256 B/clk per CU with the four SIMDs busy, against the 128 B/clk the LDS delivers: the Conv3D layers of the 3-D models in half2
-// mode (BASELINE C5: 27 * C * K multiplies per voxel, 1.5 of NVSmall's 2.7 ms) sat at 0.30-0.33 of the fp16 matrix peak, LDS-bound.
+// i.e. 256 B/clk per CU with the four SIMDs busy, which is all the LDS delivers (MI355X_MICROARCH.md: ds_read_b128, 256 B/clk): the
+// Conv3D layers of the 3-D models in half2 mode (BASELINE C5: 27 * C * K multiplies per voxel, 1.5 of NVSmall's 2.7 ms) sat at
+// 0.30-0.33 of the fp16 matrix peak.  MEASURED (round 4): this kernel is 3-6 % faster than that one on those layers and sits at 50-53 %
+// MFMA-busy (profiles/r04_traffic_3d.json) -- the layers were not LDS-bandwidth-bound; what the bigger tile buys is halo and weight traffic.
 //
 // Here a wave owns 4 output rows x 32 pixels x 32 output channels (4 accumulators = 64 VGPRs) of a 16 x 32 workgroup tile:
 //   * for a column shift s the three weight operands A[r][s] (r = 0..2) are read once and stay in 12 VGPRs;
 //   * patch row p (0..5) at shift s is read once and feeds every (output row y, tap row r) with y + r = p: up to 3 MFMAs;
-//   => 27 ds_read_b128 for 36 MFMAs per chunk (0.75 instead of 2 per MFMA): the contraction is MFMA-bound, not LDS-bound;
+//   => 27 ds_read_b128 for 36 MFMAs per chunk (0.75 instead of 2 per MFMA);
 //   * the 16-row tile reads 18 x 34 patch pixels for 16 x 32 outputs (1.19x halo instead of 1.59x for the 4-row tile);
 //   * chunks are double-buffered in LDS (2 x 28.8 KB, two workgroups per CU): the next chunk's global loads fly under the MFMAs and
 //     land in the other buffer -- one barrier per chunk.
