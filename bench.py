@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
-network (33 launches at this size) with the inputs already resident in HBM (the reference times
+network (23 launches at this size) with the inputs already resident in HBM (the reference times
 context->execute the same way, sample_app/main.cpp:303-309).  Steps are issued round-robin over
 --contexts execution contexts of the same engine configuration, each on its own stream (default 6 with one
 HIP stream each, the TensorRT throughput set-up `trtexec --streams`): the serial low-resolution tail of one pair
@@ -16,8 +16,9 @@ share nothing but the weights: rank 0 builds the weight-file image and broadcast
 processes its own K pairs).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = conv_s3_kernel<3,3,1,il,il> (the 34 residual-block 3x3 32->32 convolutions at 629x185 = 79 %
-                of the network's FLOPs and ~85 % of its GPU time): fp32 tensors, 3-term fp16 split on
+  roofline      dominant kernel = conv_s3rbs_kernel, one launch per residual block of the feature towers over both images (the 32
+                3x3 32->32 convolutions at 629x185 = 79 % of the network's FLOPs, ~55-60 % of its GPU time; layer by layer with
+                RT_RB=0: conv_s3_kernel<3,3,1,il,il>): fp32 tensors, 3-term fp16 split on
                 v_mfma_f32_32x32x16_f16 with fp32 accumulation.  At 16x the fp32 matrix rate the layer is bound by moving its
                 tensors, so the object is priced in ALGORITHMIC bytes per launch (x + residual + y + weights + bias, each once,
                 SURVEY.md 8d) / average launch duration measured with HIP events on the launch stream (IProfiler path of the
