@@ -186,8 +186,9 @@ def _area_table(ssize, dsize):
 
 def preprocess_bgr8(img_u8, dst_h, dst_w):
     """readImgFile (sample_app/main.cpp:83-98): u8 BGR HWC -> float32, cv::resize(INTER_AREA), BGR -> RGB, HWC -> CHW,
-    / 255.  PARITY UNPINNED: OpenCV is not available in this environment, the area filter restates its published
-    table construction; only shrinking / same size (what the apps do with KITTI frames)."""
+    / 255.  PARITY UNPINNED against OpenCV itself (not available in this environment): the area filter restates its published
+    table construction; tests/test_oracle_golden.py pins it to the overlap integrals the filter stands for (7.9e-4 max: the taps
+    OpenCV drops below a weight of 1e-3).  Only shrinking / same size (what the apps do with KITTI frames)."""
     sh, sw, _ = img_u8.shape
     x = img_u8.astype(np.float64)
     if (sh, sw) != (dst_h, dst_w):

@@ -247,3 +247,35 @@ def test_deconv2d_oracle_against_plain_tf_definition(hy, wy, H, W, k_in, c_out, 
     got = O.deconv2d(T(np.transpose(y, (0, 3, 1, 2))).double(), T(_rsck_to_kcrs(f)).double(), T(b).double(), stride, pad_h[0]).numpy()
     assert got.shape == (2, c_out, H, W)
     assert np.abs(np.transpose(got, (0, 2, 3, 1)) - want).max() <= 1e-12
+
+
+# ---- a second witness for the INTER_AREA restatement (readImgFile, sample_app/main.cpp:83-98; SURVEY 8f-3: no OpenCV here) -------------
+def _area_integral(x, dsize):
+    """shrinking by area averaging, stated as what it IS: destination pixel d is the mean of the piecewise-constant source signal over
+    [d s, (d + 1) s), s = ssize / dsize, clipped to the image -- exact overlap integrals in fp64, no table, no thresholds"""
+    ssize = x.shape[0]
+    s = ssize / dsize
+    edges = np.arange(ssize + 1, dtype=np.float64)
+    out = np.empty((dsize,) + x.shape[1:], np.float64)
+    for d in range(dsize):
+        a, b = d * s, min((d + 1) * s, float(ssize))
+        w = np.clip(np.minimum(edges[1:], b) - np.maximum(edges[:-1], a), 0.0, None)      # overlap of [a, b) with source pixel [i, i + 1)
+        out[d] = np.tensordot(w, x, axes=(0, 0)) / (b - a)
+    return out
+
+
+@pytest.mark.parametrize("src,dst", [((375, 1242), (321, 1025)), ((50, 97), (9, 17)), ((40, 66), (20, 33)), ((370, 1226), (369, 1225))])
+def test_inter_area_restatement_against_overlap_integrals(src, dst):
+    """oracle.preprocess_bgr8 restates OpenCV's computeResizeAreaTab (taps with weights below 1e-3 are dropped there without
+    renormalising); the area average it implements is pinned here by the overlap integrals themselves.  Not a substitute for cv::resize
+    on real KITTI frames (SURVEY 8f-3 stays 'unpinned against OpenCV'), but an independent statement of the same filter."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=src + (3,), dtype=np.uint8)
+    got = O.preprocess_bgr8(img, *dst).astype(np.float64)                                    # (3, dh, dw), RGB, / 255
+    x = img.astype(np.float64)
+    ref = _area_integral(_area_integral(x, dst[0]).transpose(1, 0, 2), dst[1]).transpose(1, 0, 2)      # rows, then columns
+    ref = ref[:, :, ::-1].transpose(2, 0, 1) / 255.0
+    # a dropped tap carries < 1e-3 of a source pixel's weight out of a cell of >= 1 pixel, per axis
+    # (measured: 7.9e-4 max / 8e-7 mean at 1242x375 -> 1025x321, 3e-8 where no tap falls under the threshold)
+    assert np.abs(got - ref).max() <= 1.5e-3, np.abs(got - ref).max()
+    assert np.abs(got - ref).mean() <= 1e-5
