@@ -27,6 +27,9 @@ struct Deconv3dSmallArgs {
     int xp, yp;            // row pitch (elements) of the input / output planes (2-D plans may be re-pitched)
     int act;
     int64_t x_bstride, y_bstride;
+    int z_inner;           // 3-D form: grid.x = x-groups * Mz, the depth block fastest inside a contiguous range per XCD (grid.z = batch): the
+                           // workgroups an XCD runs side by side are depth neighbours and share an input slice through its L2 (round 4;
+                           // PMC with z outermost: 2.3 GB fetched for NVSmall's 254 MB fp32 input)
     int sparse;            // 0: weights packed [K][COUT][phase][neighbour]; 1 + PAT: [K][COUT][27] (2-D: 9), only the pairs that carry a tap (SmallTaps<Z, PAT>)
 };
 
@@ -66,9 +69,14 @@ template <int COUT, bool Z = true, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArgs p) {
     constexpr int NJ = Z ? 8 : 4;          // neighbours = phases per block
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
-    const int mx = blockIdx.x * 256 + threadIdx.x;
+    int bxg = blockIdx.x, mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
+    if (Z && p.z_inner) {
+        const int nwg = gridDim.x, q_ = nwg >> 3, r_ = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int lin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
+        mz = lin % p.Mz; bxg = lin / p.Mz; n = blockIdx.z;
+    }
+    const int mx = bxg * 256 + threadIdx.x;
     const int my = blockIdx.y;
-    const int mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
 
     // the 8 neighbours of this block in one input channel
     unsigned voff[NJ];

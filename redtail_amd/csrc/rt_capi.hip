@@ -25,6 +25,7 @@
 #include "kernels/deconv_f16p.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
+#include "kernels/deconv_s3p.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/corr_mfma.hip.h"
 #include "kernels/elementwise.hip.h"
@@ -1380,6 +1381,14 @@ bool deconv3d_dp4_ok(const rtConvPlan* plan) {
            d.W == 2 * plan->in_dims3[2] - 1 && d.H >= 2 && d.W >= 2 && d.C % 8 == 0 && d.K % 8 == 0 && env_int("RT_NO_DECONV_P4", 0) == 0;
 }
 
+// fp32 tensors: the four-phase kernel in split-fp16 form (deconv_s3p.hip.h) -- planar input and output, the same geometry
+bool deconv3d_p4f32_ok(const rtConvPlan* plan) {
+    const rtConv3dDesc& d = plan->desc3d;
+    return d.kernel[1] == 3 && d.kernel[2] == 3 && d.stride[1] == 2 && d.stride[2] == 2 && d.pad_start[1] == 1 && d.pad_start[2] == 1 &&
+           d.H == 2 * plan->in_dims3[1] - 1 && d.W == 2 * plan->in_dims3[2] - 1 && d.H >= 2 && d.W >= 2 && d.C > 2 && (plan->flags & RT_CONV_EXACT_FP32) == 0 &&
+           !plan->w_f16 && env_int("RT_NO_DECONV_P4F32", 0) == 0;
+}
+
 int build_deconv3d_subs(rtConvPlan* plan, bool f16mma, bool dp4 = false) {
     const rtConv3dDesc* d = &plan->desc3d;
     const std::vector<float>& w = plan->w_canon;
@@ -1423,6 +1432,42 @@ int build_deconv3d_subs(rtConvPlan* plan, bool f16mma, bool dp4 = false) {
         if (f16mma) {
             if (!sc.split3 || sc.direct) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: no fp16-operand form for this window"); break; }
             sc.split3 = 0; sc.f16mma = 1; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
+        }
+        if (!f16mma && dp4 && sc.split3 && !sc.direct) {      // (not the split kernel -- exact fp32 arithmetic: the phase form below)
+            // fp32 tensors, four phases per workgroup (deconv_s3p.hip.h): split slabs in kernel order, planar gather table, one ZSlice per output depth
+            sc.dp4 = 1; sc.KH = sc.KW = 3; sc.nz = nzd; sc.CC = 16; sc.NBW = 1; sc.TXW = 1; sc.TY = sc.NW = 4;
+            sc.Ho = Hx; sc.Wo = Wx;
+            sc.CinPad = rt::round_up(cin_real, sc.CC);
+            if (sc.CinPad > 512) { rc = fail(RT_E_UNSUPPORTED, "conv3d_transpose: unsupported shape"); break; }
+            std::vector<float> packed;
+            pack_into(packed, sc, cin_real, [&](int co, int ci, int u, int v) {
+                if (az.K == 0) return 0.f;
+                const int j = ci / K, k = ci % K;
+                return w[((((size_t)k * V + az.tap[j]) * C + co) * R + u) * Sk + v];            // KVCRS, kernel taps as they are
+            });
+            std::vector<rt::ZSlice> zs;
+            for (int m = 0; m < nzd; m++) {
+                rt::ZSlice z{};
+                const int64_t dx = cls + m * sd;
+                z.ch_row = m;
+                z.r_off = dx * C * out_plane; z.r_off_il8 = z.r_off; z.r_off_il4 = z.r_off;
+                z.y_off = cdhw ? dx * out_plane : z.r_off;
+                z.y_off_il8 = z.y_off;
+                zs.push_back(z);
+            }
+            std::vector<int> table((size_t)nzd * sc.CinPad, -1);
+            for (int m = 0; m < nzd; m++)
+                for (int j = 0; j < az.K; j++) {
+                    const int dy = m + j - az.pad;
+                    if (dy < 0 || dy >= Dy) continue;
+                    for (int k = 0; k < K; k++) table[(size_t)m * sc.CinPad + j * K + k] = (int)(((int64_t)k * Dy + dy) * in_plane);
+                }
+            if (hipMalloc((void**)&sc.w_dev, packed.size() * 4) != hipSuccess || hipMemcpy(sc.w_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(RT_E_NOMEM, "conv3d_transpose: device allocation failed");
+            if (!rc) rc = upload_zslices(sc, zs);
+            if (!rc) rc = upload_table(sc, table);
+            plan->subs.push_back(sc);
+            continue;
         }
         if (f16mma && dp4) {
             // one workgroup = a 4 x 32 tile of the input grid, all four phases: weights in kernel order (3 x 3 taps), one ZSlice per output depth
@@ -1611,7 +1656,7 @@ extern "C" int rt_conv3d_transpose_plan_create(rtConvPlan** out, const rtConv3dD
     for (int i = 0; i < 3; i++) plan->in_dims3[i] = in_dims[i];
     plan->w_canon = w;                                         // KVCRS: the launches are rebuilt from it when the plan changes kernels
     plan->is_deconv3d = 1; plan->c3d_C = C;
-    rc = build_deconv3d_subs(plan, false);
+    rc = build_deconv3d_subs(plan, false, deconv3d_p4f32_ok(plan));
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, C, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, C);
@@ -1838,8 +1883,11 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
         const bool both = x_dtype == RT_F16 && y_dtype == RT_F16;
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
-        if (plan->is_deconv3d && !plan->subs.empty() && plan->subs[0].f16mma)        // back to the split kernel and planar tensors first
-            if (int rc = build_deconv3d_subs(plan, false)) return rc;
+        if (plan->is_deconv3d && !plan->subs.empty() && !plan->subs[0].small3d) {   // back to the split kernel and planar tensors first
+            const bool p4 = x_dtype == RT_F32 && y_dtype == RT_F32 && deconv3d_p4f32_ok(plan);      // (fp32 tensors: its four-phase form)
+            if (plan->subs[0].f16mma || (plan->subs[0].dp4 != 0) != p4)
+                if (int rc = build_deconv3d_subs(plan, false, p4)) return rc;
+        }
         for (SubConv& sc : plan->subs) {
             // (an fp16 input with an fp32 output has no kernel: ADVICE r02 -- say so here, not at the first enqueue)
             const bool ok = sc.small3d ? (sc.small3d == 1 && y_dtype == RT_F32) : (sc.f16mma ? both : (sc.split3 && (y_dtype == RT_F16 || x_dtype == RT_F32)));
@@ -1989,7 +2037,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
         if (plan->is_deconv3d && !plan->subs.empty() && plan->subs[0].f16mma) {
             const int xf = plan->subs[0].x_f16, yf = plan->subs[0].y_f16;
-            if (int rc = build_deconv3d_subs(plan, false)) return rc;
+            if (int rc = build_deconv3d_subs(plan, false, !xf && !yf && deconv3d_p4f32_ok(plan))) return rc;
             for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
         }
         for (SubConv& sc : plan->subs) sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
@@ -2030,7 +2078,8 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
             sc.x_il8 = x_il8 != 0;
             return 0;
         }
-        const bool want = x_il8 != 0, want_dp = want && y_il8 && deconv3d_dp4_ok(plan);
+        const bool f32 = !plan->subs[0].x_f16 && !plan->subs[0].y_f16;
+        const bool want = x_il8 != 0, want_dp = want ? (y_il8 && deconv3d_dp4_ok(plan)) : (f32 && deconv3d_p4f32_ok(plan));
         if ((plan->subs[0].f16mma != 0) != want || (plan->subs[0].dp4 != 0) != want_dp) {
             const int xf = plan->subs[0].x_f16, yf = plan->subs[0].y_f16;
             if (int rc = build_deconv3d_subs(plan, want, want_dp)) return rc;
@@ -2121,6 +2170,11 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             const int64_t gz = (int64_t)batch * a.Mz;
             RT_REQUIRE(gz <= 65535 && (a.Hx + 1) / 2 <= 65535, "rt_conv_enqueue: grid limit exceeded");
             dim3 grid((unsigned)rt::cdiv((a.Wx + 1) / 2, 256), (unsigned)((a.Hx + 1) / 2), (unsigned)gz);
+            a.z_inner = 0;
+            if (sc.small3d == 1 && a.Mz > 1 && batch <= 65535 && env_int("RT_SMALL_Z_INNER", 1) != 0) {   // 3-D: depth blocks fastest (Deconv3dSmallArgs::z_inner)
+                a.z_inner = 1;
+                grid = dim3(grid.x * (unsigned)a.Mz, grid.y, (unsigned)batch);
+            }
             if (sc.small3d == 2 && sc.x_f16) {          // half2 mode: fp16 activations in, fp32 (binding) or fp16 out
                 if (sc.y_f16) {
                     if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
@@ -2188,6 +2242,18 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         a.r_bstride = plan->r_bstride ? plan->r_bstride : plan->y_bstride;
         a.r_il8 = sc.r_il8;
         a.batch = batch; a.cin_real = sc.cin_real; a.x_cstride = (int64_t)sc.Hi * a.x_pitch;
+        if (sc.dp4 && sc.split3) {     // fp32 tensors: four phases per workgroup in split-fp16 form (deconv_s3p.hip.h), planar input and output
+            a.tiles_x = (int)rt::cdiv(sc.Wi, 32);
+            const int tiles = a.tiles_x * (int)rt::cdiv(sc.Hi, 4), nblk = (int)rt::cdiv(sc.Cout, 32);
+            RT_REQUIRE(!sc.x_il8 && !sc.y_il8 && !sc.x_f16 && !sc.y_f16, "rt_conv_enqueue: the fp32 four-phase transposed kernel takes planar fp32 tensors");
+            RT_REQUIRE((int64_t)batch * sc.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
+            RT_REQUIRE(sc.y_cstride * (int64_t)sc.Cout < (1ll << 29), "rt_conv_enqueue: output sample exceeds 2 GB (32-bit buffer offsets)");
+            dim3 g((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * sc.nz));
+            if (plan->opt_trace) fprintf(stderr, "[rt] deconv_s3p grid %u x %u x %u r%d\n", g.x, g.y, g.z, sc.r_il8);
+            hipLaunchKernelGGL(rt::deconv_s3p_kernel, g, dim3(256), 0, S(s), a);
+            RT_LAUNCH_CHECK("deconv_s3p_kernel");
+            continue;
+        }
         if (sc.dp4) {          // transposed 3-D convolution, four phases per workgroup (deconv_f16p.hip.h): tiles of the INPUT grid, one z per output depth
             a.tiles_x = (int)rt::cdiv(sc.Wi, 32);
             const int tiles = a.tiles_x * (int)rt::cdiv(sc.Hi, 4), nblk = (int)rt::cdiv(sc.Cout, 32);

@@ -378,3 +378,54 @@ def test_conv3d_transpose_fp32_reads_an_interleaved_skip_tensor(backend, K, C, y
     plan.enqueue(dev32(backend, y), out, dev32(backend, il4_dm(sk)), n)
     assert np.array_equal(host(backend, out), planar)
     plan.destroy()
+
+
+P4F32_CASES = [
+    # K, C, (Dy, Hy, Wy), out depth computed (full), kept, pad_d, skip (0 none, 1 planar, 2 interleaved), cdhw
+    (16, 8, (3, 4, 19), 7, 6, 0, 2, True),        # NVSmall's decoder pattern: depth pad 0, surplus slice dropped, fused Transform
+    (16, 8, (3, 4, 19), 7, 6, 0, 1, False),       # planar skip tensor, no Transform
+    (8, 16, (3, 5, 9), 5, 5, 1, 2, True),         # depth pad 1 (odd depth), K = 8: a half-empty chunk
+    (24, 40, (2, 3, 17), 3, 3, 1, 0, True),       # no skip tensor, two blocks of output channels (the second with 8), K not a multiple of 16
+    (32, 32, (2, 6, 33), 5, 4, 0, 2, False),      # two 32-pixel tiles across (the second holds one column: the unpaired last output pixel), 2 row tiles
+    (5, 3, (1, 1, 1), 1, 1, 1, 1, False),         # a single voxel, odd channel counts
+]
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw", P4F32_CASES)
+def test_conv3d_transpose_fp32_four_phases_per_workgroup(backend, monkeypatch, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw):
+    """deconv_s3p_kernel (fp32 tensors, 3-term fp16 split, all four output phases of a 4 x 32 input tile per workgroup, 8-byte stores of
+    pixel pairs at 4-byte aligned addresses) against the oracle and -- bit for bit -- against the one-launch-per-phase form it replaces"""
+    if skip == 2 and C % 4:
+        pytest.skip("interleaved skip tensor needs whole groups")
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y, w, b = rnd(n, K, dy, hy, wy), rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)), rnd(C)
+    sk = rnd(n, dkeep, C, hx, wx) if skip else None
+    ps = (pad_d, 1, 1)
+    ref = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    if skip:
+        ref = ref + T(sk).double()
+    ref = O.elu(ref)
+    if cdhw:
+        ref = O.transform(ref)
+    ref = ref.numpy()
+    outs = []
+    monkeypatch.setenv("RT_S3_KSPLIT", "0")         # (the phase form would split the contraction of so small a launch over wave groups: another order)
+    for p4 in ("0", "1"):
+        monkeypatch.setenv("RT_NO_DECONV_P4F32", p4)
+        plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
+                                        has_residual=bool(skip), transposed_in_dims=ydims, out_depth=dkeep)
+        if skip == 2:
+            assert plan.il_caps() == 4
+            plan.set_layouts(0, 0, 1)
+        out = empty(backend, ref.shape, False)
+        plan.enqueue(dev32(backend, y), out, dev32(backend, il4_dm(sk) if skip == 2 else sk) if skip else None, n)
+        got = host(backend, out)
+        assert not np.isnan(got).any()
+        outs.append(got)
+        plan.destroy()
+    tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
+    assert np.abs(outs[1] - ref).max() <= tol
+    assert np.array_equal(outs[0], outs[1])              # the same arithmetic, operation for operation
