@@ -11,6 +11,7 @@
 //   the buffer range check returns zeros), channel stride in an SGPR.
 #pragma once
 #include "common.hip.h"
+#include "conv_split.hip.h"
 
 namespace rt {
 
@@ -27,9 +28,6 @@ struct Deconv3dSmallArgs {
     int xp, yp;            // row pitch (elements) of the input / output planes (2-D plans may be re-pitched)
     int act;
     int64_t x_bstride, y_bstride;
-    int z_inner;           // 3-D form: grid.x = x-groups * Mz, the depth block fastest inside a contiguous range per XCD (grid.z = batch): the
-                           // workgroups an XCD runs side by side are depth neighbours and share an input slice through its L2 (round 4;
-                           // PMC with z outermost: 2.3 GB fetched for NVSmall's 254 MB fp32 input)
     int sparse;            // 0: weights packed [K][COUT][phase][neighbour]; 1 + PAT: [K][COUT][27] (2-D: 9), only the pairs that carry a tap (SmallTaps<Z, PAT>)
 };
 
@@ -69,14 +67,11 @@ template <int COUT, bool Z = true, typename TIN = float, typename TOUT = float>
 __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArgs p) {
     constexpr int NJ = Z ? 8 : 4;          // neighbours = phases per block
     constexpr unsigned ESX = Io<TIN>::ES, ESY = Io<TOUT>::ES;
-    int bxg = blockIdx.x, mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
-    if (Z && p.z_inner) {
-        const int nwg = gridDim.x, q_ = nwg >> 3, r_ = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int lin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
-        mz = lin % p.Mz; bxg = lin / p.Mz; n = blockIdx.z;
-    }
-    const int mx = bxg * 256 + threadIdx.x;
+    // (depth blocks fastest per XCD, as deconv3d_s2_il_kernel orders them, was measured on this kernel in round 4: 0.402 ms either way
+    //  for NVSmall's fp32 last layer -- it is bound by its per-channel 4-byte loads, not by where they are served from)
+    const int mx = blockIdx.x * 256 + threadIdx.x;
     const int my = blockIdx.y;
+    const int mz = blockIdx.z % p.Mz, n = blockIdx.z / p.Mz;
 
     // the 8 neighbours of this block in one input channel
     unsigned voff[NJ];
@@ -240,6 +235,111 @@ __global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p
                 const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
                 const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
                 f32x2_t o = {acc[row][2 * fy], acc[row][2 * fy + 1]};
+                if (has_r) {
+                    const f32x2_t r2 = buf_load2(rs_r, v2, 0);
+                    const float r1 = buf_load(rs_r, v1, 0);
+                    o[0] += r2[0] + r1;
+                    o[1] += r2[1];
+                }
+                o[0] = apply_act_rt(o[0], p.act);
+                o[1] = apply_act_rt(o[1], p.act);
+                buf_store2(o, rs_y, v2, 0);
+                buf_store(o[0], rs_y, v1, 0);
+            }
+        }
+    }
+}
+
+// ---- ... and for fp32 engines: input (K/4, Dy, Hy, Wy, 4) fp32, 3-term fp16 split ---------------------------------------------------------
+// The vector-ALU kernel at the top reads its fp32 input with one 4-byte load per channel and neighbour (NVSmall: 0.40 ms for 254 MB in +
+// 127 MB out; PMC: 2.3 GB through the L2).  With the layer's input channel-interleaved in groups of 4 (written that way by
+// deconv_s3p_kernel<true>), a lane's 8 channels of a neighbour are two 16-byte slots; they are split into fp16 high / low parts in
+// registers (s3_split: 5 vector instructions per pair) and multiplied as in conv_split.hip.h -- A_hi B_hi into the main accumulator,
+// A_lo B_hi + A_hi B_lo into the cross accumulator (scaled by 2^11) -- so the result has fp32-class accuracy like every other layer
+// of an fp32 engine.  Same tile shape, workgroup order and epilogue as deconv3d_s2_il_kernel; weights: [hi / lo][j][KC][64 lanes][8].
+__global__ void __launch_bounds__(256) deconv3d_s2_il4_kernel(Deconv3dSmallArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q_ = nwg >> 3, r_ = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
+    }
+    const int mz = lin % p.Mz, bx = lin / p.Mz;
+    const int my0 = 2 * blockIdx.y, n = blockIdx.z;
+    const int KC = p.K / 32;
+    const int ngroups = (int)cdiv((p.Wx + 1) / 2, 16);
+    const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 4));
+    const buf_rsrc rs_w = make_buf(p.w);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride, 4));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.y_bstride, 4), p.resid != nullptr);
+    const unsigned gstride = (unsigned)(p.Dy * p.Hy * p.xp) * 16u;           // bytes between groups of 4 channels
+    const int co = q >> 1, fz = q & 1;
+    const float bias = co < p.C ? p.bias[co] : 0.f;
+    const bool has_r = p.resid != nullptr;
+    const int nrows = (p.Hx + 1) / 2;
+
+    f32x4 ah0[8], al0[8];                                          // K = 32: the weight operands stay in registers
+    if (KC == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            ah0[j] = buf_load4(rs_w, (unsigned)(j * 64 + lane) * 16u, 0);
+            al0[j] = buf_load4(rs_w, (unsigned)((8 + j) * 64 + lane) * 16u, 0);
+        }
+    }
+    for (int it = 0; it < kSmallIlIters; it++) {
+        const int grp = (bx * 4 + wv) * kSmallIlIters + it;
+        if (grp >= ngroups) break;
+        const int mx = grp * 16 + n16;
+        f32x4 acc_m[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
+        f32x4 acc_c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int kc = 0; kc < KC; kc++) {
+#pragma unroll
+            for (int jz = 0; jz < 2; jz++) {                        // one depth neighbour at a time: 6 positions x (hi, lo) live
+                f16x8_small bh[3][2], bl[3][2];
+#pragma unroll
+                for (int ry = 0; ry < 3; ry++)
+#pragma unroll
+                    for (int jx = 0; jx < 2; jx++) {
+                        const int iz = mz + p.bz + jz, iy = my0 + p.by + ry, ix = mx + p.bx + jx;
+                        const bool ok = iz >= 0 && iz < p.Dy && iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy;
+                        const unsigned vo = (unsigned)((iz * p.Hy + iy) * p.xp + ix) * 16u + (unsigned)(kc * 8 + 2 * q) * gstride;
+                        const S3Split s0 = s3_split(buf_load4(rs_x, ok ? vo : kBufOOB, 0));
+                        const S3Split s1 = s3_split(buf_load4(rs_x, ok ? vo + gstride : kBufOOB, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            bh[ry][jx][e] = s0.hi[e]; bh[ry][jx][4 + e] = s1.hi[e];
+                            bl[ry][jx][e] = s0.lo[e]; bl[ry][jx][4 + e] = s1.lo[e];
+                        }
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = 4 * jz + jj;
+                    const f32x4 avh = KC == 1 ? ah0[j] : buf_load4(rs_w, (unsigned)((j * KC + kc) * 64 + lane) * 16u, 0);
+                    const f32x4 avl = KC == 1 ? al0[j] : buf_load4(rs_w, (unsigned)(((8 + j) * KC + kc) * 64 + lane) * 16u, 0);
+                    const f16x8_small ah = __builtin_bit_cast(f16x8_small, avh), al = __builtin_bit_cast(f16x8_small, avl);
+#pragma unroll
+                    for (int row = 0; row < 2; row++) {
+                        const f16x8_small h = bh[row + ((jj >> 1) & 1)][jj & 1], l = bl[row + ((jj >> 1) & 1)][jj & 1];
+                        acc_m[row] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, h, acc_m[row], 0, 0, 0);
+                        acc_c[row] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, h, acc_c[row], 0, 0, 0);
+                        acc_c[row] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, l, acc_c[row], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int oz = 2 * mz + fz, ox = 2 * mx;
+#pragma unroll
+        for (int row = 0; row < 2; row++) {
+            if (my0 + row >= nrows) break;                         // uniform
+#pragma unroll
+            for (int fy = 0; fy < 2; fy++) {
+                const int oy = 2 * (my0 + row) + fy;
+                const bool row_ok = co < p.C && oz < p.Dx && oy < p.Hx;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
+                const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;
+                const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;
+                f32x2_t o = {fmaf(acc_c[row][2 * fy], kSplitInv, acc_m[row][2 * fy]), fmaf(acc_c[row][2 * fy + 1], kSplitInv, acc_m[row][2 * fy + 1])};
                 if (has_r) {
                     const f32x2_t r2 = buf_load2(rs_r, v2, 0);
                     const float r1 = buf_load(rs_r, v1, 0);

@@ -39,6 +39,9 @@ struct DeconvS3PCfg {
 
 // p.zs: one ZSlice per output depth of the launch's class (offsets of phase (0, 0), gather-table row); p.Ho / p.Wo: the FULL output
 // plane (Hx, Wx) = (2 Hi - 1, 2 Wi - 1); p.y_ystride = 2 * Wx.
+// YIL: the output is channel-interleaved in groups of 4 -- (D, C/4, H, W, 4) or, with the fused Transform, (C/4, D, H, W, 4), the tensor
+// the last layer's matrix-core kernel reads (deconv3d_small.hip.h: deconv3d_s2_il4_kernel); ZSlice::y_off_il8 carries its depth offset.
+template <bool YIL>
 __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(ConvArgs p) {
     using Cfg = DeconvS3PCfg;
     constexpr int NKP = Cfg::NKP, NK_W = Cfg::NK_W, PXB = Cfg::PXB, PC = Cfg::PC;
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(Conv
 
     // ---- epilogue: the lane's 16 channels (4 (2 q + kg) .. + 3, q = 0 .. 3) of output pixels (2 my + py, 2 mx) and (2 my + py, 2 mx + 1) ----
     const bool r_il = p.r_il8 != 0, has_r = p.resid != nullptr;
-    const int64_t ybase = (int64_t)n * p.y_bstride + z.y_off;
+    const int64_t ybase = (int64_t)n * p.y_bstride + (YIL ? z.y_off_il8 : z.y_off);
     const int64_t rbase = (int64_t)n * p.r_bstride + (r_il ? z.r_off_il4 : z.r_off);
     const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
     const int my = ty0 + wv, mx = tx0 + l31;
@@ -185,24 +188,41 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(Conv
                     for (int e = 0; e < 4; e++)
                         sk[px][q][e] = buf_load(rs_r, ((px ? ok1 : ok0) && cb + 8 * q + 4 * kg + e < p.Cout) ? (pix + px + (unsigned)(4 * kg * rs32)) * 4u : kBufOOB,
                                                 (unsigned)((cb + 8 * q + e) * rs32) * 4u);
+        } else {
+#pragma unroll
+            for (int px = 0; px < 2; px++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) sk[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * q + 4 * kg);     // padded to 64 channels
+            f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int c = cb + 8 * q + 4 * kg + e;
                 // (conv_s3_kernel's epilogue, operation for operation: main + cross, then + (bias + skip))
-                float v0 = fmaf(acc_c[2 * py][4 * q + e], kSplitInv, acc_m[2 * py][4 * q + e]);
-                float v1 = fmaf(acc_c[2 * py + 1][4 * q + e], kSplitInv, acc_m[2 * py + 1][4 * q + e]);
-                v0 = apply_act_fast(v0 + (bv[e] + (has_r ? sk[0][q][e] : 0.f)), act);
-                v1 = apply_act_fast(v1 + (bv[e] + (has_r ? sk[1][q][e] : 0.f)), act);
-                const unsigned vo = (pix + (unsigned)(4 * kg * cs32)) * 4u, so = (unsigned)((cb + 8 * q + e) * cs32) * 4u;
-                const bool cok = c < p.Cout;
-                // the pair (2 mx, 2 mx + 1): 8 bytes at a 4-byte aligned address (rows of odd width)
-                const u32x2_t pair = {__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
-                __builtin_amdgcn_raw_buffer_store_b64(pair, rs_y, (ok1 && cok) ? vo : kBufOOB, so, 0);
-                if (right_edge) buf_store(v0, rs_y, (ok0 && !ok1 && cok) ? vo : kBufOOB, so);
+                const float v0 = fmaf(acc_c[2 * py][4 * q + e], kSplitInv, acc_m[2 * py][4 * q + e]);
+                const float v1 = fmaf(acc_c[2 * py + 1][4 * q + e], kSplitInv, acc_m[2 * py + 1][4 * q + e]);
+                o0[e] = apply_act_fast(v0 + (bv[e] + sk[0][q][e]), act);
+                o1[e] = apply_act_fast(v1 + (bv[e] + sk[1][q][e]), act);
+            }
+            if constexpr (YIL) {
+                // the lane's 4 channels are one 16-byte slot of each of its two pixels
+                const bool gok = cb + 8 * q + 4 * kg < p.Cout;
+                const unsigned so = (unsigned)((cb + 8 * q) * cs32) * 4u;
+                buf_store4(o0, rs_y, (ok0 && gok) ? (pix * 4u + (unsigned)(4 * kg * cs32)) * 4u : kBufOOB, so);
+                buf_store4(o1, rs_y, (ok1 && gok) ? ((pix + 1u) * 4u + (unsigned)(4 * kg * cs32)) * 4u : kBufOOB, so);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const unsigned vo = (pix + (unsigned)(4 * kg * cs32)) * 4u, so = (unsigned)((cb + 8 * q + e) * cs32) * 4u;
+                    const bool cok = cb + 8 * q + 4 * kg + e < p.Cout;
+                    // the pair (2 mx, 2 mx + 1): 8 bytes at a 4-byte aligned address (rows of odd width)
+                    const float a0 = o0[e], a1 = o1[e];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 with this clang)
+                    const u32x2_t pair = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(pair, rs_y, (ok1 && cok) ? vo : kBufOOB, so, 0);
+                    if (right_edge) buf_store(a0, rs_y, (ok0 && !ok1 && cok) ? vo : kBufOOB, so);
+                }
             }
         }
     }

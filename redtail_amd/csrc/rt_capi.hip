@@ -543,7 +543,8 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
     int small3d = 0;                    // deconv3d_s2_small_kernel (stride-2 transposed 3x3x3 (1) / 3x3 (2), <= 2 output channels)
     rt::Deconv3dSmallArgs s3{};         // its geometry (pointers filled at enqueue)
     std::vector<float> small_w;         // ... its weights as [K][COUT][phase 8][neighbour 8] before structural zeros are dropped (3-D form)
-    void* small_il_dev = nullptr;       // deconv3d_s2_il_kernel: the MFMA A operands (set when the input becomes channel-interleaved)
+    void* small_il_dev = nullptr;       // deconv3d_s2_il_kernel / _il4_kernel: the MFMA A operands (set when the input becomes channel-interleaved)
+    int small_il_f32 = 0;               // ... built for the fp32 form (hi and lo slabs)
 };
 
 }  // namespace
@@ -1452,7 +1453,7 @@ int build_deconv3d_subs(rtConvPlan* plan, bool f16mma, bool dp4 = false) {
                 z.ch_row = m;
                 z.r_off = dx * C * out_plane; z.r_off_il8 = z.r_off; z.r_off_il4 = z.r_off;
                 z.y_off = cdhw ? dx * out_plane : z.r_off;
-                z.y_off_il8 = z.y_off;
+                z.y_off_il8 = cdhw ? 4 * dx * out_plane : z.r_off;      // (C/4, D, H, W, 4) / (D, C/4, H, W, 4): deconv_s3p_kernel<true>
                 zs.push_back(z);
             }
             std::vector<int> table((size_t)nzd * sc.CinPad, -1);
@@ -1982,12 +1983,19 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
             return 0;
         }
         if (plan->is_deconv3d) {
-            if (sc.small3d)      // last layer: (K/8, Dy, Hy, Wy, 8) fp16 in on the matrix cores (deconv3d_s2_il_kernel), fp32 volume out
-                return (sc.small3d == 1 && sc.x_f16 && !sc.y_f16 && sc.s3.K % 32 == 0 && !sc.small_w.empty() && env_int("RT_NO_SMALL_IL", 0) == 0) ? 1 : 0;
+            if (sc.small3d) {    // last layer: (K/8, Dy, Hy, Wy, 8) fp16 in on the matrix cores (deconv3d_s2_il_kernel), fp32 volume out;
+                                 // fp32 engines: (K/4, Dy, Hy, Wy, 4) fp32 in, split form (deconv3d_s2_il4_kernel)
+                if (sc.small3d != 1 || sc.y_f16 || sc.s3.K % 32 != 0 || sc.small_w.empty() || env_int("RT_NO_SMALL_IL", 0) != 0) return 0;
+                if (!sc.x_f16 && ((plan->flags & RT_CONV_EXACT_FP32) || env_int("RT_NO_IL8_3D_F32", 0) != 0 || env_int("RT_NO_SMALL_IL_F32", 0) != 0)) return 0;
+                return 1;
+            }
             bool all_f32 = true;
             for (const SubConv& q : plan->subs) all_f32 = all_f32 && q.split3 && !q.x_f16 && !q.y_f16 && q.TY == 4;
-            if (all_f32)           // fp32 tensors: the skip tensor (D, C/4, H, W, 4) only (ZSlice::r_off_il4); input and output stay planar
-                return (plan->has_resid && plan->c3d_C % 4 == 0 && env_int("RT_NO_IL8_3D_F32", 0) == 0) ? 4 : 0;
+            if (all_f32) {         // fp32 tensors: the skip tensor (D, C/4, H, W, 4) (ZSlice::r_off_il4); the four-phase form also WRITES an
+                                   // interleaved tensor (for the last layer's matrix-core kernel); the input stays planar
+                if (plan->c3d_C % 4 != 0 || env_int("RT_NO_IL8_3D_F32", 0) != 0) return 0;
+                return (plan->has_resid ? 4 : 0) | (sc.dp4 ? 2 : 0);
+            }
             for (const SubConv& q : plan->subs)
                 if (!(q.split3 || q.f16mma) || !q.y_f16 || q.TY != 4) return 0;
             // fp16 in and out: an interleaved INPUT moves the plan to fp16 operands (conv_f16mma_kernel, 2x2 phase windows), which also
@@ -2058,7 +2066,29 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         RT_REQUIRE(!r_il8 || plan->has_resid, "rt_conv_plan_set_layouts: plan has no residual");
         if (plan->subs[0].small3d) {
             SubConv& sc = plan->subs[0];
+            const bool f32in = !sc.x_f16;
+            if (x_il8 && sc.small_il_dev && sc.small_il_f32 != (f32in ? 1 : 0)) { (void)hipFree(sc.small_il_dev); sc.small_il_dev = nullptr; }
+            if (x_il8 && !sc.small_il_dev && f32in) {
+                // fp32 input: the same lane images twice -- fp16 high parts, then the scaled fp16 low parts (split_f16)
+                const int K = sc.s3.K, CO = sc.Cout, KC = K / 32;
+                std::vector<uint16_t> slab((size_t)2 * 8 * KC * 64 * 8, 0);
+                for (int j = 0; j < 8; j++)
+                    for (int kc = 0; kc < KC; kc++)
+                        for (int l = 0; l < 64; l++)
+                            for (int e = 0; e < 8; e++) {
+                                const int row = l % 16, co = row / 8, f = row % 8, k = kc * 32 + 8 * (l / 16) + e;
+                                if (co >= CO) continue;
+                                uint16_t hi, lo;
+                                split_f16(sc.small_w[(((size_t)k * CO + co) * 8 + f) * 8 + j], hi, lo);
+                                slab[(((size_t)j * KC + kc) * 64 + l) * 8 + e] = hi;
+                                slab[(((size_t)(8 + j) * KC + kc) * 64 + l) * 8 + e] = lo;
+                            }
+                RT_HIP(hipMalloc(&sc.small_il_dev, slab.size() * 2));
+                RT_HIP(hipMemcpy(sc.small_il_dev, slab.data(), slab.size() * 2, hipMemcpyHostToDevice));
+                sc.small_il_f32 = 1;
+            }
             if (x_il8 && !sc.small_il_dev) {
+                sc.small_il_f32 = 0;
                 // A operands of deconv3d_s2_il_kernel: per neighbour j and block of 32 input channels a 16 x 32 tile [row = co * 8 + phase][k],
                 // stored as the MFMA's lane image: lane l holds row l % 16, channels 8 * (l / 16) .. + 7
                 const int K = sc.s3.K, CO = sc.Cout, KC = K / 32;
@@ -2170,11 +2200,6 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             const int64_t gz = (int64_t)batch * a.Mz;
             RT_REQUIRE(gz <= 65535 && (a.Hx + 1) / 2 <= 65535, "rt_conv_enqueue: grid limit exceeded");
             dim3 grid((unsigned)rt::cdiv((a.Wx + 1) / 2, 256), (unsigned)((a.Hx + 1) / 2), (unsigned)gz);
-            a.z_inner = 0;
-            if (sc.small3d == 1 && a.Mz > 1 && batch <= 65535 && env_int("RT_SMALL_Z_INNER", 1) != 0) {   // 3-D: depth blocks fastest (Deconv3dSmallArgs::z_inner)
-                a.z_inner = 1;
-                grid = dim3(grid.x * (unsigned)a.Mz, grid.y, (unsigned)batch);
-            }
             if (sc.small3d == 2 && sc.x_f16) {          // half2 mode: fp16 activations in, fp32 (binding) or fp16 out
                 if (sc.y_f16) {
                     if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, false, _Float16, _Float16>), grid, dim3(256), 0, S(s), a);
@@ -2189,6 +2214,13 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 RT_REQUIRE(batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
                 dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rt::cdiv((a.Hx + 1) / 2, 2), (unsigned)batch);
                 hipLaunchKernelGGL(rt::deconv3d_s2_il_kernel, g2, dim3(256), 0, S(s), a);
+            } else if (sc.small3d == 1 && !sc.x_f16 && sc.x_il8) {    // fp32 engines: (K/4, D, H, W, 4) in, split form on the matrix cores
+                RT_REQUIRE(sc.small_il_dev && sc.small_il_f32, "rt_conv_enqueue: interleaved fp32 input without its weight operands (rt_conv_plan_set_layouts)");
+                a.w = static_cast<const float*>(sc.small_il_dev);
+                const int groups = (int)rt::cdiv((a.Wx + 1) / 2, 16);
+                RT_REQUIRE(batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
+                dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rt::cdiv((a.Hx + 1) / 2, 2), (unsigned)batch);
+                hipLaunchKernelGGL(rt::deconv3d_s2_il4_kernel, g2, dim3(256), 0, S(s), a);
             } else if (sc.small3d == 1 && sc.x_f16) {   // 3-D last layer in half2 mode: fp16 (K,D,H,W) in, fp32 volume out
                 if (a.C == 1) hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<1, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
                 else hipLaunchKernelGGL((rt::deconv3d_s2_small_kernel<2, true, _Float16, float>), grid, dim3(256), 0, S(s), a);
@@ -2245,12 +2277,13 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
         if (sc.dp4 && sc.split3) {     // fp32 tensors: four phases per workgroup in split-fp16 form (deconv_s3p.hip.h), planar input and output
             a.tiles_x = (int)rt::cdiv(sc.Wi, 32);
             const int tiles = a.tiles_x * (int)rt::cdiv(sc.Hi, 4), nblk = (int)rt::cdiv(sc.Cout, 32);
-            RT_REQUIRE(!sc.x_il8 && !sc.y_il8 && !sc.x_f16 && !sc.y_f16, "rt_conv_enqueue: the fp32 four-phase transposed kernel takes planar fp32 tensors");
+            RT_REQUIRE(!sc.x_il8 && !sc.x_f16 && !sc.y_f16, "rt_conv_enqueue: the fp32 four-phase transposed kernel takes a planar fp32 input and writes fp32");
             RT_REQUIRE((int64_t)batch * sc.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
             RT_REQUIRE(sc.y_cstride * (int64_t)sc.Cout < (1ll << 29), "rt_conv_enqueue: output sample exceeds 2 GB (32-bit buffer offsets)");
             dim3 g((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * sc.nz));
             if (plan->opt_trace) fprintf(stderr, "[rt] deconv_s3p grid %u x %u x %u r%d\n", g.x, g.y, g.z, sc.r_il8);
-            hipLaunchKernelGGL(rt::deconv_s3p_kernel, g, dim3(256), 0, S(s), a);
+            if (sc.y_il8) hipLaunchKernelGGL(rt::deconv_s3p_kernel<true>, g, dim3(256), 0, S(s), a);
+            else hipLaunchKernelGGL(rt::deconv_s3p_kernel<false>, g, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("deconv_s3p_kernel");
             continue;
         }

@@ -367,7 +367,7 @@ def test_conv3d_transpose_fp32_reads_an_interleaved_skip_tensor(backend, K, C, y
     ps = (pad_d, 1, 1)
     plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=False,
                                     has_residual=True, transposed_in_dims=ydims, out_depth=dkeep)
-    assert plan.il_caps() == 4
+    assert plan.il_caps() == 6                            # the skip tensor read interleaved, the output written interleaved (four-phase form)
     out = empty(backend, (n, dkeep, C, hx, wx), False)
     plan.enqueue(dev32(backend, y), out, dev32(backend, sk), n)
     planar = host(backend, out)
@@ -417,7 +417,7 @@ def test_conv3d_transpose_fp32_four_phases_per_workgroup(backend, monkeypatch, K
         plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
                                         has_residual=bool(skip), transposed_in_dims=ydims, out_depth=dkeep)
         if skip == 2:
-            assert plan.il_caps() == 4
+            assert plan.il_caps() == (4 if p4 == "1" else 6)
             plan.set_layouts(0, 0, 1)
         out = empty(backend, ref.shape, False)
         plan.enqueue(dev32(backend, y), out, dev32(backend, il4_dm(sk) if skip == 2 else sk) if skip else None, n)
@@ -429,3 +429,74 @@ def test_conv3d_transpose_fp32_four_phases_per_workgroup(backend, monkeypatch, K
     assert np.abs(outs[0] - ref).max() <= tol, np.abs(outs[0] - ref).max()
     assert np.abs(outs[1] - ref).max() <= tol
     assert np.array_equal(outs[0], outs[1])              # the same arithmetic, operation for operation
+
+
+def il4_cm(a):
+    """channel-major (N, K, D, H, W) -> (N, K/4, D, H, W, 4)"""
+    n, k, d, h, w = a.shape
+    return np.ascontiguousarray(a.reshape(n, k // 4, 4, d, h, w).transpose(0, 1, 3, 4, 5, 2))
+
+
+def un_il4_cm(a):
+    n, g, d, h, w, _ = a.shape
+    return a.transpose(0, 1, 5, 2, 3, 4).reshape(n, g * 4, d, h, w)
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw", [(16, 8, (3, 4, 19), 7, 6, 0, True, True), (8, 16, (3, 5, 9), 5, 5, 1, True, False),
+                                                                  (24, 40, (2, 3, 17), 3, 3, 1, False, True), (32, 32, (2, 6, 33), 5, 4, 0, True, True)])
+def test_conv3d_transpose_fp32_writes_an_interleaved_tensor(backend, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw):
+    """deconv_s3p_kernel<true>: the same arithmetic, the output as (C/4, D, H, W, 4) (fused Transform) or (D, C/4, H, W, 4) -- the tensor the
+    last layer of an fp32 3-D engine reads on the matrix cores.  Same bits as the planar output."""
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y, w, b = rnd(n, K, dy, hy, wy), rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)), rnd(C)
+    sk = rnd(n, dkeep, C, hx, wx) if skip else None
+    ps = (pad_d, 1, 1)
+    plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
+                                    has_residual=skip, transposed_in_dims=ydims, out_depth=dkeep)
+    assert plan.il_caps() == (2 | (4 if skip else 0))
+    shape = (n, C, dkeep, hx, wx) if cdhw else (n, dkeep, C, hx, wx)
+    out = empty(backend, shape, False)
+    plan.enqueue(dev32(backend, y), out, dev32(backend, sk) if skip else None, n)
+    planar = host(backend, out)
+    plan.set_layouts(0, 1, 1 if skip else 0)
+    out = empty(backend, (il4_cm if cdhw else il4_dm)(planar).shape, False)
+    plan.enqueue(dev32(backend, y), out, dev32(backend, il4_dm(sk)) if skip else None, n)
+    got = host(backend, out)
+    assert not np.isnan(got).any()
+    assert np.array_equal((un_il4_cm if cdhw else un_il4_dm)(got), planar)
+    with pytest.raises(capi.RtError):
+        plan.set_layouts(1, 1, 0)                       # the input stays planar
+    plan.destroy()
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,act", SMALL_CASES)
+def test_last_deconv3d_fp32_on_interleaved_input(backend, K, C, ydims, dfull, dkeep, pad_d, act):
+    """deconv3d_s2_il4_kernel: the last layer of an fp32 3-D engine with its input as (K/4, Dy, Hy, Wy, 4), 3-term fp16 split on
+    v_mfma_f32_16x16x32_f16 -- against the oracle in fp64 and against the vector-ALU fp32 kernel on the planar tensor"""
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y, w, b = rnd(n, K, dy, hy, wy), rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)), rnd(C)
+    ps = (pad_d, 1, 1)
+    ref = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    ref = (O.elu(ref) if act == capi.RT_ACT_ELU else torch.sigmoid(ref) if act == capi.RT_ACT_SIGMOID else ref).numpy()
+    plan = backend.klib.conv3d_plan(w, b, C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=act, transposed_in_dims=ydims, out_depth=dkeep)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, y), out, None, n)
+    planar = host(backend, out)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(planar - ref).max() <= tol
+    assert plan.il_caps() == 1
+    plan.set_layouts(1, 0, 0)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, il4_cm(y)), out, None, n)
+    got = host(backend, out)
+    assert not np.isnan(got).any()
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()            # fp32-class accuracy, as the fp32 fma chain
+    plan.set_layouts(0, 0, 0)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, y), out, None, n)
+    assert np.array_equal(host(backend, out), planar)
+    plan.destroy()

@@ -264,10 +264,15 @@ def test_3d_fp32_interleaved_equals_planar(rt, monkeypatch, model, cfg, disp):
     w = O.synth_weights_3d(getattr(O, cfg))
     l, r = pairs(1, 17, 33) if rt.kind == "emu" else pairs(2, 33, 65)
     il, _ = run_net(rt, model, w, l, r, max_disp=disp)
+    # (the last layer reads its interleaved input on the matrix cores in split form -- other arithmetic than the vector-ALU fp32 kernel
+    #  of the planar engine, the same accuracy; without it the two engines agree bit for bit)
+    monkeypatch.setenv("RT_NO_SMALL_IL_F32", "1")
+    il_valu, _ = run_net(rt, model, w, l, r, max_disp=disp)
     monkeypatch.setenv("RT_NO_IL8_3D_F32", "1")
     planar, _ = run_net(rt, model, w, l, r, max_disp=disp)
     assert not np.isnan(il).any()
-    assert np.array_equal(il, planar)
+    assert np.array_equal(il_valu, planar)
+    assert np.abs(il - planar).max() <= 2e-5, np.abs(il - planar).max()
 
 
 def test_resnet18_2d_half2_mode(rt, monkeypatch):
