@@ -261,6 +261,8 @@ def test_nvtiny_unfused_equals_fused(rt, monkeypatch):
 def test_3d_fp32_interleaved_equals_planar(rt, monkeypatch, model, cfg, disp):
     """fp32 engines keep the 3-D tensors between Conv3D launches (and the decoder's skip tensors) as (D, C/4, H, W, 4): the same arithmetic
     in the same order as on planar tensors, hence the same bits"""
+    if rt.kind == "emu" and model == "nvsmall":
+        pytest.skip("CPU tier time: NVTiny covers the executor path on the emulator, NVSmall runs in the GPU tier")
     w = O.synth_weights_3d(getattr(O, cfg))
     l, r = pairs(1, 17, 33) if rt.kind == "emu" else pairs(2, 33, 65)
     il, _ = run_net(rt, model, w, l, r, max_disp=disp)
