@@ -222,7 +222,8 @@ int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
  * uses the layout for tensors that only 3x3 stride-1 plans in fp16 arithmetic (and, as output, the first layer)
  * touch.  rt_conv_plan_supports_il8: which tensors of the plan may be interleaved (bit 0 input, bit 1 output, bit 2
  * residual, bit 3: an interleaved output only together with an interleaved input, bit 4: an interleaved input whose channel
- * count is padded up to a whole group -- the pad channels must hold finite values; call it after
+ * count is padded up to a whole group -- the pad channels must hold finite values, bit 5: the input must stay planar fp32 (the
+ * factored cost-volume fold of the first Conv3D); call it after
  * rt_conv_plan_set_io_types); rt_conv_plan_set_layouts: layout (0 planar, 1 interleaved) of
  * the input, the output and the residual tensor. */
 int rt_conv_plan_supports_il8(const rtConvPlan* plan);

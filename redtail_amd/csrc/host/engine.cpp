@@ -1413,6 +1413,7 @@ void EngineImpl::assignHalf3D() {
         for (size_t ci = 0; ci < ops_.size(); ci++) {
             const Op& cv = ops_[ci];
             if (cv.kind != OpKind::kConv3D || !cv.splugin->fusion().cv_fold) continue;
+            if (cv.splugin->ilCaps() & 32) continue;                    // the factored fold (fold_factor.hip.h) wants the maps as they are: planar fp32
             const int x = root(cv.in[0]);
             TensorImpl& ft = *tensors_[x];
             if (ft.dims.nbDims != 3 || ft.f16 || ft.il8 || ft.pitch || ft.dims.d[0] % 16 != 0) continue;
@@ -1516,6 +1517,7 @@ void EngineImpl::assignInterleaved3D() {
         for (size_t ci = 0; ci < ops_.size(); ci++) {
             const Op& cv = ops_[ci];
             if (cv.kind != OpKind::kConv3D || !cv.splugin->fusion().cv_fold) continue;
+            if (cv.splugin->ilCaps() & 32) continue;                    // (the factored fold reads planar maps)
             const int x = root(cv.in[0]);
             const TensorImpl& ft = *tensors_[x];
             if (ft.dims.nbDims != 3 || ft.f16 || ft.il8 || ft.pitch || ft.dims.d[0] % 8 != 0) continue;

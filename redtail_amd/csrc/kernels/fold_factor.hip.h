@@ -1,0 +1,126 @@
+// The first Conv3D of the 3-D models over the DEFAULT cost volume, factored (round 4).
+//
+// The reference builds cv[d, 0:F] = L, cv[d, F:2F, y, x] = R[:, y, x - d] (0 for x < d) for d = 0 .. D-1 (lib/kernels.cu:50-97) and runs a
+// 3x3x3 Conv3D over it (nvsmall_1025x321_net.cpp: conv3D_1; 64 -> 32 channels, 48 x 161 x 513: 438 GFLOP).  Rounds 2-4 never built the
+// volume (rtConv3dDesc::cv_fold: the convolution gathers it from the two feature maps) but still multiplied all of it.  The volume is D
+// shifted copies of TWO images, and a convolution commutes with a shift:
+//
+//   out[d, k, y, x] = b[k] + sum_{j in J(d)} ( (W_j^L * L)[k, y, x] + (W_j^R * R)~[k, y, x - d - j + 1] ),   J(d) = { j : 0 <= d + j - 1 < D }
+//
+// with W_j the depth tap j of the kernel split into its left / right channel halves, `*` a 2-D 3x3 convolution (zero padding) and ~ the
+// same convolution evaluated one column beyond the image on the left (column -1 sees R[., 0] through the tap dx = +1).  So:
+//   A_v  = conv3x3(L, sum_{j in v} W_j^L),   v = first / middle / last depth slice       one 2-D convolution F -> 3K
+//   C'_j = conv3x3([0 | R], W_j^R)           (R with one zero column in front)           one 2-D convolution F -> 3K, width W + 1
+//   out[d](x) = act( b + A_v(d)(x) + sum_{j in J(d)} C'_j(x - d - j + 2) - [x = W-1] E[d] )
+// Both convolutions run on the split-fp16 kernels of conv_split.hip.h (fp32-class accuracy); what is left per output voxel is three loads
+// and four adds.  NVSmall: 438 GFLOP -> 9 GFLOP + one pass that writes the 254 MB (fp16) / 507 MB (fp32) output.
+//
+// E: the one place where shift and convolution do not commute.  The volume ends at x = W-1, so at the last column the tap dx = +1 reads the
+// zero padding of the VOLUME -- while C'_j there still sees the pixel R[., W + 1 - d - j] of the (longer) image.  E[d, k, y] is that
+// contribution (a 3 x 1 convolution of one image column per depth tap), subtracted at x = W-1.
+#pragma once
+#include "common.hip.h"
+
+namespace rt {
+
+struct FoldFactorArgs {
+    const float* x;        // (N, 2F, H, W) fp32 planar: [left | right] feature maps
+    const float* a;        // (N, 3K, H, W): A_first, A_middle, A_last
+    const float* c;        // (N, 3K, H, W + 1): C'_0, C'_1, C'_2
+    float* rext;           // (N, F, H, W + 1)
+    float* e;              // (N, D, K, H)
+    const float* wedge;    // [j 3][dy 3][c F][k K]: w[k, j, F + c, dy, dx = 2]
+    const float* bias;     // [K]
+    void* y;               // output, depth-major: (N, D, K, H, W) planar or (N, D, K/G, H, W, G) interleaved (G = 4 fp32, 8 fp16)
+    int F, K, D, H, W;
+    int act;
+    int64_t x_bstride, a_bstride, c_bstride, r_bstride, e_bstride, y_bstride;    // elements
+};
+
+// R -> [0 | R]
+__global__ void __launch_bounds__(256) fold_pad_kernel(FoldFactorArgs p) {
+    const int xw = blockIdx.x * 256 + threadIdx.x;            // column of R_ext
+    const int y = blockIdx.y, c = blockIdx.z % p.F, n = blockIdx.z / p.F;
+    if (xw > p.W) return;
+    const float v = xw == 0 ? 0.f : p.x[(int64_t)n * p.x_bstride + ((int64_t)(p.F + c) * p.H + y) * p.W + xw - 1];
+    p.rext[(int64_t)n * p.r_bstride + ((int64_t)c * p.H + y) * (p.W + 1) + xw] = v;
+}
+
+// E[n, d, k, y]: one thread per (k, y); grid (ceil(H * K / 256), D, N)
+__global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y, n = blockIdx.z;
+    if (t >= p.H * p.K) return;
+    const int k = t % p.K, y = t / p.K;
+    const float* __restrict__ r = p.x + (int64_t)n * p.x_bstride + (int64_t)p.F * p.H * p.W;
+    float acc = 0.f;
+    for (int j = 0; j < 3; j++) {
+        const int dz = d + j - 1, col = p.W + 1 - d - j;
+        if (dz < 0 || dz >= p.D || d + j < 2 || col < 0) continue;                    // depth padding / the pixel lies outside the image as well
+        for (int dy = 0; dy < 3; dy++) {
+            const int iy = y + dy - 1;
+            if (iy < 0 || iy >= p.H) continue;
+            const float* __restrict__ wv = p.wedge + ((int64_t)(j * 3 + dy) * p.F) * p.K + k;
+            for (int c = 0; c < p.F; c++) acc = fmaf(wv[(int64_t)c * p.K], r[((int64_t)c * p.H + iy) * p.W + col], acc);
+        }
+    }
+    p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k) * p.H + y] = acc;
+}
+
+// out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output
+template <typename TOUT, bool IL>
+__global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
+    constexpr int G = sizeof(TOUT) == 2 ? 8 : 4;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, kg = blockIdx.z % (p.K / G), n = blockIdx.z / (p.K / G);
+    if (x >= p.W) return;
+    const int64_t plane = (int64_t)p.H * p.W, cplane = (int64_t)p.H * (p.W + 1);
+    const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + x;
+    const float* __restrict__ c = p.c + (int64_t)n * p.c_bstride + (int64_t)y * (p.W + 1);
+    const float* __restrict__ e = p.e + (int64_t)n * p.e_bstride + y;
+    float av[3][G], bv[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        bv[g] = p.bias[kg * G + g];
+#pragma unroll
+        for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane];
+    }
+    char* __restrict__ yb = static_cast<char*>(p.y) + (int64_t)n * p.y_bstride * sizeof(TOUT);
+    const bool last_col = x == p.W - 1;
+    for (int d = 0; d < p.D; d++) {
+        const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);
+        float o[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) o[g] = av[v][g];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int dz = d + j - 1, t = x - d - j + 2;                                // column of C'_j
+            if (dz < 0 || dz >= p.D || t < 0) continue;                                 // (t <= W always)
+#pragma unroll
+            for (int g = 0; g < G; g++) o[g] += c[(int64_t)(j * p.K + kg * G + g) * cplane + t];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (last_col) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
+            o[g] = apply_act_fast(o[g] + bv[g], p.act);
+        }
+        if constexpr (IL) {
+            TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * (p.K / G) + kg) * plane + (int64_t)y * p.W + x) * G;
+            if constexpr (G == 8) {
+                u32x4_t w;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    w[q] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * q]) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * q + 1]) << 16);
+                *reinterpret_cast<u32x4_t*>(dst) = w;
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+            }
+        } else {
+            TOUT* dst = reinterpret_cast<TOUT*>(yb) + ((int64_t)d * p.K + kg * G) * plane + (int64_t)y * p.W + x;
+#pragma unroll
+            for (int g = 0; g < G; g++) dst[(int64_t)g * plane] = (TOUT)o[g];
+        }
+    }
+}
+
+}  // namespace rt

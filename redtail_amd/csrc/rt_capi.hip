@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -26,6 +27,7 @@
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
 #include "kernels/deconv_s3p.hip.h"
+#include "kernels/fold_factor.hip.h"
 #include "kernels/cost_volume.hip.h"
 #include "kernels/corr_mfma.hip.h"
 #include "kernels/elementwise.hip.h"
@@ -549,8 +551,21 @@ struct SubConv {                    // one launch of conv_mfma_f32_kernel
 
 }  // namespace
 
+// The first Conv3D over a folded default cost volume, factored into two 2-D convolutions and one combining pass (fold_factor.hip.h)
+struct FoldFactor {
+    rtConvPlan* pl = nullptr;          // conv3x3 F -> 3K on the left feature map: A_first, A_middle, A_last
+    rtConvPlan* pr = nullptr;          // conv3x3 F -> 3K on [0 | right feature map]: C'_0, C'_1, C'_2
+    float* wedge_dev = nullptr;        // [j][dy][c][k]: the taps dx = +1 of the right half (edge term)
+    int F = 0, K = 0, D = 0, H = 0, W = 0;
+    int64_t a_elems = 0, c_elems = 0, r_elems = 0, e_elems = 0;      // per sample
+    // scratch (A, C', [0 | R], E) per stream: execution contexts share a plan and launch it on their own streams
+    std::mutex mu;
+    std::map<void*, std::pair<void*, size_t>> scratch;
+};
+
 struct rtConvPlan {
     std::vector<SubConv> subs;
+    FoldFactor* ff = nullptr;
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
@@ -1027,6 +1042,14 @@ void free_subs(rtConvPlan* p) {
 void free_plan(rtConvPlan* p) {
     if (!p) return;
     free_subs(p);
+    if (p->ff) {
+        if (p->ff->pl) free_plan(p->ff->pl);
+        if (p->ff->pr) free_plan(p->ff->pr);
+        if (p->ff->wedge_dev) (void)hipFree(p->ff->wedge_dev);
+        for (auto& e : p->ff->scratch)
+            if (e.second.first) (void)hipFree(e.second.first);
+        delete p->ff;
+    }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
     if (p->rb_w1_dev) (void)hipFree(p->rb_w1_dev);
     if (p->rb_bias1_dev) (void)hipFree(p->rb_bias1_dev);
@@ -1362,10 +1385,99 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
         const std::vector<float> b = bias ? to_f32(bias, K, d->dtype) : std::vector<float>();
         rc = upload_bias(plan, bias ? b.data() : nullptr, K);
     }
+    // The folded cost volume, factored (fold_factor.hip.h): 3x3x3, stride 1, pad 1, depth-major output, no skip tensor -- the first Conv3D
+    // of every 3-D model of the reference.  The gather form above stays as the fallback for tensors this form does not take.
+    if (!rc && F && V == 3 && R == 3 && Sk == 3 && sd == 1 && sh == 1 && pd == 1 && ph == 1 && pw == 1 && Do == d->D && Ho == d->H && Wo == d->W &&
+        d->D >= 3 && d->out_dchw && !d->has_residual && K % 8 == 0 && !(d->flags & RT_CONV_EXACT_FP32) && sc.split3 && env_int("RT_NO_FOLD_FACTOR", 0) == 0) {
+        auto ff = new FoldFactor();
+        plan->ff = ff;
+        ff->F = F; ff->K = K; ff->D = d->D; ff->H = d->H; ff->W = d->W;
+        ff->a_elems = (int64_t)3 * K * d->H * d->W; ff->c_elems = (int64_t)3 * K * d->H * (d->W + 1);
+        ff->r_elems = (int64_t)F * d->H * (d->W + 1); ff->e_elems = (int64_t)d->D * K * d->H;
+        std::vector<float> wl((size_t)3 * K * F * 9, 0.f), wr((size_t)3 * K * F * 9, 0.f), wedge((size_t)9 * F * K, 0.f);
+        for (int k = 0; k < K; k++)
+            for (int c = 0; c < F; c++)
+                for (int t = 0; t < 9; t++) {
+                    float wj[3];
+                    for (int j = 0; j < 3; j++) {
+                        wj[j] = w[((size_t)k * cin_real + j * C + c) * 9 + t];                               // left half, depth tap j
+                        const float wrj = w[((size_t)k * cin_real + j * C + F + c) * 9 + t];                 // right half
+                        wr[(((size_t)j * K + k) * F + c) * 9 + t] = wrj;
+                        if (t % 3 == 2) wedge[(((size_t)j * 3 + t / 3) * F + c) * K + k] = wrj;
+                    }
+                    wl[(((size_t)0 * K + k) * F + c) * 9 + t] = wj[1] + wj[2];                                   // first slice: depth taps 1, 2
+                    wl[(((size_t)1 * K + k) * F + c) * 9 + t] = (wj[0] + wj[1]) + wj[2];
+                    wl[(((size_t)2 * K + k) * F + c) * 9 + t] = wj[0] + wj[1];                                   // last slice
+                }
+        rtConv2dDesc d2{};
+        d2.Cin = F; d2.Cout = 3 * K; d2.Hin = d->H; d2.Win = d->W; d2.KH = d2.KW = 3; d2.stride = 1; d2.pad_h = d2.pad_w = 1;
+        d2.act = RT_ACT_NONE; d2.has_residual = 0; d2.dtype = RT_F32; d2.flags = d->flags;
+        rc = rt_conv2d_plan_create(&ff->pl, &d2, wl.data(), nullptr);
+        if (!rc) rc = rt_conv_plan_set_batch_strides(ff->pl, (int64_t)C * d->H * d->W, 0, 0);                    // L: the first F planes of a (2F, H, W) sample
+        d2.Win = d->W + 1;
+        if (!rc) rc = rt_conv2d_plan_create(&ff->pr, &d2, wr.data(), nullptr);
+        if (!rc && (hipMalloc((void**)&ff->wedge_dev, wedge.size() * 4) != hipSuccess ||
+                    hipMemcpy(ff->wedge_dev, wedge.data(), wedge.size() * 4, hipMemcpyHostToDevice) != hipSuccess))
+            rc = fail(RT_E_NOMEM, "conv3d: device allocation failed");
+    }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
     return 0;
 }
+
+namespace {
+// Is the factored form the one this plan launches?  (planar fp32 feature maps; any of the four output forms)
+bool fold_factor_active(const rtConvPlan* plan) {
+    if (!plan->ff || plan->subs.size() != 1) return false;
+    const SubConv& sc = plan->subs[0];
+    return !sc.x_f16 && !sc.x_il8 && !sc.f16mma && !plan->has_resid;
+}
+
+int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batch, rtStream s, int hints) {
+    FoldFactor* ff = plan->ff;
+    const SubConv& sc = plan->subs[0];
+    const int64_t per = ff->a_elems + ff->c_elems + ff->r_elems + ff->e_elems;
+    const size_t need = (size_t)per * 4 * (size_t)batch;
+    float* buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ff->mu);
+        auto& e = ff->scratch[(void*)S(s)];
+        if (e.second < need) {
+            if (e.first) { (void)hipStreamSynchronize(S(s)); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+            if (hipMalloc(&e.first, need) != hipSuccess) return fail(RT_E_NOMEM, "conv3d (factored cost volume): %zu bytes of scratch", need);
+            e.second = need;
+        }
+        buf = static_cast<float*>(e.first);
+    }
+    rt::FoldFactorArgs a;
+    a.x = static_cast<const float*>(x);
+    a.a = buf; a.c = buf + (int64_t)batch * ff->a_elems;
+    a.rext = buf + (int64_t)batch * (ff->a_elems + ff->c_elems);
+    a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->r_elems);
+    a.wedge = ff->wedge_dev; a.bias = plan->bias_dev; a.y = y;
+    a.F = ff->F; a.K = ff->K; a.D = ff->D; a.H = ff->H; a.W = ff->W; a.act = plan->act;
+    a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.r_bstride = ff->r_elems; a.e_bstride = ff->e_elems;
+    a.y_bstride = plan->y_bstride;
+    RT_REQUIRE((int64_t)batch * ff->F <= 65535 && (int64_t)batch * (ff->K / 4) <= 65535 && ff->H <= 65535, "rt_conv_enqueue: grid limit exceeded");
+    hipLaunchKernelGGL(rt::fold_pad_kernel, dim3((unsigned)rt::cdiv(ff->W + 1, 256), (unsigned)ff->H, (unsigned)(batch * ff->F)), dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("fold_pad_kernel");
+    if (int rc = rt_conv_enqueue_hint(ff->pl, x, const_cast<float*>(a.a), nullptr, batch, s, hints)) return rc;
+    if (int rc = rt_conv_enqueue_hint(ff->pr, a.rext, const_cast<float*>(a.c), nullptr, batch, s, hints)) return rc;
+    hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * ff->K, 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("fold_edge_kernel");
+    const int G = sc.y_f16 ? 8 : 4;
+    const dim3 grid((unsigned)rt::cdiv(ff->W, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));
+    if (sc.y_f16) {
+        if (sc.y_il8) hipLaunchKernelGGL((rt::fold_combine_kernel<_Float16, true>), grid, dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((rt::fold_combine_kernel<_Float16, false>), grid, dim3(256), 0, S(s), a);
+    } else {
+        if (sc.y_il8) hipLaunchKernelGGL((rt::fold_combine_kernel<float, true>), grid, dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((rt::fold_combine_kernel<float, false>), grid, dim3(256), 0, S(s), a);
+    }
+    RT_LAUNCH_CHECK("fold_combine_kernel");
+    return 0;
+}
+}  // namespace
 
 namespace {
 // The launches of a transposed 3-D convolution (not the small-output last layer): one launch per output-depth class (depths cls, cls+sd,
@@ -1964,6 +2076,9 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
         // one; a fused Conv3DTranspose reads its skip tensor that way.  Channel-major (K, D, H, W) tensors stay planar.
         if (env_int("RT_NO_IL8", 0) != 0 || env_int("RT_NO_IL8_3D", 0) != 0 || plan->subs.empty()) return 0;
         const SubConv& sc = plan->subs[0];
+        if (plan->is_conv3d && plan->subs.size() == 1 && plan->ff && !sc.x_f16 && !sc.f16mma)
+            // the factored cost-volume fold: planar fp32 feature maps in (bit 5: keep them so), interleaved output in either storage type
+            return 32 | 2;
         if (plan->is_conv3d && plan->subs.size() == 1) {
             // the fused Transform's (D, K/8, H, W, 8), or -- fp16 operands only -- the plain (K/8, D, H, W, 8) a Conv3DTranspose then reads
             const int out_dm = (plan->c3d_dchw && sc.Cout % 8 == 0) ? 2 : 0, out = sc.Cout % 8 == 0 ? 2 : 0;
@@ -2191,6 +2306,7 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
     RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
     RT_REQUIRE(!plan->has_resid || residual || plan->rb_w1_dev, "rt_conv_enqueue: plan expects a residual tensor");
     RT_REQUIRE(!plan->rb_w1_dev || !residual || residual == x, "rt_conv_enqueue: a residual block's skip connection is its input tensor");
+    if (fold_factor_active(plan)) return enqueue_fold_factor(plan, x, y, batch, s, hints);
     for (const SubConv& sc : plan->subs) {
         if (sc.small3d) {
             rt::Deconv3dSmallArgs a = sc.s3;

@@ -331,9 +331,10 @@ def test_conv3d_fp32_on_interleaved_tensors(backend, c, k, d, h, w, stride, resi
 
 
 @pytest.mark.parametrize("f,k,h,w,D", [(8, 16, 9, 37, 6), (32, 32, 5, 40, 4), (4, 8, 7, 33, 5)])
-def test_conv3d_fp32_folded_cost_volume_on_interleaved_feature_maps(backend, f, k, h, w, D):
-    """the first Conv3D of an fp32 3-D engine reads the two feature maps [left | right] as (2F/4, H, W, 4): the right half shifted by the
-    slice's disparity in whole 16-byte slots.  Same bits as on planar maps."""
+def test_conv3d_fp32_folded_cost_volume_on_interleaved_feature_maps(backend, monkeypatch, f, k, h, w, D):
+    """the GATHER form of the first Conv3D (the fallback of the factored form, RT_NO_FOLD_FACTOR=1 here) reads the two feature maps
+    [left | right] as (2F/4, H, W, 4): the right half shifted by the slice's disparity in whole 16-byte slots.  Same bits as on planar maps."""
+    monkeypatch.setenv("RT_NO_FOLD_FACTOR", "1")
     n = 2
     l, r = rnd(n, f, h, w), rnd(n, f, h, w)
     wt, b = rnd(k, 3, 2 * f, 3, 3) * np.float32(1 / np.sqrt(27 * 2 * f)), rnd(k)
@@ -355,6 +356,65 @@ def test_conv3d_fp32_folded_cost_volume_on_interleaved_feature_maps(backend, f, 
         got = host(backend, out)
         assert np.array_equal(un_il4_dm(got) if yi else got, planar), yi
     plan.destroy()
+
+
+FOLD_CASES = [
+    # F, K, H, W, D
+    (8, 16, 9, 37, 6),
+    (32, 32, 5, 40, 12),
+    (4, 8, 7, 33, 5),
+    (8, 8, 4, 5, 9),          # more disparities than columns: most of the right half is masked (x < d)
+    (16, 24, 3, 70, 3),       # the minimum depth: first / middle / last slice and nothing else
+]
+
+
+@pytest.mark.parametrize("f,k,h,w,D", FOLD_CASES)
+def test_conv3d_on_folded_cost_volume_factored(backend, monkeypatch, f, k, h, w, D):
+    """fold_factor.hip.h: the first Conv3D over the default cost volume as two 2-D convolutions of the feature maps + one combining pass
+    (a convolution commutes with the shift that builds the volume; the volume's right edge does not: the edge term) -- against the oracle's
+    cost_volume + conv3d_tf in fp64, against the gather form, and in all four output forms"""
+    n = 2
+    l, r = rnd(n, f, h, w), rnd(n, f, h, w)
+    wt, b = rnd(k, 3, 2 * f, 3, 3) * np.float32(1 / np.sqrt(27 * 2 * f)), rnd(k)
+    cv = O.cost_volume(T(l).double(), T(r).double(), D)
+    ref = O.elu(O.transform(O.conv3d_tf(cv, T(wt).double(), T(b).double(), (1, 1, 1), (1, 1, 1), (1, 1, 1)))).numpy()      # (N, D, K, H, W)
+    x = np.concatenate([l, r], axis=1)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+    def make():
+        return backend.klib.conv3d_plan(wt, b, 2 * f, k, (D, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU, out_dchw=True, cv_fold=f)
+    plan = make()
+    caps = plan.il_caps()
+    assert caps & 32 and caps & 2 and not caps & 1, caps                  # the factored form: planar fp32 maps in, any output
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    fact = host(backend, out)
+    assert not np.isnan(fact).any()
+    assert np.abs(fact - ref).max() <= tol, np.abs(fact - ref).max()
+    plan.set_layouts(0, 1, 0)                                               # (D, K/4, H, W, 4)
+    out = empty(backend, il4_dm(ref).shape, False)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    assert np.array_equal(un_il4_dm(host(backend, out)), fact)
+    plan.set_layouts(0, 0, 0)
+    plan.set_io_types(capi.RT_F32, capi.RT_F16)                             # half2 mode: fp32 maps in, fp16 volume out
+    out = empty(backend, ref.shape, True)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    f16 = host(backend, out)
+    assert np.array_equal(f16, fact.astype(np.float16).astype(np.float32))  # the same sums, one rounding
+    plan.set_layouts(0, 1, 0)                                               # (D, K/8, H, W, 8)
+    out = empty(backend, il_dm(ref).shape, True)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    assert np.array_equal(un_il_dm(host(backend, out)), f16)
+    plan.destroy()
+    monkeypatch.setenv("RT_NO_FOLD_FACTOR", "1")                            # the gather form: every product of the volume
+    plan = make()
+    assert not plan.il_caps() & 32
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev32(backend, x), out, None, n)
+    gather = host(backend, out)
+    plan.destroy()
+    assert np.abs(gather - ref).max() <= tol
+    assert np.abs(gather - fact).max() <= tol
 
 
 @pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d", [(16, 8, (3, 4, 19), 7, 6, 0), (8, 16, (3, 5, 9), 5, 5, 1)])
