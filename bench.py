@@ -379,7 +379,13 @@ def bench_3d(lib, dev, model, half2, b, steps, warmup, nctx, blob, weights, desc
                          step_algorithmic_bytes=total * b, step_gbs=total * b / step_s / 1e9,
                          frac_step=total * b / step_s / 1e9 / HBM_PEAK_GBS,
                          frac_step_note="algorithmic bytes of the whole 3-D trunk (each tensor once per launch that touches it) / step time / 8 TB/s",
-                         step_gflop=gflop * b, frac_step_mfma=terms * gflop * b / step_s / 1e3 / MFMA_F16_PEAK_TFLOPS),
+                         step_gflop=gflop * b, frac_step_mfma=terms * gflop * b / step_s / 1e3 / MFMA_F16_PEAK_TFLOPS,
+                         step_gflop_note="direct-form FLOPs of the reference's formulation (27 taps x channels per voxel, SURVEY 8d).  The first "
+                                         "Conv3D is EXECUTED in factored form (redtail_amd/csrc/kernels/fold_factor.hip.h: two 2-D convolutions of "
+                                         "the feature maps + a combining pass, %.1f of its %.0f direct-form GFLOP per pair), so frac_step_mfma "
+                                         "prices work the GPU did not have to do; the dominant launch above is priced in its own FLOPs" % (
+                                             2.0 * 9 * cfg["feat"] * 3 * cfg["conv3d"][0][1] * ((h_img + 1) // 2) * ((w_img + 1) // 2) * 2 / 1e9,
+                                             FLOPS_3D[cfg["conv3d"][0][0]] / 1e9)),
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

@@ -11,9 +11,10 @@
 // same convolution evaluated one column beyond the image on the left (column -1 sees R[., 0] through the tap dx = +1).  So:
 //   A_v  = conv3x3(L, sum_{j in v} W_j^L),   v = first / middle / last depth slice       one 2-D convolution F -> 3K
 //   C'_j = conv3x3([0 | R], W_j^R)           (R with one zero column in front)           one 2-D convolution F -> 3K, width W + 1
-//   out[d](x) = act( b + A_v(d)(x) + sum_{j in J(d)} C'_j(x - d - j + 2) - [x = W-1] E[d] )
-// Both convolutions run on the split-fp16 kernels of conv_split.hip.h (fp32-class accuracy); what is left per output voxel is three loads
-// and four adds.  NVSmall: 438 GFLOP -> 9 GFLOP + one pass that writes the 254 MB (fp16) / 507 MB (fp32) output.
+//   T_v(u) = sum_{j in v} C'_j(u - j + 2),   u = x - d in [-2, W-1]                     one small pass (the three taps' shifts folded)
+//   out[d](x) = act( b + A_v(d)(x) + T_v(d)(x - d) - [x = W-1] E[d] )
+// Both convolutions run on the split-fp16 kernels of conv_split.hip.h (fp32-class accuracy); what is left per output voxel is one load
+// and two adds.  NVSmall: 438 GFLOP -> 9 GFLOP + one pass that writes the 254 MB (fp16) / 507 MB (fp32) output.
 //
 // E: the one place where shift and convolution do not commute.  The volume ends at x = W-1, so at the last column the tap dx = +1 reads the
 // zero padding of the VOLUME -- while C'_j there still sees the pixel R[., W + 1 - d - j] of the (longer) image.  E[d, k, y] is that
@@ -27,6 +28,7 @@ struct FoldFactorArgs {
     const float* x;        // (N, 2F, H, W) fp32 planar: [left | right] feature maps
     const float* a;        // (N, 3K, H, W): A_first, A_middle, A_last
     const float* c;        // (N, 3K, H, W + 1): C'_0, C'_1, C'_2
+    float* t;              // (N, 3K, H, W + 2): T_first, T_middle, T_last at index u + 2
     float* rext;           // (N, F, H, W + 1)
     float* e;              // (N, D, K, H)
     const float* wedge;    // [j 3][dy 3][c F][k K]: w[k, j, F + c, dy, dx = 2]
@@ -34,7 +36,7 @@ struct FoldFactorArgs {
     void* y;               // output, depth-major: (N, D, K, H, W) planar or (N, D, K/G, H, W, G) interleaved (G = 4 fp32, 8 fp16)
     int F, K, D, H, W;
     int act;
-    int64_t x_bstride, a_bstride, c_bstride, r_bstride, e_bstride, y_bstride;    // elements
+    int64_t x_bstride, a_bstride, c_bstride, t_bstride, r_bstride, e_bstride, y_bstride;    // elements
 };
 
 // R -> [0 | R]
@@ -44,6 +46,23 @@ __global__ void __launch_bounds__(256) fold_pad_kernel(FoldFactorArgs p) {
     if (xw > p.W) return;
     const float v = xw == 0 ? 0.f : p.x[(int64_t)n * p.x_bstride + ((int64_t)(p.F + c) * p.H + y) * p.W + xw - 1];
     p.rext[(int64_t)n * p.r_bstride + ((int64_t)c * p.H + y) * (p.W + 1) + xw] = v;
+}
+
+// T_v[n, v K + k, y, i] = sum_{j in v} C'_j[k, y, i - j]  (i = u + 2 in [0, W + 1]; C' indices outside [0, W] contribute nothing)
+__global__ void __launch_bounds__(256) fold_t_kernel(FoldFactorArgs p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, k = blockIdx.z % p.K, n = blockIdx.z / p.K;
+    if (i > p.W + 1) return;
+    const int64_t cplane = (int64_t)p.H * (p.W + 1), tplane = (int64_t)p.H * (p.W + 2);
+    const float* __restrict__ c = p.c + (int64_t)n * p.c_bstride + (int64_t)y * (p.W + 1);
+    float cj[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) cj[j] = (i - j >= 0 && i - j <= p.W) ? c[(int64_t)(j * p.K + k) * cplane + i - j] : 0.f;
+    float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2) + i;
+    // (summed in tap order 0, 1, 2)
+    t[(int64_t)(0 * p.K + k) * tplane] = cj[1] + cj[2];
+    t[(int64_t)(1 * p.K + k) * tplane] = (cj[0] + cj[1]) + cj[2];
+    t[(int64_t)(2 * p.K + k) * tplane] = cj[0] + cj[1];
 }
 
 // E[n, d, k, y]: one thread per (k, y); grid (ceil(H * K / 256), D, N)
@@ -74,9 +93,9 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y, kg = blockIdx.z % (p.K / G), n = blockIdx.z / (p.K / G);
     if (x >= p.W) return;
-    const int64_t plane = (int64_t)p.H * p.W, cplane = (int64_t)p.H * (p.W + 1);
+    const int64_t plane = (int64_t)p.H * p.W, tplane = (int64_t)p.H * (p.W + 2);
     const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + x;
-    const float* __restrict__ c = p.c + (int64_t)n * p.c_bstride + (int64_t)y * (p.W + 1);
+    const float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2);
     const float* __restrict__ e = p.e + (int64_t)n * p.e_bstride + y;
     float av[3][G], bv[G];
 #pragma unroll
@@ -90,15 +109,9 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
     for (int d = 0; d < p.D; d++) {
         const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);
         float o[G];
+        const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] = av[v][g];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int dz = d + j - 1, t = x - d - j + 2;                                // column of C'_j
-            if (dz < 0 || dz >= p.D || t < 0) continue;                                 // (t <= W always)
-#pragma unroll
-            for (int g = 0; g < G; g++) o[g] += c[(int64_t)(j * p.K + kg * G + g) * cplane + t];
-        }
+        for (int g = 0; g < G; g++) o[g] = av[v][g] + (i >= 0 ? t[(int64_t)(v * p.K + kg * G + g) * tplane + i] : 0.f);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (last_col) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];

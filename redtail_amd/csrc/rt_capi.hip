@@ -557,7 +557,7 @@ struct FoldFactor {
     rtConvPlan* pr = nullptr;          // conv3x3 F -> 3K on [0 | right feature map]: C'_0, C'_1, C'_2
     float* wedge_dev = nullptr;        // [j][dy][c][k]: the taps dx = +1 of the right half (edge term)
     int F = 0, K = 0, D = 0, H = 0, W = 0;
-    int64_t a_elems = 0, c_elems = 0, r_elems = 0, e_elems = 0;      // per sample
+    int64_t a_elems = 0, c_elems = 0, t_elems = 0, r_elems = 0, e_elems = 0;      // per sample
     // scratch (A, C', [0 | R], E) per stream: execution contexts share a plan and launch it on their own streams
     std::mutex mu;
     std::map<void*, std::pair<void*, size_t>> scratch;
@@ -1393,6 +1393,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
         plan->ff = ff;
         ff->F = F; ff->K = K; ff->D = d->D; ff->H = d->H; ff->W = d->W;
         ff->a_elems = (int64_t)3 * K * d->H * d->W; ff->c_elems = (int64_t)3 * K * d->H * (d->W + 1);
+        ff->t_elems = (int64_t)3 * K * d->H * (d->W + 2);
         ff->r_elems = (int64_t)F * d->H * (d->W + 1); ff->e_elems = (int64_t)d->D * K * d->H;
         std::vector<float> wl((size_t)3 * K * F * 9, 0.f), wr((size_t)3 * K * F * 9, 0.f), wedge((size_t)9 * F * K, 0.f);
         for (int k = 0; k < K; k++)
@@ -1436,7 +1437,7 @@ bool fold_factor_active(const rtConvPlan* plan) {
 int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batch, rtStream s, int hints) {
     FoldFactor* ff = plan->ff;
     const SubConv& sc = plan->subs[0];
-    const int64_t per = ff->a_elems + ff->c_elems + ff->r_elems + ff->e_elems;
+    const int64_t per = ff->a_elems + ff->c_elems + ff->t_elems + ff->r_elems + ff->e_elems;
     const size_t need = (size_t)per * 4 * (size_t)batch;
     float* buf = nullptr;
     {
@@ -1452,17 +1453,21 @@ int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batc
     rt::FoldFactorArgs a;
     a.x = static_cast<const float*>(x);
     a.a = buf; a.c = buf + (int64_t)batch * ff->a_elems;
-    a.rext = buf + (int64_t)batch * (ff->a_elems + ff->c_elems);
-    a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->r_elems);
+    a.t = buf + (int64_t)batch * (ff->a_elems + ff->c_elems);
+    a.rext = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems);
+    a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems + ff->r_elems);
     a.wedge = ff->wedge_dev; a.bias = plan->bias_dev; a.y = y;
     a.F = ff->F; a.K = ff->K; a.D = ff->D; a.H = ff->H; a.W = ff->W; a.act = plan->act;
-    a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.r_bstride = ff->r_elems; a.e_bstride = ff->e_elems;
+    a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.t_bstride = ff->t_elems; a.r_bstride = ff->r_elems; a.e_bstride = ff->e_elems;
     a.y_bstride = plan->y_bstride;
     RT_REQUIRE((int64_t)batch * ff->F <= 65535 && (int64_t)batch * (ff->K / 4) <= 65535 && ff->H <= 65535, "rt_conv_enqueue: grid limit exceeded");
     hipLaunchKernelGGL(rt::fold_pad_kernel, dim3((unsigned)rt::cdiv(ff->W + 1, 256), (unsigned)ff->H, (unsigned)(batch * ff->F)), dim3(256), 0, S(s), a);
     RT_LAUNCH_CHECK("fold_pad_kernel");
     if (int rc = rt_conv_enqueue_hint(ff->pl, x, const_cast<float*>(a.a), nullptr, batch, s, hints)) return rc;
     if (int rc = rt_conv_enqueue_hint(ff->pr, a.rext, const_cast<float*>(a.c), nullptr, batch, s, hints)) return rc;
+    RT_REQUIRE((int64_t)batch * ff->K <= 65535, "rt_conv_enqueue: grid limit exceeded");
+    hipLaunchKernelGGL(rt::fold_t_kernel, dim3((unsigned)rt::cdiv(ff->W + 2, 256), (unsigned)ff->H, (unsigned)(batch * ff->K)), dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("fold_t_kernel");
     hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * ff->K, 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
     RT_LAUNCH_CHECK("fold_edge_kernel");
     const int G = sc.y_f16 ? 8 : 4;
