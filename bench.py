@@ -409,6 +409,8 @@ def measured_traffic_3d(model, half2, layer):
     e = t.get("%s%s" % (model, " half2" if half2 else ""), {}).get(layer)
     if not e:
         return None, None
+    if e.get("incomplete"):
+        return None, "%s: %s" % (src, e["incomplete"])
     return float(e["fetch_bytes_x2"] + e["write_bytes"]), src + ": per pair, FETCH_SIZE x 2 + WRITE_SIZE of the launch's dispatches"
 
 
