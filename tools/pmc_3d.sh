@@ -44,7 +44,7 @@ for f in sorted(glob.glob(out + "/g*/p_counter_collection.csv")):
     # between two of them are ONE launch (a Conv3DTranspose of the phase form is two: one per depth class)
     segs, cur = [], []
     for d in disp:
-        if "rt::" not in disp[d]["kernel"]:
+        if "rt::" not in disp[d]["kernel"] and not disp[d]["kernel"].startswith("_ZN2rt"):      # (rocprofv3 leaves _Float16 template instantiations mangled)
             continue
         if "hash_words_kernel" in disp[d]["kernel"]:
             segs.append(cur); cur = []
