@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
     if (t >= p.H * p.K) return;
     const int k = t % p.K, y = t / p.K;
     const float* __restrict__ r = p.x + (int64_t)n * p.x_bstride + (int64_t)p.F * p.H * p.W;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};            // four independent chains over the channels (F is a multiple of 4): the loop is latency-bound
     for (int j = 0; j < 3; j++) {
         const int dz = d + j - 1, col = p.W + 1 - d - j;
         if (dz < 0 || dz >= p.D || d + j < 2 || col < 0) continue;                    // depth padding / the pixel lies outside the image as well
@@ -80,43 +80,60 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
             const int iy = y + dy - 1;
             if (iy < 0 || iy >= p.H) continue;
             const float* __restrict__ wv = p.wedge + ((int64_t)(j * 3 + dy) * p.F) * p.K + k;
-            for (int c = 0; c < p.F; c++) acc = fmaf(wv[(int64_t)c * p.K], r[((int64_t)c * p.H + iy) * p.W + col], acc);
+            const float* __restrict__ rv = r + (int64_t)iy * p.W + col;
+            const int64_t cstep = (int64_t)p.H * p.W;
+            for (int c = 0; c < p.F; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] = fmaf(wv[(int64_t)(c + u) * p.K], rv[(c + u) * cstep], acc[u]);
+            }
         }
     }
-    p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k) * p.H + y] = acc;
+    p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k) * p.H + y] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output
+// out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output.
+// The pass is bound by its vector instructions, not by memory (round 4: 150 per depth slice and wave with 64-bit pointer arithmetic
+// per load): the T maps are read with raw buffer loads -- one lane offset (x - d + 2, out of range = masked = 0 by the buffer's own
+// bounds check) and the plane of each channel as a wave-uniform scalar offset -- and the bias sits in the A registers.
 template <typename TOUT, bool IL>
 __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
     constexpr int G = sizeof(TOUT) == 2 ? 8 : 4;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y, kg = blockIdx.z % (p.K / G), n = blockIdx.z / (p.K / G);
-    if (x >= p.W) return;
+    const bool live = x < p.W;
     const int64_t plane = (int64_t)p.H * p.W, tplane = (int64_t)p.H * (p.W + 2);
-    const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + x;
-    const float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2);
+    const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + (live ? x : 0);
     const float* __restrict__ e = p.e + (int64_t)n * p.e_bstride + y;
-    float av[3][G], bv[G];
+    const buf_rsrc rs_t = make_buf(p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2));
+    float av[3][G];                                  // A_v + bias
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        bv[g] = p.bias[kg * G + g];
+        const float b = p.bias[kg * G + g];
 #pragma unroll
-        for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane];
+        for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane] + b;
     }
+    const unsigned tp4 = (unsigned)(tplane * 4);     // bytes between channel planes of T (3 K planes of one sample: < 4 GB)
+    const unsigned cbase = (unsigned)(kg * G) * tp4;
     char* __restrict__ yb = static_cast<char*>(p.y) + (int64_t)n * p.y_bstride * sizeof(TOUT);
-    const bool last_col = x == p.W - 1;
+    const bool last_col = live && x == p.W - 1;
+    const int act = p.act;
     for (int d = 0; d < p.D; d++) {
-        const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);
-        float o[G];
+        const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);                             // wave-uniform
         const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
+        const unsigned vo = (live && i >= 0) ? (unsigned)i * 4u : kBufOOB;
+        const unsigned vbase = (unsigned)(v * p.K) * tp4 + cbase;
+        float o[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] = av[v][g] + (i >= 0 ? t[(int64_t)(v * p.K + kg * G + g) * tplane + i] : 0.f);
+        for (int g = 0; g < G; g++) o[g] = buf_load(rs_t, vo, vbase + (unsigned)g * tp4);
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            if (last_col) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
-            o[g] = apply_act_fast(o[g] + bv[g], p.act);
+        for (int g = 0; g < G; g++) o[g] += av[v][g];
+        if (last_col) {
+#pragma unroll
+            for (int g = 0; g < G; g++) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
         }
+#pragma unroll
+        for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);
+        if (!live) continue;
         if constexpr (IL) {
             TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * (p.K / G) + kg) * plane + (int64_t)y * p.W + x) * G;
             if constexpr (G == 8) {
