@@ -11,15 +11,16 @@ from redtail_amd import build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(binary):
-    res = subprocess.run([binary], capture_output=True, text=True, timeout=1200)
+def _run(binary, quick=False):
+    env = dict(os.environ, RT_TEST_QUICK="1") if quick else None
+    res = subprocess.run([binary], capture_output=True, text=True, timeout=1200, env=env)
     out = res.stdout + res.stderr
     assert res.returncode == 0, out[-4000:]
     assert "PASSED 3 of 3 engine graph tests" in out, out[-2000:]
 
 
 def test_engine_graphs_on_emulator():
-    _run(build.build_engine_tests(emu=True))
+    _run(build.build_engine_tests(emu=True), quick=True)       # (batch 2 of the siamese cases runs in the GPU tier: CPU-tier time)
 
 
 @pytest.mark.gpu

@@ -110,6 +110,8 @@ def test_resnet18_2d_siamese_merge_is_bit_identical(rt, monkeypatch):
     towers whose weights differ are not merged."""
     w = O.synth_weights_resnet18_2d()
     for n, maxb, env in ((1, 1, {}), (2, 3, {}), (2, 2, {"RT_RB": "1", "RT_RBS_SEG": "16"})):
+        if rt.kind == "emu" and (n, maxb) == (2, 3):
+            continue                                              # (a batch below maxBatchSize: GPU tier and tests/cpp/engine_graph_tests.cpp; CPU-tier time)
         hh, ww = (41, 73) if (env or rt.kind != "emu") else (25, 41)      # the streaming block needs two strips x two segments; otherwise small on the emulator
         l, r = pairs(n, hh, ww)
         for k, v in env.items():
