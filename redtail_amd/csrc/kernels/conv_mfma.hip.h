@@ -94,6 +94,9 @@ struct ConvArgs {
     // the SAME input patch follow each other on one XCD, so that patch comes from HBM once instead of once per block (round 4, PMC:
     // the stride-2 Conv3D 32 -> 64 of NVSmall half2 fetched 839 MB for a 254 MB input at 6.6 TB/s of fabric traffic).  0: grid.y.
     int nb_inner;
+    // conv_f16dw_kernel / conv_s3dw_kernel (depth-walking Conv3D, conv_f16dw.hip.h): output slices per depth segment, segments per tile
+    // pair, 16-channel chunks per input slice (C / 16), image tiles per sample (tiles_x * tiles_y of 12 x 32 pixels)
+    int dw_seg, dw_nseg, dw_cpc, dw_ntiles;
 };
 
 // workgroup -> (tile of the output plane, z-slice, sample)

@@ -23,6 +23,7 @@
 #include "kernels/conv_f16.hip.h"
 #include "kernels/conv_f16_first.hip.h"
 #include "kernels/conv_f16r4.hip.h"
+#include "kernels/conv_f16dw.hip.h"
 #include "kernels/deconv_f16p.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
@@ -569,7 +570,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -589,6 +590,7 @@ struct rtConvPlan {
     // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
     int is_conv3d = 0, is_deconv3d = 0;
     int c3d_C = 0, c3d_cin = 0, c3d_dchw = 0, c3d_fold = 0;
+    int c3d_dw = 0;                               // 3x3x3, stride 1, pad 1, C % 16 == 0, no folded pad / cost volume: the depth-walking kernels apply (conv_f16dw.hip.h)
     rtConv3dDesc desc3d{};                        // transposed 3-D plans: the descriptor and input dims they were created with (the launches are
     int in_dims3[3] = {0, 0, 0};                  // rebuilt when the plan moves between the split-fp16 and the fp16-operand kernel)
     int flags = 0;                                // RT_CONV_* option bits of the descriptor(s) the plan was created with: every later re-planning
@@ -1380,6 +1382,7 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
     }
     plan->subs.push_back(sc);
     plan->is_conv3d = 1; plan->c3d_C = C; plan->c3d_cin = cin_real; plan->c3d_dchw = d->out_dchw != 0; plan->c3d_fold = F;
+    plan->c3d_dw = V == 3 && R == 3 && Sk == 3 && sd == 1 && sh == 1 && pd == 1 && ph == 1 && pw == 1 && d->in_pad_end == 0 && F == 0 && C % 16 == 0 && Do == d->D;
     plan->w_canon = w;                                         // (K, V*C, R, S): re-packed when the plan switches to fp16 operands
     if (!rc) {
         const std::vector<float> b = bias ? to_f32(bias, K, d->dtype) : std::vector<float>();
@@ -2091,7 +2094,8 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
             // odd plane sizes of dense 4-D tensors misalign) -- bit 3: an interleaved output needs an interleaved input
             const bool f16mma_ok = !sc.small3d && !sc.direct && (sc.split3 || sc.f16mma) && sc.KH == 3 && sc.KW == 3 &&
                                    (sc.S == 1 || sc.S == 2) && sc.TY == 4 && plan->c3d_C % 8 == 0 && env_int("RT_NO_F16MMA_3D", 0) == 0;
-            if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0)) : 0;
+            // (bit 2: the skip tensor of a fused add may be interleaved like the output -- the fp16-operand kernels read it either way)
+            if (sc.x_f16 && sc.y_f16) return f16mma_ok ? (1 | out | (out ? 8 : 0) | ((out && plan->has_resid) ? 4 : 0)) : 0;
             if (sc.split3 && sc.y_f16 && !sc.x_f16 && sc.TY == 4) return out_dm;         // fp32 (feature maps) in, fp16 volume out
             // fp32 tensors (round 4): the split kernel takes (D, C/4, H, W, 4) on either side -- one 16-byte load per pixel and group of 4
             // channels instead of four 4-byte ones, 16-byte stores.  The folded cost volume's two feature maps: (2F/4, H, W, 4), the right
@@ -2176,8 +2180,9 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
         if ((caps & 8) && y_il8 && !x_il8) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D writes an interleaved tensor only when it reads one");
         if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2))) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D plan takes no interleaved tensors");
         if (int rc = switch_conv3d_f16mma(plan, x_il8 != 0)) return rc;           // interleaved input: fp16 operands; planar input: the split kernel
+        if (r_il8 && (!(caps & 4) || !x_il8)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D reads an interleaved skip tensor only on fp16 operands (interleaved input)");
         SubConv& sc = plan->subs[0];
-        sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = 0;
+        sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
         return 0;
     }
     if (plan->is_deconv3d && !plan->subs.empty()) {
@@ -2361,6 +2366,8 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
             plan->opt_zinner = env_int("RT_Z_INNER", 1);     // 3-D launches: depth slices fastest inside a tile (ConvArgs::z_inner); 0 = z outermost
             plan->opt_nbinner = env_int("RT_NB_INNER", 1);  // 3-D launches: blocks of 32 output channels fastest (ConvArgs::nb_inner); 0 = grid.y
+            plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
+            plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
             plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
         });
         rt::ConvArgs a;
@@ -2592,6 +2599,46 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (plan->opt_trace)
                 fprintf(stderr, "[rt] conv_f16mma %dx%d s%d rows %d il8 x%d y%d r%d grid %u x %u x %u\n", sc.KH, sc.KW, sc.S, sc.TY, sc.x_il8,
                         sc.y_il8, sc.r_il8, grid.x, grid.y, grid.z);
+            // Conv3D 3x3x3 stride 1 between interleaved fp16 tensors: the workgroup walks down the depth axis (conv_f16dw.hip.h)
+            if (plan->c3d_dw && plan->opt_dw != 0 && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.x_il8 && sc.y_il8 && !sc.zs_dev && sc.y_xstride == 1 &&
+                (!plan->has_resid || sc.r_il8) && (plan->act == RT_ACT_NONE || plan->act == RT_ACT_ELU) && !sc.shift_dev) {
+                using Dw = rt::ConvF16DwCfg;
+                a.tiles_x = (int)rt::cdiv(sc.Wo, Dw::TX);
+                a.dw_ntiles = a.tiles_x * (int)rt::cdiv(sc.Ho, Dw::TY);
+                a.dw_cpc = plan->c3d_C / 16;
+                a.nb_inner = (int)rt::cdiv(sc.Cout, 32);
+                const int64_t npairs = rt::cdiv(a.dw_ntiles, 2);
+                // depth segments: every segment pays two steps' worth of MFMAs for its neighbours' slices and a prologue, every round of
+                // workgroups over the CUs costs a whole segment -- minimise rounds x (segment + overhead); results do not depend on it
+                int nseg = plan->opt_dw_nseg;
+                if (nseg <= 0) {
+                    double best = 1e30;
+                    for (int ns = 1; ns <= sc.nz; ns++) {
+                        const int seg = (int)rt::cdiv(sc.nz, ns);
+                        if (ns > 1 && seg < 4) break;
+                        if ((int)rt::cdiv(sc.nz, seg) != ns) continue;
+                        const double cost = (double)rt::cdiv(npairs * ns * a.nb_inner * batch, (int64_t)device_cus()) * (seg + (ns > 1 ? 3.0 : 1.7));
+                        if (cost < best - 1e-9) { best = cost; nseg = ns; }
+                    }
+                }
+                nseg = std::max(1, std::min(nseg, sc.nz));
+                a.dw_seg = (int)rt::cdiv(sc.nz, nseg);
+                a.dw_nseg = (int)rt::cdiv(sc.nz, a.dw_seg);
+                const int64_t gx = npairs * a.dw_nseg * a.nb_inner;
+                RT_REQUIRE(gx < (1ll << 31) && batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
+                dim3 gd((unsigned)gx, 1u, (unsigned)batch);
+                if (plan->opt_trace) fprintf(stderr, "[rt] conv_f16dw grid %u x %u segments %d x %d slices, %d chunks per slice\n", gd.x, gd.z, a.dw_nseg, a.dw_seg, a.dw_cpc);
+                const bool resident = a.dw_cpc <= 2;
+                if (resident) {
+                    if (plan->has_resid) hipLaunchKernelGGL((rt::conv_f16dw_kernel<true, true>), gd, dim3(512), 0, S(s), a);
+                    else hipLaunchKernelGGL((rt::conv_f16dw_kernel<true, false>), gd, dim3(512), 0, S(s), a);
+                } else {
+                    if (plan->has_resid) hipLaunchKernelGGL((rt::conv_f16dw_kernel<false, true>), gd, dim3(512), 0, S(s), a);
+                    else hipLaunchKernelGGL((rt::conv_f16dw_kernel<false, false>), gd, dim3(512), 0, S(s), a);
+                }
+                RT_LAUNCH_CHECK("conv_f16dw_kernel");
+                continue;
+            }
             // Conv3D between interleaved fp16 tensors: four output rows per wave, operands reused from registers (conv_f16r4.hip.h) -- the
             // 4 x 32-tile kernel below reads 2 KB of LDS per MFMA and is LDS-bound at 0.3 of the matrix peak on these layers
             if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.x_il8 && sc.y_il8 && !sc.zs_dev && sc.TY == 4 && sc.y_xstride == 1 &&
