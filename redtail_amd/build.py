@@ -26,7 +26,7 @@ HOST_SOURCES = ["host/plugins.cpp", "host/engine.cpp", "host/networks.cpp", "hos
 # on the headline without them) and (b) were the trigger of the one run-to-run deviation ever located in this code base -- the exact-fp32
 # Winograd kernel's interleaved epilogue beside co-resident fp16-MFMA waves; with -fno-slp-vectorize 0 of 8000 launches deviate, with it
 # 40 %.  Packed math that is WRITTEN as such in the kernels (f32x2 types) is unaffected.
-DEVICE_FLAGS = ["-fno-slp-vectorize"]
+DEVICE_FLAGS = ["-fno-slp-vectorize", "-DRT_BUILT_NO_SLP"]      # rt_capi.hip refuses to compile for the device without the pair (profiles/r04_race.txt)
 
 
 def _newer(target, sources):
@@ -56,7 +56,23 @@ def build_hip(force=False):
     if force or _newer(out, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
               "-Wno-unused-function"] + DEVICE_FLAGS + [os.path.join(CSRC, "rt_capi.hip"), "-o", out])
+        check_no_packed_f32(out)
     return out
+
+
+def check_no_packed_f32(lib):
+    """The product library must not contain compiler-formed packed fp32 math outside the allow-list (tools/check_no_packed_f32.py,
+    profiles/r04_race.txt): a build that does is deleted and the build fails."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import check_no_packed_f32 as guard
+    finally:
+        sys.path.pop(0)
+    counts, bad, kernels = guard.check(lib)
+    print("packed-fp32 guard: %d kernels, v_pk_{add,mul,fma}_f32 in %d allow-listed kernels, %d violations" % (kernels, len(counts) - len(bad), len(bad)))
+    if bad:
+        os.remove(lib)
+        raise RuntimeError("packed fp32 instructions outside the allow-list (tools/check_no_packed_f32.py): %s" % sorted(bad.items()))
 
 
 def build_hip_timing(force=False):
@@ -86,7 +102,7 @@ def build_hip_ablation(mask, force=False, timing=False):
     return out
 
 
-def build_variant(name, defines, force=False, device_flags=None):
+def build_variant(name, defines, force=False, device_flags=None, kernels_only=False):
     """Another build of the two product libraries side by side in tools/build/<name>/ (probes: RT_EXPERIMENTAL kernel families, hazard
     probes ...; never the product).  Tools take the directory through RT_VARIANT_DIR."""
     outdir = os.path.join(ROOT, "tools", "build", name)
@@ -97,7 +113,7 @@ def build_variant(name, defines, force=False, device_flags=None):
     if force or _newer(kern, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w"] + (DEVICE_FLAGS if device_flags is None else list(device_flags)) +
              list(defines) + [os.path.join(CSRC, "rt_capi.hip"), "-o", kern])
-    if force or _newer(host, [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern]):
+    if not kernels_only and (force or _newer(host, [os.path.join(CSRC, "host"), os.path.join(ROOT, "include"), os.path.join(ROOT, "redtail_amd", "include"), kern])):
         _build_host_against(kern, host)
     return outdir
 

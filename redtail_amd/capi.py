@@ -100,6 +100,8 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_enqueue_hint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "rt_conv_plan_workspace_bytes": (ctypes.c_size_t, [c_void_p, c_int]),
+    "rt_conv_enqueue_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_int]),
     "rt_conv_plan_destroy": (c_int, [c_void_p]),
     # multi-GPU: RCCL communicator + byte broadcast (librccl is loaded on first use)
     "rt_comm_unique_id": (c_int, [c_void_p]),

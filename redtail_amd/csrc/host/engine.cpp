@@ -372,8 +372,9 @@ private:
     int streams_ = 2;
     int alloc_batch_ = 0;
     std::vector<void*> buffers_;       // per tensor id (owned)
-    void* workspace_ = nullptr;
+    void* workspace_ = nullptr;        // 2 x workspace_bytes_: the launches of the main / the side stream never share scratch
     size_t workspace_bytes_ = 0;
+    void* wsOf(bool side) const { return workspace_ ? static_cast<char*>(workspace_) + (side ? workspace_bytes_ : 0) : nullptr; }
     rtStream side_stream_ = nullptr;
     rtStream main_stream_ = nullptr;   // execute() runs on its own stream, never on the NULL stream
     std::vector<void*> events_;        // per tensor id, lazily created
@@ -547,6 +548,12 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) applySampleStrides();
     if (ok_) assignStreams();           // final: the passes above removed and merged ops (waits and publish flags are recomputed)
     if (ok_) planIssueOrder();
+    // the launches' scratch (IPlugin::getWorkspaceSize) as it is AFTER fusion and layout negotiation -- the factored first Conv3D of the
+    // 3-D models only exists once the cost volume is folded into it.  A context keeps one block per stream it issues on.
+    if (ok_)
+        for (auto& op : ops_)
+            if (op.kind == OpKind::kConv3D && op.plugin) workspace_bytes_ = std::max(workspace_bytes_, op.plugin->getWorkspaceSize(max_batch_));
+    workspace_bytes_ = (workspace_bytes_ + 255) / 256 * 256;
 }
 
 EngineImpl::~EngineImpl() {
@@ -1894,7 +1901,7 @@ bool ContextImpl::ensureBuffers(int batch) {
         if (t->cpad && (rt_memset(buffers_[t->id], 0, bytes, nullptr) != 0 || rt_stream_sync(nullptr) != 0)) return false;
     }
     if (eng_.workspace_bytes_ && !workspace_) {
-        if (rt_malloc(&workspace_, eng_.workspace_bytes_) != 0) return false;
+        if (rt_malloc(&workspace_, 2 * eng_.workspace_bytes_) != 0) return false;        // one block per stream of the context (main, side)
         workspace_bytes_ = eng_.workspace_bytes_;
     }
     alloc_batch_ = batch;
@@ -2082,8 +2089,8 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
                                           op.twin ? 2 * batch : batch, st, streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
                 break;
             case OpKind::kConv3D:
-                rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y,
-                                              op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr, (cudaStream_t)st);
+                rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,
+                                              wsOf(st == side_stream_ && two), workspace_bytes_, (cudaStream_t)st);
                 break;
             case OpKind::kPlugin: {
                 const void* ins[8];
@@ -2101,12 +2108,12 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
                     if (rc == 0 && !ho) rc = RT_E_NOMEM;
                     if (rc == 0) {
                         outs[0] = ho;
-                        rc = op.plugin->enqueue(batch, ins, outs, workspace_, (cudaStream_t)st);
+                        rc = op.plugin->enqueue(batch, ins, outs, wsOf(st == side_stream_ && two), (cudaStream_t)st);
                     }
                     if (rc == 0) rc = rt_convert_format(ho, y, batch, out.dims.d[0], (int64_t)(volume(out.dims) / out.dims.d[0]), op.half_kind, 0, st);
                     break;
                 }
-                rc = op.plugin->enqueue(batch, ins, outs, workspace_, (cudaStream_t)st);
+                rc = op.plugin->enqueue(batch, ins, outs, wsOf(st == side_stream_ && two), (cudaStream_t)st);
                 break;
             }
             case OpKind::kAdd:

@@ -45,7 +45,8 @@ public:
     // 3 = output only together with the input), and their layouts (kept across setFusion)
     virtual int ilCaps() const { return 0; }
     virtual bool setLayouts(bool, bool, bool) { return false; }
-    virtual int enqueueFused(int, const void*, void*, const void*, cudaStream_t) { return -1; }
+    // (workspace: getWorkspaceSize(maxBatchSize) bytes private to the stream, or null -- the plan then uses a block of its own)
+    virtual int enqueueFused(int, const void*, void*, const void*, void*, size_t, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}
 };
 

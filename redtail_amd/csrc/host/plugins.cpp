@@ -318,13 +318,15 @@ public:
         if (plan_) rt_conv_plan_destroy(plan_);
         plan_ = nullptr;
     }
-    size_t getWorkspaceSize(int) const override { return 0; }
-    int enqueue(int batchSize, const void* const* inputs, void** outputs, void*, cudaStream_t stream) override {
-        return enqueueFused(batchSize, inputs[0], outputs[0], nullptr, stream);
+    // scratch of the plan's launches (the factored first Conv3D over a folded cost volume keeps four small maps per sample): the runtime
+    // owns it and hands it to enqueue, as TensorRT does for the reference's plugins (lib/conv3d_plugin.cpp:179-190)
+    size_t getWorkspaceSize(int maxBatchSize) const override { return plan_ ? rt_conv_plan_workspace_bytes(plan_, maxBatchSize) : 0; }
+    int enqueue(int batchSize, const void* const* inputs, void** outputs, void* workspace, cudaStream_t stream) override {
+        return enqueueFused(batchSize, inputs[0], outputs[0], nullptr, workspace, workspace ? getWorkspaceSize(batchSize) : 0, stream);
     }
-    int enqueueFused(int batchSize, const void* x, void* y, const void* residual, cudaStream_t stream) override {
+    int enqueueFused(int batchSize, const void* x, void* y, const void* residual, void* workspace, size_t workspace_bytes, cudaStream_t stream) override {
         if (!plan_) return -1;
-        int rc = rt_conv_enqueue(plan_, x, y, residual, batchSize, stream);
+        int rc = rt_conv_enqueue_ws(plan_, x, y, residual, batchSize, workspace, workspace_bytes, stream, 0);
         RT_CHECKL(rc, log_);
         return rc == 0 ? 0 : -1;
     }

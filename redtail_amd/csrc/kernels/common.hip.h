@@ -100,6 +100,30 @@ __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned v
 #define RT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
 
+// ---- hand-placed waits around LDS-DMA (conv_f16dw.hip.h) -------------------------------------------------------------------------------
+// __syncthreads() drains the vector-memory counter whenever an LDS-DMA is pending -- and with it every global STORE the wave has in flight
+// (gfx9 counts stores on vmcnt): a kernel that stores its results in the middle of a phase would wait for their acknowledgement at the
+// next barrier.  These two let it wait for its DMA pieces where that is cheap and cross the barrier with the stores still under way.
+// wait_vmem_but<N>: all but the N newest vector-memory operations are complete (loads return in order among themselves).
+// pack_f16: two fp32 values rounded to nearest even into one register (v_cvt_pk_f16_f32, new on gfx950: one instruction instead of three).
+#ifdef HIPEMU
+__device__ static __forceinline__ void wait_vmem() {}
+template <int N> __device__ static __forceinline__ void wait_vmem_but() {}
+__device__ static __forceinline__ void lds_barrier() { __syncthreads(); }
+__device__ static __forceinline__ unsigned pack_f16(float lo, float hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16);
+}
+#else
+__device__ static __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> __device__ static __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ static __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ static __forceinline__ unsigned pack_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+#endif
+
 // ---- storage-type generic element access ---------------------------------------------------------------------
 // Activations are stored as fp32 or (TensorRT "half2 mode": setHalf2Mode + fp16 weights, sample_app/main.cpp:256-262)
 // as fp16; arithmetic is fp32 either way (what the reference's fp16 correlation kernel does too,

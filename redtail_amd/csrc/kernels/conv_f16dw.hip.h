@@ -28,6 +28,18 @@
 
 namespace rt {
 
+// tools/iso_conv3d.py builds instrumented variants (-DRT_DW_ABL=<mask>: 1 no patch loads, 2 no stores, 4 no MFMAs, 8 no skip-tensor loads,
+// 16 patch loads for the first three chunks only);
+// the product has 0 and every switch folds away
+#ifndef RT_DW_ABL
+#define RT_DW_ABL 0
+#endif
+constexpr int kDwAbl = RT_DW_ABL;
+#ifndef RT_DW_VALU_PER_MFMA
+#define RT_DW_VALU_PER_MFMA 5
+#endif
+constexpr int kDwValuPerMfma = RT_DW_VALU_PER_MFMA;
+
 struct ConvF16DwCfg {
     static constexpr int NH = 2, NWH = 4, RPW = 3;                 // tiles per workgroup, waves per tile, output rows per wave
     static constexpr int TY = NWH * RPW, TX = 32, CC = 16;
@@ -37,17 +49,18 @@ struct ConvF16DwCfg {
     static constexpr int GBUF = GPIECES * 64;
     static constexpr int WFR = 27;                                 // weight fragments (32 co x 16 ci = 1 KB) per chunk
     static constexpr int WBUF = WFR * 64;
-    static constexpr int P_SLOTS = NH * 2 * 2 * GBUF;              // [tile][buffer][group][GBUF]
+    static constexpr int NPB = 3;                                  // patch ring: chunk q in buffer q % 3 (read / landing / being issued)
+    static constexpr int P_SLOTS = NH * NPB * 2 * GBUF;            // [tile][buffer][group][GBUF]
     static constexpr int LDS_SLOTS = 2 * WBUF + P_SLOTS + 8;       // + bias (32 floats)
     static constexpr int LDS_BYTES = LDS_SLOTS * 16;
 };
 
 // RESIDENT: p.dw_cpc <= 2 chunks per slice, their weight slabs stay in the two weight buffers for the whole walk
-// HAS_R: a skip tensor (channel-interleaved like the output) is added before the activation
-template <bool RESIDENT, bool HAS_R>
+// HAS_R: a skip tensor (channel-interleaved like the output) is added before the activation;  ELU: the activation (else none)
+template <bool RESIDENT, bool HAS_R, bool ELU>
 __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(ConvArgs p) {
     using Cfg = ConvF16DwCfg;
-    constexpr int RPW = Cfg::RPW, PC = Cfg::PC, GBUF = Cfg::GBUF, WBUF = Cfg::WBUF;
+    constexpr int RPW = Cfg::RPW, PC = Cfg::PC, GBUF = Cfg::GBUF, WBUF = Cfg::WBUF, NPB = Cfg::NPB;
     constexpr unsigned ES = 2;
     __shared__ __attribute__((aligned(16))) f32x4 smem[Cfg::LDS_SLOTS];
     f32x4* const sW = smem;
@@ -75,8 +88,8 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
     const int tx0 = (tile % p.tiles_x) * Cfg::TX, ty0 = (tile / p.tiles_x) * Cfg::TY;
     const int cpc = p.dw_cpc, C = cpc * Cfg::CC, D = p.nz;
     const int d0 = seg * p.dw_seg, d1 = d0 + p.dw_seg < D ? d0 + p.dw_seg : D;       // output slices [d0, d1)
-    const int ta = d0 > 0 ? d0 - 1 : 0, tb = d1;                                     // steps (input slices) ta .. tb; step D has no input
-    const int tin = tb < D ? tb : D - 1;
+    const int ta = d0 > 0 ? d0 - 1 : 0;                                              // steps = input slices ta .. tin
+    const int tin = d1 < D ? d1 : D - 1;
     const int nq = (tin - ta + 1) * cpc;                                             // chunks of this walk
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
     const int Ho = p.Ho, Wo = p.Wo;
@@ -99,28 +112,42 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, RT_LDS_PTR(sW + wbuf * WBUF + fr * 64), 16, (unsigned)lane * 16u,
                                                  (unsigned)(((v * cpc + c) * 9 + tap) * 1024), 0, 0);
     };
-    auto issue = [&](int q) __attribute__((always_inline)) {          // chunk q of the walk -> patch buffer q & 1 (and, streamed, weight buffer q & 1)
-        const int t = ta + q / cpc, c = q - (q / cpc) * cpc;
-        const int* __restrict__ tabrow = p.ch_off + (int64_t)t * p.CinPad + C + c * Cfg::CC;       // depth tap 1 of output slice t reads input slice t
+    // Patch of chunk q = (input slice ip, 16-channel chunk icp) -> ring buffer q % 3 (pwr).  Dense (D, C/8, H, W, 8) tensor: channel
+    // group j of slice t starts at element (t * C + 8 j) * plane -- scalar arithmetic (a gather-table look-up here is a VECTOR load whose
+    // result the buffer resource has to be made uniform from, behind a vmcnt(0): round 5, first version).  kPieces LDS-DMA instructions.
+    constexpr int kPieces = 4;
+    int ip = ta, icp = 0, pwr = 0;
+    const unsigned plane2 = (unsigned)p.x_cstride * ES;
+    const buf_rsrc rs_x = make_buf(xb, tile_ok);
+    int n_issued = 0;
+    auto issue_patch = [&]() __attribute__((always_inline)) {
+        const bool skip = (kDwAbl & 1) || ((kDwAbl & 16) && n_issued >= 3);        // 16: the ring is filled once (real data) and never refreshed
+        n_issued++;
 #pragma unroll
         for (int g = 0; g < 2; g++) {
-            const int off = tabrow[8 * g];
-            const buf_rsrc rs = make_buf(xb, off >= 0);
-            f32x4* dst = sP + ((hw * 2 + (q & 1)) * 2 + g) * GBUF + (2 * wq) * 64;
+            const unsigned so = (unsigned)(ip * C + icp * Cfg::CC + 8 * g) * plane2;
+            f32x4* dst = sP + ((hw * NPB + pwr) * 2 + g) * GBUF + (2 * wq) * 64;
 #pragma unroll
             for (int k = 0; k < 2; k++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, RT_LDS_PTR(dst + k * 64), 16, voff[k], (unsigned)off * ES, 0, 0);
+                if (!skip) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, RT_LDS_PTR(dst + k * 64), 16, voff[k], so, 0, 0);
         }
-        if constexpr (!RESIDENT) {
+        if (++icp == cpc) { icp = 0; ip++; }
+        pwr = pwr == NPB - 1 ? 0 : pwr + 1;
+    };
+    // streamed weights: the slab of chunk q -> weight buffer q & 1
+    int icw = 0, wwr = 0;
+    auto issue_weights = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int fr = wv + 8 * j;
-                if (fr < Cfg::WFR) weights_to_lds(c, q & 1, fr);
-            }
+        for (int j = 0; j < 4; j++) {
+            const int fr = wv + 8 * j;
+            if (fr < Cfg::WFR) weights_to_lds(icw, wwr, fr);
         }
+        if (++icw == cpc) icw = 0;
+        wwr ^= 1;
     };
 
-    // ---- prologue: zero the patch buffers (out-of-image slots are never written again), bias, resident weights, first chunk -------------
+    // ---- prologue: zero the patch ring (slots outside the image are only ever written with the zeros of out-of-range DMA lanes), bias,
+    // weights (all of them when resident, else chunk 0), the first two patches
     for (int i = tid; i < Cfg::P_SLOTS; i += 512) sP[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 32) sBias[tid] = p.bias[nblk * 32 + tid];
     __syncthreads();
@@ -129,14 +156,38 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
             const int c = f / Cfg::WFR;
             weights_to_lds(c, c, f - c * Cfg::WFR);
         }
+    } else {
+        issue_weights();
     }
-    issue(0);
+    issue_patch();
+    if (nq > 1) issue_patch();
+    wait_vmem();
+    lds_barrier();
+
+    // End of phase q: the patch of chunk q + 2 goes into the buffer chunk q - 1 was read from (every wave is past the barrier that ended
+    // phase q - 1).  Before the barrier this wave's pieces of chunk q + 1 (issued a phase ago) must have landed:
+    //   * a phase WITHOUT stores waits until all but the kPieces newest vector-memory operations are complete -- loads return in order, so
+    //     a pending piece of chunk q + 1 implies kPieces pending newer ones (stores of an earlier phase may be among the waited-for: they
+    //     are a phase old);
+    //   * a phase WITH stores (the epilogue) has waited for everything BEFORE its first store (`before_stores`) -- chunk q + 1 was issued a
+    //     phase and 27 MFMAs earlier -- and crosses the barrier with its stores and the new pieces in flight.  Stores count on vmcnt and may
+    //     complete out of order with loads, so no counted wait can tell them from the pieces; waiting for them here would put the store
+    //     latency of every step on the critical path (measured, first version: loads, stores and MFMAs took the SUM of their times).
+    auto end_phase = [&](int q, bool waited) __attribute__((always_inline)) {
+        if (q + 2 < nq) {
+            issue_patch();
+            if (!waited) { if (kDwAbl & 17) wait_vmem(); else wait_vmem_but<kPieces>(); }
+        } else if (!waited) {
+            wait_vmem();
+        }
+        lds_barrier();
+    };
 
     // ---- waves without a row of the image (ragged last tile, odd tile count) only keep their LDS-DMA and barrier duties ------------------
     if (!wave_on) {
         for (int q = 0; q < nq; q++) {
-            __syncthreads();
-            if (q + 1 < nq) issue(q + 1);
+            if (!RESIDENT && q + 1 < nq) issue_weights();
+            end_phase(q, false);
         }
         return;
     }
@@ -154,21 +205,22 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
         }
     };
 
-    // ---- epilogue of output slice d from accumulator set AI: skip tensor, activation, 8-byte stores of 4 consecutive channels ----------
+    // ---- epilogue of output slice d from accumulator set AI: skip tensor, activation, 8-byte stores of 4 consecutive channels.  Branch-free
+    // (`live` only masks the addresses) so that it can be scheduled into the MFMA stream that follows it.
     const int cs32 = (int)p.y_cstride, rs32 = (int)p.r_cstride;
     const int ox = tx0 + l31;
-    const bool noact = p.act != 1;
     unsigned yvoff[RPW];
 #pragma unroll
     for (int y = 0; y < RPW; y++) {
         const int oy = ty0 + wq * RPW + y;
         yvoff[y] = (oy < Ho && ox < Wo) ? (unsigned)((oy * p.y_ystride + ox) * 8 + 4 * half) * ES : kBufOOB;
     }
-    auto epilogue = [&](auto aic, int d) __attribute__((always_inline)) {
+    auto epilogue = [&](auto aic, int d, bool live) __attribute__((always_inline)) {
         constexpr int AI = decltype(aic)::value;
         const int64_t zoff = p.y_off + (int64_t)d * p.y_zstride;
         const char* yb = elem_ptr(p.y, (int64_t)n * p.y_bstride + zoff, ES);
         const char* rb = HAS_R ? elem_ptr(p.resid, (int64_t)n * p.r_bstride + zoff, ES) : nullptr;
+        const unsigned dead = live ? 0u : kBufOOB;
 #pragma unroll
         for (int y = 0; y < RPW; y++) {
 #pragma unroll
@@ -178,18 +230,19 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[AI][y][4 * q4 + e];
                 if constexpr (HAS_R) {
-                    const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(make_buf(rb, cs < p.Cout), yvoff[y], (unsigned)(cs * rs32) * ES, 0);
+                    const u32x2_t u = (kDwAbl & 8) ? u32x2_t{0u, 0u}
+                                                   : __builtin_amdgcn_raw_buffer_load_b64(make_buf(rb, cs < p.Cout), yvoff[y] | dead, (unsigned)(cs * rs32) * ES, 0);
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] += (float)__builtin_bit_cast(_Float16, (unsigned short)(u[e >> 1] >> (16 * (e & 1))));
                 }
+                if constexpr (ELU) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = (v[e] > 0.f || noact) ? v[e] : fast_exp(v[e]) - 1.f;      // ELU or nothing (host contract)
+                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : fast_exp(v[e]) - 1.f;
+                }
                 u32x2_t o;
 #pragma unroll
-                for (int e = 0; e < 2; e++)
-                    o[e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * e]) |
-                           ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * e + 1]) << 16);
-                __builtin_amdgcn_raw_buffer_store_b64(o, make_buf(yb, cs < p.Cout), yvoff[y], (unsigned)(cs * cs32) * ES, 0);
+                for (int e = 0; e < 2; e++) o[e] = pack_f16(v[2 * e], v[2 * e + 1]);
+                if (!(kDwAbl & 2)) __builtin_amdgcn_raw_buffer_store_b64(o, make_buf(yb, cs < p.Cout), yvoff[y] | dead, (unsigned)(cs * cs32) * ES, 0);
             }
         }
     };
@@ -198,40 +251,83 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
     // runs in every step (no branch touches an accumulator): at the two ends of a segment the groups that belong to slices of the
     // neighbouring segments compute into sets that are never stored (two steps' worth of MFMAs per segment; the volume's own first and last
     // slice cost a third of a step each) -- the host keeps segments long.
-    int q = 0;
+    int q = 0, prd = 0;
     auto step = [&](auto phc, int t) __attribute__((always_inline)) {
         constexpr int PH = decltype(phc)::value;
         constexpr int A0 = (PH + 1) % 3, A1 = PH, A2 = (PH + 2) % 3;     // sets of the outputs t + 1 (tap v = 0), t (v = 1), t - 1 (v = 2)
         const bool fin = t - 1 >= d0;                                     // output t - 1 belongs to this segment (t <= d1 always)
         init_acc(std::integral_constant<int, A0>());
-        for (int c = 0; c < cpc; c++, q++) {
-            __syncthreads();                   // (vmcnt(0) first) chunk q has landed for every wave; every wave is done with chunk q - 1
-            if (q + 1 < nq) issue(q + 1);
-            const f32x4* pB = sP + ((hw * 2 + (q & 1)) * 2 + half) * GBUF + (wq * RPW) * PC + l31;
+        // the 5 patch rows at column shift s are read once (20 VGPRs) and serve the (v, r) taps of the shift
+        auto taps = [&](const f32x4* pA, const f16x8_t (&b)[RPW + 2], int s, auto vc, auto aic) __attribute__((always_inline)) {
+            constexpr int V = decltype(vc)::value, AI = decltype(aic)::value;
+            f16x8_t a[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) a[r] = __builtin_bit_cast(f16x8_t, pA[(V * 9 + r * 3 + s) * 64]);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int y = 0; y < RPW; y++) {
+                    if (kDwAbl & 4) acc[AI][y][0] += (float)a[r][0] * (float)b[y + r][0];
+                    else acc[AI][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[r], b[y + r], acc[AI][y], 0, 0, 0);
+                }
+        };
+        // (the last chunk is peeled off the loop rather than branched to inside it: a branch that both arms update the accumulators in
+        //  costs the register allocator a second copy of them -- measured: 900 spilled registers)
+        for (int c = 0; c + 1 < cpc; c++, q++) {
+            if (!RESIDENT && q + 1 < nq) issue_weights();
+            const f32x4* pB = sP + ((hw * NPB + prd) * 2 + half) * GBUF + (wq * RPW) * PC + l31;
             const f32x4* pA = sW + (RESIDENT ? c : (q & 1)) * WBUF + lane;
-            // column shift s outermost: the 5 patch rows at that shift are read once (20 VGPRs) and serve the 9 (v, r) taps of the shift
 #pragma unroll
             for (int s = 0; s < 3; s++) {
                 f16x8_t b[RPW + 2];
 #pragma unroll
                 for (int pp = 0; pp < RPW + 2; pp++) b[pp] = __builtin_bit_cast(f16x8_t, pB[pp * PC + s]);
-                auto taps = [&](auto vc, auto aic) __attribute__((always_inline)) {
-                    constexpr int V = decltype(vc)::value, AI = decltype(aic)::value;
-                    f16x8_t a[3];
-#pragma unroll
-                    for (int r = 0; r < 3; r++) a[r] = __builtin_bit_cast(f16x8_t, pA[(V * 9 + r * 3 + s) * 64]);
-#pragma unroll
-                    for (int r = 0; r < 3; r++)
-#pragma unroll
-                        for (int y = 0; y < RPW; y++) acc[AI][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[r], b[y + r], acc[AI][y], 0, 0, 0);
-                };
-                taps(std::integral_constant<int, 2>(), std::integral_constant<int, A2>());
-                if (s == 2 && fin && c == cpc - 1) epilogue(std::integral_constant<int, A2>(), t - 1);
-                taps(std::integral_constant<int, 1>(), std::integral_constant<int, A1>());
-                taps(std::integral_constant<int, 0>(), std::integral_constant<int, A0>());
+                taps(pA, b, s, std::integral_constant<int, 2>(), std::integral_constant<int, A2>());
+                taps(pA, b, s, std::integral_constant<int, 1>(), std::integral_constant<int, A1>());
+                taps(pA, b, s, std::integral_constant<int, 0>(), std::integral_constant<int, A0>());
             }
+            end_phase(q, false);
+            prd = prd == NPB - 1 ? 0 : prd + 1;
         }
-        if (t == D - 1) epilogue(std::integral_constant<int, A1>(), t);      // the volume's last slice has no slice behind it
+        {
+            // the slice's last chunk: the v = 2 taps of all three shifts first -- output t - 1 is complete after 27 MFMAs -- then its
+            // epilogue together with the 54 MFMAs of the v = 1 and v = 0 taps (the patch rows are read a second time: 15 ds_read_b128).
+            // Same order of summation per accumulator as the plain form: shifts outermost, kernel rows inside.
+            if (!RESIDENT && q + 1 < nq) issue_weights();
+            const f32x4* pB = sP + ((hw * NPB + prd) * 2 + half) * GBUF + (wq * RPW) * PC + l31;
+            const f32x4* pA = sW + (RESIDENT ? cpc - 1 : (q & 1)) * WBUF + lane;
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                f16x8_t b[RPW + 2];
+#pragma unroll
+                for (int pp = 0; pp < RPW + 2; pp++) b[pp] = __builtin_bit_cast(f16x8_t, pB[pp * PC + s]);
+                taps(pA, b, s, std::integral_constant<int, 2>(), std::integral_constant<int, A2>());
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmem();                       // before_stores: chunk q + 1 (and a streamed weight slab) has landed; see end_phase
+            epilogue(std::integral_constant<int, A2>(), t - 1, fin);
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                f16x8_t b[RPW + 2];
+#pragma unroll
+                for (int pp = 0; pp < RPW + 2; pp++) b[pp] = __builtin_bit_cast(f16x8_t, pB[pp * PC + s]);
+                taps(pA, b, s, std::integral_constant<int, 1>(), std::integral_constant<int, A1>());
+                taps(pA, b, s, std::integral_constant<int, 0>(), std::integral_constant<int, A0>());
+            }
+            // one MFMA, then the vector instructions that fit under it (MI355X_MICROARCH.md: <= 5 per v_mfma_f32_32x32x16)
+            if (kDwValuPerMfma > 0) {
+#pragma unroll
+                for (int i = 0; i < 54; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, kDwValuPerMfma, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            end_phase(q, true);
+            prd = prd == NPB - 1 ? 0 : prd + 1;
+            q++;
+        }
+        if (t == D - 1) epilogue(std::integral_constant<int, A1>(), t, true);      // the volume's last slice has no slice behind it
     };
 
     init_acc(std::integral_constant<int, 0>());

@@ -250,6 +250,108 @@ __global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p
     }
 }
 
+// ---- the same kernel WALKING DOWN THE DEPTH AXIS (round 5; K = 32) -----------------------------------------------------------------------
+// deconv3d_s2_il_kernel gives a wave three 16-block groups of one depth block and lets it go: 131 k wave-lives per pair for NVSmall's last
+// layer, each with its own prologue (weight operands, address set-up), every input slice requested by two depth blocks: 2.5-2.9 TB/s of
+// algorithmic bytes (profiles/r04_traffic_3d.json: 11 % MFMA-busy, nothing else busy either).  Here a wave keeps its 16 blocks x 2 block rows
+// and walks the depth blocks of a segment: the slice two consecutive depth blocks share stays in registers (6 instead of 12 16-byte loads per
+// step), the next slice is requested before the current step's MFMAs (three register sets, the loop unrolled by three so that their roles
+// are static), and prologue and weight operands are paid once per walk.  Same arithmetic in the same order: bit-identical.
+// Grid: x = ceil(groups / 4) * segments, y = pairs of block rows, z = samples; p.Mz = depth blocks, seg_len blocks per segment.
+__global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs p, int seg_len, int nseg) {
+    const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seg = blockIdx.x % nseg, bxg = blockIdx.x / nseg;
+    const int my0 = 2 * blockIdx.y, n = blockIdx.z;
+    const int ngroups = (int)cdiv((p.Wx + 1) / 2, 16);
+    const int grp = bxg * 4 + wv;                                  // wave-uniform
+    if (grp >= ngroups) return;
+    const int z0 = seg * seg_len, z1 = z0 + seg_len < p.Mz ? z0 + seg_len : p.Mz;
+    const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, 2));
+    const buf_rsrc rs_w = make_buf(p.w);
+    const buf_rsrc rs_y = make_buf(elem_ptr(p.y, (int64_t)n * p.y_bstride, 4));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, (int64_t)n * p.y_bstride, 4), p.resid != nullptr);
+    const unsigned gstride = (unsigned)(p.Dy * p.Hy * p.xp) * 16u;           // bytes between channel groups of the input
+    const int co = q >> 1, fz = q & 1;
+    const float bias = co < p.C ? p.bias[co] : 0.f;
+    const bool has_r = p.resid != nullptr;                        // uniform
+    const int nrows = (p.Hx + 1) / 2;
+    const int mx = grp * 16 + n16;
+
+    f32x4 a0[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a0[j] = buf_load4(rs_w, (unsigned)(j * 64 + lane) * 16u, 0);
+
+    // in-plane part of the six positions (rows my0 + by + {0, 1, 2}, columns mx + bx + {0, 1}) of this lane's channel group; the slice is a
+    // wave-uniform scalar offset
+    unsigned pos[3][2];
+#pragma unroll
+    for (int ry = 0; ry < 3; ry++)
+#pragma unroll
+        for (int jx = 0; jx < 2; jx++) {
+            const int iy = my0 + p.by + ry, ix = mx + p.bx + jx;
+            pos[ry][jx] = (iy >= 0 && iy < p.Hy && ix >= 0 && ix < p.Wy) ? (unsigned)(iy * p.xp + ix) * 16u + (unsigned)q * gstride : kBufOOB;
+        }
+    const unsigned zbytes = (unsigned)(p.Hy * p.xp) * 16u;
+    auto load_slice = [&](f32x4 (&b)[3][2], int iz) __attribute__((always_inline)) {
+        const bool ok = iz >= 0 && iz < p.Dy;                     // uniform
+#pragma unroll
+        for (int ry = 0; ry < 3; ry++)
+#pragma unroll
+            for (int jx = 0; jx < 2; jx++) b[ry][jx] = buf_load4(rs_x, ok ? pos[ry][jx] : kBufOOB, ok ? (unsigned)iz * zbytes : 0u);
+    };
+    auto block = [&](int mz, const f32x4 (&b0)[3][2], const f32x4 (&b1)[3][2]) __attribute__((always_inline)) {
+        f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const f16x8_small a = __builtin_bit_cast(f16x8_small, a0[j]);
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+                const f32x4 bv = (j >> 2) ? b1[row + ((j >> 1) & 1)][j & 1] : b0[row + ((j >> 1) & 1)][j & 1];
+                acc[row] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(f16x8_small, bv), acc[row], 0, 0, 0);
+            }
+        }
+        const int oz = 2 * mz + fz, ox = 2 * mx;
+#pragma unroll
+        for (int row = 0; row < 2; row++) {
+            if (my0 + row >= nrows) break;                         // uniform
+#pragma unroll
+            for (int fy = 0; fy < 2; fy++) {
+                const int oy = 2 * (my0 + row) + fy;
+                const bool row_ok = co < p.C && oz < p.Dx && oy < p.Hx;
+                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
+                const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
+                const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
+                f32x2_t o = {acc[row][2 * fy], acc[row][2 * fy + 1]};
+                if (has_r) {
+                    const f32x2_t r2 = buf_load2(rs_r, v2, 0);
+                    const float r1 = buf_load(rs_r, v1, 0);
+                    o[0] += r2[0] + r1;
+                    o[1] += r2[1];
+                }
+                o[0] = apply_act_rt(o[0], p.act);
+                o[1] = apply_act_rt(o[1], p.act);
+                buf_store2(o, rs_y, v2, 0);
+                buf_store(o[0], rs_y, v1, 0);
+            }
+        }
+    };
+
+    f32x4 s0[3][2], s1[3][2], s2[3][2];
+    load_slice(s0, z0 + p.bz);
+    load_slice(s1, z0 + p.bz + 1);
+    for (int mz = z0; mz < z1; mz += 3) {
+        load_slice(s2, mz + p.bz + 2);             // (beyond the segment / the volume: zeros, never used)
+        block(mz, s0, s1);
+        if (mz + 1 >= z1) break;
+        load_slice(s0, mz + p.bz + 3);
+        block(mz + 1, s1, s2);
+        if (mz + 2 >= z1) break;
+        load_slice(s1, mz + p.bz + 4);
+        block(mz + 2, s2, s0);
+    }
+}
+
 // ---- ... and for fp32 engines: input (K/4, Dy, Hy, Wy, 4) fp32, 3-term fp16 split ---------------------------------------------------------
 // The vector-ALU kernel at the top reads its fp32 input with one 4-byte load per channel and neighbour (NVSmall: 0.40 ms for 254 MB in +
 // 127 MB out; PMC: 2.3 GB through the L2).  With the layer's input channel-interleaved in groups of 4 (written that way by

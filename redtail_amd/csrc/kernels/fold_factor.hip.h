@@ -11,6 +11,8 @@
 // same convolution evaluated one column beyond the image on the left (column -1 sees R[., 0] through the tap dx = +1).  So:
 //   A_v  = conv3x3(L, sum_{j in v} W_j^L),   v = first / middle / last depth slice       one 2-D convolution F -> 3K
 //   C'_j = conv3x3([0 | R], W_j^R)           (R with one zero column in front)           one 2-D convolution F -> 3K, width W + 1
+//                                            (round 5: R itself with a left pad of 2 -- no copy; the plan's output is W + 2 wide, its last
+//                                             column is never read)
 //   T_v(u) = sum_{j in v} C'_j(u - j + 2),   u = x - d in [-2, W-1]                     one small pass (the three taps' shifts folded)
 //   out[d](x) = act( b + A_v(d)(x) + T_v(d)(x - d) - [x = W-1] E[d] )
 // Both convolutions run on the split-fp16 kernels of conv_split.hip.h (fp32-class accuracy); what is left per output voxel is one load
@@ -27,52 +29,55 @@ namespace rt {
 struct FoldFactorArgs {
     const float* x;        // (N, 2F, H, W) fp32 planar: [left | right] feature maps
     const float* a;        // (N, 3K, H, W): A_first, A_middle, A_last
-    const float* c;        // (N, 3K, H, W + 1): C'_0, C'_1, C'_2
-    float* t;              // (N, 3K, H, W + 2): T_first, T_middle, T_last at index u + 2
-    float* rext;           // (N, F, H, W + 1)
+    const float* c;        // (N, 3K, H, W + 2): C'_0, C'_1, C'_2 (column W + 1 is not used)
+    float* t;              // (N, 3K/G, H, W + 2, G): T_first, T_middle, T_last at index u + 2, channel-interleaved in the combining pass's groups
     float* e;              // (N, D, K, H)
     const float* wedge;    // [j 3][dy 3][c F][k K]: w[k, j, F + c, dy, dx = 2]
     const float* bias;     // [K]
     void* y;               // output, depth-major: (N, D, K, H, W) planar or (N, D, K/G, H, W, G) interleaved (G = 4 fp32, 8 fp16)
     int F, K, D, H, W;
     int act;
-    int64_t x_bstride, a_bstride, c_bstride, t_bstride, r_bstride, e_bstride, y_bstride;    // elements
+    int64_t x_bstride, a_bstride, c_bstride, t_bstride, e_bstride, y_bstride;    // elements
 };
 
-// R -> [0 | R]
-__global__ void __launch_bounds__(256) fold_pad_kernel(FoldFactorArgs p) {
-    const int xw = blockIdx.x * 256 + threadIdx.x;            // column of R_ext
-    const int y = blockIdx.y, c = blockIdx.z % p.F, n = blockIdx.z / p.F;
-    if (xw > p.W) return;
-    const float v = xw == 0 ? 0.f : p.x[(int64_t)n * p.x_bstride + ((int64_t)(p.F + c) * p.H + y) * p.W + xw - 1];
-    p.rext[(int64_t)n * p.r_bstride + ((int64_t)c * p.H + y) * (p.W + 1) + xw] = v;
-}
-
-// T_v[n, v K + k, y, i] = sum_{j in v} C'_j[k, y, i - j]  (i = u + 2 in [0, W + 1]; C' indices outside [0, W] contribute nothing)
+// T_v[n, v K + k, y, i] = sum_{j in v} C'_j[k, y, i - j]  (i = u + 2 in [0, W + 1]; C' indices outside [0, W] contribute nothing), written
+// in groups of G channels: one thread per (i, y, group) reads 3 G planar values (coalesced along i) and stores 3 x G / 4 16-byte slots
+template <int G>
 __global__ void __launch_bounds__(256) fold_t_kernel(FoldFactorArgs p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y, k = blockIdx.z % p.K, n = blockIdx.z / p.K;
+    const int KG = p.K / G;
+    const int y = blockIdx.y, kg = blockIdx.z % KG, n = blockIdx.z / KG;
     if (i > p.W + 1) return;
-    const int64_t cplane = (int64_t)p.H * (p.W + 1), tplane = (int64_t)p.H * (p.W + 2);
-    const float* __restrict__ c = p.c + (int64_t)n * p.c_bstride + (int64_t)y * (p.W + 1);
-    float cj[3];
+    const int64_t cplane = (int64_t)p.H * (p.W + 2);
+    const float* __restrict__ c = p.c + (int64_t)n * p.c_bstride + (int64_t)y * (p.W + 2);
+    float tv[3][G];
 #pragma unroll
-    for (int j = 0; j < 3; j++) cj[j] = (i - j >= 0 && i - j <= p.W) ? c[(int64_t)(j * p.K + k) * cplane + i - j] : 0.f;
-    float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2) + i;
-    // (summed in tap order 0, 1, 2)
-    t[(int64_t)(0 * p.K + k) * tplane] = cj[1] + cj[2];
-    t[(int64_t)(1 * p.K + k) * tplane] = (cj[0] + cj[1]) + cj[2];
-    t[(int64_t)(2 * p.K + k) * tplane] = cj[0] + cj[1];
+    for (int g = 0; g < G; g++) {
+        float cj[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) cj[j] = (i - j >= 0 && i - j <= p.W) ? c[(int64_t)(j * p.K + kg * G + g) * cplane + i - j] : 0.f;
+        // (summed in tap order 0, 1, 2)
+        tv[0][g] = cj[1] + cj[2];
+        tv[1][g] = (cj[0] + cj[1]) + cj[2];
+        tv[2][g] = cj[0] + cj[1];
+    }
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + ((((int64_t)v * KG + kg) * p.H + y) * (p.W + 2) + i) * G;
+#pragma unroll
+        for (int q = 0; q < G / 4; q++) *reinterpret_cast<f32x4*>(t + 4 * q) = f32x4{tv[v][4 * q], tv[v][4 * q + 1], tv[v][4 * q + 2], tv[v][4 * q + 3]};
+    }
 }
 
-// E[n, d, k, y]: one thread per (k, y); grid (ceil(H * K / 256), D, N)
+// E[n, d, k, y]: one thread per (4 output channels, y) -- the image column is read once for the four; grid (ceil(H * K / 4 / 256), D, N)
 __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int d = blockIdx.y, n = blockIdx.z;
-    if (t >= p.H * p.K) return;
-    const int k = t % p.K, y = t / p.K;
+    const int K4 = p.K / 4;
+    if (t >= p.H * K4) return;
+    const int k = (t % K4) * 4, y = t / K4;
     const float* __restrict__ r = p.x + (int64_t)n * p.x_bstride + (int64_t)p.F * p.H * p.W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};            // four independent chains over the channels (F is a multiple of 4): the loop is latency-bound
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};       // two chains per output over the channels (F is a multiple of 4)
     for (int j = 0; j < 3; j++) {
         const int dz = d + j - 1, col = p.W + 1 - d - j;
         if (dz < 0 || dz >= p.D || d + j < 2 || col < 0) continue;                    // depth padding / the pixel lies outside the image as well
@@ -82,29 +87,36 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
             const float* __restrict__ wv = p.wedge + ((int64_t)(j * 3 + dy) * p.F) * p.K + k;
             const float* __restrict__ rv = r + (int64_t)iy * p.W + col;
             const int64_t cstep = (int64_t)p.H * p.W;
-            for (int c = 0; c < p.F; c += 4) {
+            for (int c = 0; c < p.F; c += 2) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) acc[u] = fmaf(wv[(int64_t)(c + u) * p.K], rv[(c + u) * cstep], acc[u]);
+                for (int u = 0; u < 2; u++) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + (int64_t)(c + u) * p.K);
+                    const float rr = rv[(c + u) * cstep];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[u][q] = fmaf(w4[q], rr, acc[u][q]);
+                }
             }
         }
     }
-    p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k) * p.H + y] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k + q) * p.H + y] = acc[0][q] + acc[1][q];
 }
 
 // out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output.
-// The pass is bound by its vector instructions, not by memory (round 4: 150 per depth slice and wave with 64-bit pointer arithmetic
-// per load): the T maps are read with raw buffer loads -- one lane offset (x - d + 2, out of range = masked = 0 by the buffer's own
-// bounds check) and the plane of each channel as a wave-uniform scalar offset -- and the bias sits in the A registers.
+// Round 4: bound by its vector-memory instructions (G 4-byte loads of T per 16 bytes stored: 2.2 TB/s).  Round 5: T is interleaved in the
+// same groups, so a voxel group is G / 4 16-byte loads (lane offset (x - d + 2) * 4 G bytes, out of range = masked = 0 by the buffer's
+// own bounds check; the row of the group as a wave-uniform scalar offset); the bias sits in the A registers.
 template <typename TOUT, bool IL>
 __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
     constexpr int G = sizeof(TOUT) == 2 ? 8 : 4;
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y, kg = blockIdx.z % (p.K / G), n = blockIdx.z / (p.K / G);
+    const int KG = p.K / G;
+    const int y = blockIdx.y, kg = blockIdx.z % KG, n = blockIdx.z / KG;
     const bool live = x < p.W;
-    const int64_t plane = (int64_t)p.H * p.W, tplane = (int64_t)p.H * (p.W + 2);
+    const int64_t plane = (int64_t)p.H * p.W;
     const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + (live ? x : 0);
     const float* __restrict__ e = p.e + (int64_t)n * p.e_bstride + y;
-    const buf_rsrc rs_t = make_buf(p.t + (int64_t)n * p.t_bstride + (int64_t)y * (p.W + 2));
+    const buf_rsrc rs_t = make_buf(p.t + (int64_t)n * p.t_bstride);
     float av[3][G];                                  // A_v + bias
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -112,35 +124,41 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
 #pragma unroll
         for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane] + b;
     }
-    const unsigned tp4 = (unsigned)(tplane * 4);     // bytes between channel planes of T (3 K planes of one sample: < 4 GB)
-    const unsigned cbase = (unsigned)(kg * G) * tp4;
+    const unsigned trow = (unsigned)(p.W + 2) * (unsigned)(G * 4);            // bytes of one row of a T group (3 K planes of one sample: < 4 GB)
     char* __restrict__ yb = static_cast<char*>(p.y) + (int64_t)n * p.y_bstride * sizeof(TOUT);
     const bool last_col = live && x == p.W - 1;
+    const bool elu = p.act == 1;
     const int act = p.act;
     for (int d = 0; d < p.D; d++) {
         const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);                             // wave-uniform
         const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
-        const unsigned vo = (live && i >= 0) ? (unsigned)i * 4u : kBufOOB;
-        const unsigned vbase = (unsigned)(v * p.K) * tp4 + cbase;
+        const unsigned vo = (live && i >= 0) ? (unsigned)i * (unsigned)(G * 4) : kBufOOB;
+        const unsigned so = (unsigned)((v * KG + kg) * p.H + y) * trow;
         float o[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] = buf_load(rs_t, vo, vbase + (unsigned)g * tp4);
+        for (int q = 0; q < G / 4; q++) {
+            const f32x4 tv = buf_load4(rs_t, vo == kBufOOB ? kBufOOB : vo + 16u * q, so);
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] += av[v][g];
+            for (int g = 0; g < 4; g++) o[4 * q + g] = tv[g] + av[v][4 * q + g];
+        }
         if (last_col) {
 #pragma unroll
             for (int g = 0; g < G; g++) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
         }
+        if (elu) {
 #pragma unroll
-        for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);
+            for (int g = 0; g < G; g++) o[g] = o[g] > 0.f ? o[g] : fast_exp(o[g]) - 1.f;
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);
+        }
         if (!live) continue;
         if constexpr (IL) {
-            TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * (p.K / G) + kg) * plane + (int64_t)y * p.W + x) * G;
+            TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * KG + kg) * plane + (int64_t)y * p.W + x) * G;
             if constexpr (G == 8) {
                 u32x4_t w;
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    w[q] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * q]) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)o[2 * q + 1]) << 16);
+                for (int q = 0; q < 4; q++) w[q] = pack_f16(o[2 * q], o[2 * q + 1]);
                 *reinterpret_cast<u32x4_t*>(dst) = w;
             } else {
                 *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};

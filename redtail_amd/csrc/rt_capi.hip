@@ -15,6 +15,13 @@
 #include <vector>
 
 #include "../../include/rt_stereo.h"
+// Every device build of this file goes through redtail_amd/build.py (DEVICE_FLAGS): compiler-formed packed fp32 math (the SLP vectoriser
+// of -O3) beside co-resident fp16-MFMA waves computed wrong values in round 3 / 4 (profiles/r04_race.txt: 1662 of 4000 launches; 0 with
+// -fno-slp-vectorize) and the hardware mechanism is not established -- so the flag is part of the source's contract, not of one build
+// script: it travels with a define, and a compile without the pair stops here.  tools/check_no_packed_f32.py disassembles the product.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_BUILT_NO_SLP)
+#error "rt_capi.hip must be compiled with -fno-slp-vectorize -DRT_BUILT_NO_SLP (redtail_amd/build.py: DEVICE_FLAGS)"
+#endif
 #include "kernels/common.hip.h"
 #include "kernels/conv_mfma.hip.h"
 #include "kernels/conv_wino.hip.h"
@@ -558,10 +565,14 @@ struct FoldFactor {
     rtConvPlan* pr = nullptr;          // conv3x3 F -> 3K on [0 | right feature map]: C'_0, C'_1, C'_2
     float* wedge_dev = nullptr;        // [j][dy][c][k]: the taps dx = +1 of the right half (edge term)
     int F = 0, K = 0, D = 0, H = 0, W = 0;
-    int64_t a_elems = 0, c_elems = 0, t_elems = 0, r_elems = 0, e_elems = 0;      // per sample
-    // scratch (A, C', [0 | R], E) per stream: execution contexts share a plan and launch it on their own streams
+    int64_t a_elems = 0, c_elems = 0, t_elems = 0, e_elems = 0;      // per sample
+    // Scratch (A, C', T, E: rt_conv_plan_workspace_bytes) belongs to the CALLER: an execution context passes its own workspace
+    // (rt_conv_enqueue_ws; IPlugin::getWorkspaceSize / enqueue's `workspace`, as the reference's plugins receive theirs,
+    // lib/conv3d_plugin.cpp:179-185).  rt_conv_enqueue without one -- the operator-level tests and tools -- falls back to a block owned by
+    // the plan, ONE per plan: such callers drive a plan from one stream at a time.
     std::mutex mu;
-    std::map<void*, std::pair<void*, size_t>> scratch;
+    void* own = nullptr;
+    size_t own_bytes = 0;
 };
 
 struct rtConvPlan {
@@ -570,7 +581,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -1048,8 +1059,7 @@ void free_plan(rtConvPlan* p) {
         if (p->ff->pl) free_plan(p->ff->pl);
         if (p->ff->pr) free_plan(p->ff->pr);
         if (p->ff->wedge_dev) (void)hipFree(p->ff->wedge_dev);
-        for (auto& e : p->ff->scratch)
-            if (e.second.first) (void)hipFree(e.second.first);
+        if (p->ff->own) (void)hipFree(p->ff->own);
         delete p->ff;
     }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
@@ -1395,9 +1405,9 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
         auto ff = new FoldFactor();
         plan->ff = ff;
         ff->F = F; ff->K = K; ff->D = d->D; ff->H = d->H; ff->W = d->W;
-        ff->a_elems = (int64_t)3 * K * d->H * d->W; ff->c_elems = (int64_t)3 * K * d->H * (d->W + 1);
+        ff->a_elems = (int64_t)3 * K * d->H * d->W; ff->c_elems = (int64_t)3 * K * d->H * (d->W + 2);
         ff->t_elems = (int64_t)3 * K * d->H * (d->W + 2);
-        ff->r_elems = (int64_t)F * d->H * (d->W + 1); ff->e_elems = (int64_t)d->D * K * d->H;
+        ff->e_elems = (int64_t)d->D * K * d->H;
         std::vector<float> wl((size_t)3 * K * F * 9, 0.f), wr((size_t)3 * K * F * 9, 0.f), wedge((size_t)9 * F * K, 0.f);
         for (int k = 0; k < K; k++)
             for (int c = 0; c < F; c++)
@@ -1418,8 +1428,11 @@ extern "C" int rt_conv3d_plan_create(rtConvPlan** out, const rtConv3dDesc* d, co
         d2.act = RT_ACT_NONE; d2.has_residual = 0; d2.dtype = RT_F32; d2.flags = d->flags;
         rc = rt_conv2d_plan_create(&ff->pl, &d2, wl.data(), nullptr);
         if (!rc) rc = rt_conv_plan_set_batch_strides(ff->pl, (int64_t)C * d->H * d->W, 0, 0);                    // L: the first F planes of a (2F, H, W) sample
-        d2.Win = d->W + 1;
+        // C' = conv3x3([0 | R]) = conv3x3(R) with a left pad of 2: the plan reads the right feature map where it lies (round 4 copied it
+        // behind a zero column first); its output is W + 2 wide, column W + 1 is never read
+        d2.pad_w = 2;
         if (!rc) rc = rt_conv2d_plan_create(&ff->pr, &d2, wr.data(), nullptr);
+        if (!rc) rc = rt_conv_plan_set_batch_strides(ff->pr, (int64_t)C * d->H * d->W, 0, 0);                    // R: planes F .. 2F-1 of a (2F, H, W) sample
         if (!rc && (hipMalloc((void**)&ff->wedge_dev, wedge.size() * 4) != hipSuccess ||
                     hipMemcpy(ff->wedge_dev, wedge.data(), wedge.size() * 4, hipMemcpyHostToDevice) != hipSuccess))
             rc = fail(RT_E_NOMEM, "conv3d: device allocation failed");
@@ -1437,43 +1450,47 @@ bool fold_factor_active(const rtConvPlan* plan) {
     return !sc.x_f16 && !sc.x_il8 && !sc.f16mma && !plan->has_resid;
 }
 
-int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batch, rtStream s, int hints) {
+size_t fold_factor_bytes(const rtConvPlan* plan, int batch) {
+    const FoldFactor* ff = plan->ff;
+    return (size_t)(ff->a_elems + ff->c_elems + ff->t_elems + ff->e_elems) * 4 * (size_t)batch;
+}
+
+int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batch, void* ws, size_t ws_bytes, rtStream s, int hints) {
     FoldFactor* ff = plan->ff;
     const SubConv& sc = plan->subs[0];
-    const int64_t per = ff->a_elems + ff->c_elems + ff->t_elems + ff->r_elems + ff->e_elems;
-    const size_t need = (size_t)per * 4 * (size_t)batch;
-    float* buf = nullptr;
-    {
+    const size_t need = fold_factor_bytes(plan, batch);
+    float* buf = static_cast<float*>(ws);
+    if (!buf) {               // no caller workspace: the plan's own block (see FoldFactor)
         std::lock_guard<std::mutex> lock(ff->mu);
-        auto& e = ff->scratch[(void*)S(s)];
-        if (e.second < need) {
-            if (e.first) { (void)hipStreamSynchronize(S(s)); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
-            if (hipMalloc(&e.first, need) != hipSuccess) return fail(RT_E_NOMEM, "conv3d (factored cost volume): %zu bytes of scratch", need);
-            e.second = need;
+        if (ff->own_bytes < need) {
+            if (ff->own) { (void)hipDeviceSynchronize(); (void)hipFree(ff->own); ff->own = nullptr; ff->own_bytes = 0; }
+            if (hipMalloc(&ff->own, need) != hipSuccess) return fail(RT_E_NOMEM, "conv3d (factored cost volume): %zu bytes of scratch", need);
+            ff->own_bytes = need;
         }
-        buf = static_cast<float*>(e.first);
+        buf = static_cast<float*>(ff->own);
+    } else {
+        RT_REQUIRE(ws_bytes >= need, "rt_conv_enqueue_ws: workspace of %zu bytes, the plan needs %zu for batch %d", ws_bytes, need, batch);
+        RT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "rt_conv_enqueue_ws: workspace must be 16-byte aligned");
     }
     rt::FoldFactorArgs a;
     a.x = static_cast<const float*>(x);
     a.a = buf; a.c = buf + (int64_t)batch * ff->a_elems;
     a.t = buf + (int64_t)batch * (ff->a_elems + ff->c_elems);
-    a.rext = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems);
-    a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems + ff->r_elems);
+    a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems);
     a.wedge = ff->wedge_dev; a.bias = plan->bias_dev; a.y = y;
     a.F = ff->F; a.K = ff->K; a.D = ff->D; a.H = ff->H; a.W = ff->W; a.act = plan->act;
-    a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.t_bstride = ff->t_elems; a.r_bstride = ff->r_elems; a.e_bstride = ff->e_elems;
+    a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.t_bstride = ff->t_elems; a.e_bstride = ff->e_elems;
     a.y_bstride = plan->y_bstride;
-    RT_REQUIRE((int64_t)batch * ff->F <= 65535 && (int64_t)batch * (ff->K / 4) <= 65535 && ff->H <= 65535, "rt_conv_enqueue: grid limit exceeded");
-    hipLaunchKernelGGL(rt::fold_pad_kernel, dim3((unsigned)rt::cdiv(ff->W + 1, 256), (unsigned)ff->H, (unsigned)(batch * ff->F)), dim3(256), 0, S(s), a);
-    RT_LAUNCH_CHECK("fold_pad_kernel");
-    if (int rc = rt_conv_enqueue_hint(ff->pl, x, const_cast<float*>(a.a), nullptr, batch, s, hints)) return rc;
-    if (int rc = rt_conv_enqueue_hint(ff->pr, a.rext, const_cast<float*>(a.c), nullptr, batch, s, hints)) return rc;
-    RT_REQUIRE((int64_t)batch * ff->K <= 65535, "rt_conv_enqueue: grid limit exceeded");
-    hipLaunchKernelGGL(rt::fold_t_kernel, dim3((unsigned)rt::cdiv(ff->W + 2, 256), (unsigned)ff->H, (unsigned)(batch * ff->K)), dim3(256), 0, S(s), a);
-    RT_LAUNCH_CHECK("fold_t_kernel");
-    hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * ff->K, 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
-    RT_LAUNCH_CHECK("fold_edge_kernel");
     const int G = sc.y_f16 ? 8 : 4;
+    RT_REQUIRE((int64_t)batch * ff->K <= 65535 && ff->H <= 65535, "rt_conv_enqueue: grid limit exceeded");
+    if (int rc = rt_conv_enqueue_hint(ff->pl, x, const_cast<float*>(a.a), nullptr, batch, s, hints)) return rc;
+    if (int rc = rt_conv_enqueue_hint(ff->pr, a.x + (int64_t)ff->F * ff->H * ff->W, const_cast<float*>(a.c), nullptr, batch, s, hints)) return rc;
+    const dim3 tgrid((unsigned)rt::cdiv(ff->W + 2, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));
+    if (G == 8) hipLaunchKernelGGL(rt::fold_t_kernel<8>, tgrid, dim3(256), 0, S(s), a);
+    else hipLaunchKernelGGL(rt::fold_t_kernel<4>, tgrid, dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("fold_t_kernel");
+    hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * (ff->K / 4), 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("fold_edge_kernel");
     const dim3 grid((unsigned)rt::cdiv(ff->W, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));
     if (sc.y_f16) {
         if (sc.y_il8) hipLaunchKernelGGL((rt::fold_combine_kernel<_Float16, true>), grid, dim3(256), 0, S(s), a);
@@ -2310,13 +2327,34 @@ extern "C" int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, c
     return rt_conv_enqueue_hint(plan, x, y, residual, batch, s, 0);
 }
 
+extern "C" size_t rt_conv_plan_workspace_bytes(const rtConvPlan* plan, int batch) {
+    if (!plan || batch <= 0 || !plan->ff) return 0;
+    return fold_factor_bytes(plan, batch);           // (a plan that has the factored form may still launch the gather form: the bytes are then unused)
+}
+
 extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                                     rtStream s, int hints) {
+    return rt_conv_enqueue_ws(plan, x, y, residual, batch, nullptr, 0, s, hints);
+}
+
+extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch, void* workspace,
+                                  size_t workspace_bytes, rtStream s, int hints) {
     RT_REQUIRE(plan && x && y, "rt_conv_enqueue: null pointer");
     RT_REQUIRE(batch > 0, "rt_conv_enqueue: batch must be positive");
     RT_REQUIRE(!plan->has_resid || residual || plan->rb_w1_dev, "rt_conv_enqueue: plan expects a residual tensor");
     RT_REQUIRE(!plan->rb_w1_dev || !residual || residual == x, "rt_conv_enqueue: a residual block's skip connection is its input tensor");
-    if (fold_factor_active(plan)) return enqueue_fold_factor(plan, x, y, batch, s, hints);
+    std::call_once(plan->env_once, [&] {        // execution contexts of one engine share the plan and may launch it from different threads
+        plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
+        plan->opt_rb_tiles = exp_knob("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
+        plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
+        plan->opt_zinner = env_int("RT_Z_INNER", 1);     // 3-D launches: depth slices fastest inside a tile (ConvArgs::z_inner); 0 = z outermost
+        plan->opt_nbinner = env_int("RT_NB_INNER", 1);  // 3-D launches: blocks of 32 output channels fastest (ConvArgs::nb_inner); 0 = grid.y
+        plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
+        plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
+        plan->opt_small_walk = env_int("RT_SMALL_IL_WALK", -1);   // last transposed layer on interleaved fp16 input: 0 = one depth block per workgroup
+        plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
+    });
+    if (fold_factor_active(plan)) return enqueue_fold_factor(plan, x, y, batch, workspace, workspace_bytes, s, hints);
     for (const SubConv& sc : plan->subs) {
         if (sc.small3d) {
             rt::Deconv3dSmallArgs a = sc.s3;
@@ -2338,8 +2376,21 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
                 a.w = static_cast<const float*>(sc.small_il_dev);
                 const int groups = (int)rt::cdiv((a.Wx + 1) / 2, 16);
                 RT_REQUIRE(batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
-                dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rt::cdiv((a.Hx + 1) / 2, 2), (unsigned)batch);
-                hipLaunchKernelGGL(rt::deconv3d_s2_il_kernel, g2, dim3(256), 0, S(s), a);
+                const int rowpairs = (int)rt::cdiv((a.Hx + 1) / 2, 2);
+                if (a.K == 32 && plan->opt_small_walk != 0) {
+                    // the depth walk (deconv3d_s2_ilw_kernel): segments long enough to pay for their prologue (>= 8 depth blocks), as many as
+                    // it takes to give every SIMD about two waves
+                    const int64_t waves = (int64_t)groups * rowpairs * batch;
+                    int nseg = (int)std::min<int64_t>(std::max<int64_t>(1, rt::cdiv((int64_t)8 * device_cus(), waves)), std::max(1, a.Mz / 8));
+                    const int seg_len = (int)rt::cdiv(a.Mz, nseg);
+                    nseg = (int)rt::cdiv(a.Mz, seg_len);
+                    RT_REQUIRE(rowpairs <= 65535, "rt_conv_enqueue: grid limit exceeded");
+                    dim3 gw((unsigned)(rt::cdiv(groups, 4) * nseg), (unsigned)rowpairs, (unsigned)batch);
+                    hipLaunchKernelGGL(rt::deconv3d_s2_ilw_kernel, gw, dim3(256), 0, S(s), a, seg_len, nseg);
+                } else {
+                    dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rowpairs, (unsigned)batch);
+                    hipLaunchKernelGGL(rt::deconv3d_s2_il_kernel, g2, dim3(256), 0, S(s), a);
+                }
             } else if (sc.small3d == 1 && !sc.x_f16 && sc.x_il8) {    // fp32 engines: (K/4, D, H, W, 4) in, split form on the matrix cores
                 RT_REQUIRE(sc.small_il_dev && sc.small_il_f32, "rt_conv_enqueue: interleaved fp32 input without its weight operands (rt_conv_plan_set_layouts)");
                 a.w = static_cast<const float*>(sc.small_il_dev);
@@ -2360,16 +2411,6 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             RT_LAUNCH_CHECK("deconv3d_s2_small_kernel");
             continue;
         }
-        std::call_once(plan->env_once, [&] {        // execution contexts of one engine share the plan and may launch it from different threads
-            plan->opt_xcd = env_int("RT_CONV_XCD", 1); plan->opt_trace = env_int("RT_CONV_TRACE", 0);
-            plan->opt_rb_tiles = exp_knob("RT_RB_TILES", 0); plan->opt_rbs_seg = env_int("RT_RBS_SEG", 0); plan->opt_ksplit = env_int("RT_S3_KSPLIT", -1);
-            plan->opt_s3p_grid = env_int("RT_S3P_GRID", 0);
-            plan->opt_zinner = env_int("RT_Z_INNER", 1);     // 3-D launches: depth slices fastest inside a tile (ConvArgs::z_inner); 0 = z outermost
-            plan->opt_nbinner = env_int("RT_NB_INNER", 1);  // 3-D launches: blocks of 32 output channels fastest (ConvArgs::nb_inner); 0 = grid.y
-            plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
-            plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
-            plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
-        });
         rt::ConvArgs a;
         a.z_inner = 0; a.nb_inner = 0;
         a.x = static_cast<const float*>(x);
@@ -2603,42 +2644,50 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
             if (plan->c3d_dw && plan->opt_dw != 0 && sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.x_il8 && sc.y_il8 && !sc.zs_dev && sc.y_xstride == 1 &&
                 (!plan->has_resid || sc.r_il8) && (plan->act == RT_ACT_NONE || plan->act == RT_ACT_ELU) && !sc.shift_dev) {
                 using Dw = rt::ConvF16DwCfg;
-                a.tiles_x = (int)rt::cdiv(sc.Wo, Dw::TX);
+                const int dw_tiles_x = (int)rt::cdiv(sc.Wo, Dw::TX), dw_nkb = (int)rt::cdiv(sc.Cout, 32);
+                const int64_t npairs = rt::cdiv(dw_tiles_x * (int)rt::cdiv(sc.Ho, Dw::TY), 2);
+                // depth segments: every segment pays two steps' worth of MFMAs for its neighbours' slices and a prologue, every round of
+                // workgroups over the CUs costs a whole segment -- minimise rounds x (segment + overhead); results do not depend on it.
+                // MI355X, NVSmall half2 (profiles/r05_conv3d_layers.txt): batch 8 -- one segment everywhere (conv3D_2 0.206 ms per pair, two
+                // segments 0.215, four 0.228); batch 1 -- conv3D_2 two segments (0.232; one: 0.340), conv3D_4 four (0.137; one: 0.298).
+                int nseg = plan->opt_dw_nseg;
+                double best = 1e30, fill = 1.0;
+                for (int ns = 1; ns <= sc.nz; ns++) {
+                    const int seg = (int)rt::cdiv(sc.nz, ns);
+                    if (ns > 1 && seg < 4) break;
+                    if ((int)rt::cdiv(sc.nz, seg) != ns || (plan->opt_dw_nseg > 0 && ns != std::min(plan->opt_dw_nseg, sc.nz))) continue;
+                    const int64_t wgs = npairs * ns * dw_nkb * batch, rounds = rt::cdiv(wgs, (int64_t)device_cus());
+                    const double steps = seg + (ns > 1 ? 3.0 : 1.7), cost = (double)rounds * steps;
+                    if (cost < best - 1e-9) { best = cost; nseg = ns; fill = (double)wgs / (double)(rounds * device_cus()) * seg / steps; }
+                }
+                // a launch that would leave most of the chip idle or spend its time on segment ends stays with the per-slice kernel (the
+                // 128-channel layers at 12 x 41 x 129: 0.155 against 0.098 ms at batch 1, a tie at batch 8)
+                if (plan->opt_dw < 0 && fill < 0.6) goto dw_declined;
+                nseg = std::max(1, std::min(nseg, sc.nz));
+                a.tiles_x = dw_tiles_x;
                 a.dw_ntiles = a.tiles_x * (int)rt::cdiv(sc.Ho, Dw::TY);
                 a.dw_cpc = plan->c3d_C / 16;
-                a.nb_inner = (int)rt::cdiv(sc.Cout, 32);
-                const int64_t npairs = rt::cdiv(a.dw_ntiles, 2);
-                // depth segments: every segment pays two steps' worth of MFMAs for its neighbours' slices and a prologue, every round of
-                // workgroups over the CUs costs a whole segment -- minimise rounds x (segment + overhead); results do not depend on it
-                int nseg = plan->opt_dw_nseg;
-                if (nseg <= 0) {
-                    double best = 1e30;
-                    for (int ns = 1; ns <= sc.nz; ns++) {
-                        const int seg = (int)rt::cdiv(sc.nz, ns);
-                        if (ns > 1 && seg < 4) break;
-                        if ((int)rt::cdiv(sc.nz, seg) != ns) continue;
-                        const double cost = (double)rt::cdiv(npairs * ns * a.nb_inner * batch, (int64_t)device_cus()) * (seg + (ns > 1 ? 3.0 : 1.7));
-                        if (cost < best - 1e-9) { best = cost; nseg = ns; }
-                    }
-                }
-                nseg = std::max(1, std::min(nseg, sc.nz));
+                a.nb_inner = dw_nkb;
                 a.dw_seg = (int)rt::cdiv(sc.nz, nseg);
                 a.dw_nseg = (int)rt::cdiv(sc.nz, a.dw_seg);
                 const int64_t gx = npairs * a.dw_nseg * a.nb_inner;
                 RT_REQUIRE(gx < (1ll << 31) && batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
                 dim3 gd((unsigned)gx, 1u, (unsigned)batch);
                 if (plan->opt_trace) fprintf(stderr, "[rt] conv_f16dw grid %u x %u segments %d x %d slices, %d chunks per slice\n", gd.x, gd.z, a.dw_nseg, a.dw_seg, a.dw_cpc);
-                const bool resident = a.dw_cpc <= 2;
+                const bool resident = a.dw_cpc <= 2, elu = plan->act == RT_ACT_ELU;
+#define RT_DW_LAUNCH(res, hr, el) hipLaunchKernelGGL((rt::conv_f16dw_kernel<res, hr, el>), gd, dim3(512), 0, S(s), a)
                 if (resident) {
-                    if (plan->has_resid) hipLaunchKernelGGL((rt::conv_f16dw_kernel<true, true>), gd, dim3(512), 0, S(s), a);
-                    else hipLaunchKernelGGL((rt::conv_f16dw_kernel<true, false>), gd, dim3(512), 0, S(s), a);
+                    if (plan->has_resid) { if (elu) RT_DW_LAUNCH(true, true, true); else RT_DW_LAUNCH(true, true, false); }
+                    else { if (elu) RT_DW_LAUNCH(true, false, true); else RT_DW_LAUNCH(true, false, false); }
                 } else {
-                    if (plan->has_resid) hipLaunchKernelGGL((rt::conv_f16dw_kernel<false, true>), gd, dim3(512), 0, S(s), a);
-                    else hipLaunchKernelGGL((rt::conv_f16dw_kernel<false, false>), gd, dim3(512), 0, S(s), a);
+                    if (plan->has_resid) { if (elu) RT_DW_LAUNCH(false, true, true); else RT_DW_LAUNCH(false, true, false); }
+                    else { if (elu) RT_DW_LAUNCH(false, false, true); else RT_DW_LAUNCH(false, false, false); }
                 }
+#undef RT_DW_LAUNCH
                 RT_LAUNCH_CHECK("conv_f16dw_kernel");
                 continue;
             }
+            dw_declined:
             // Conv3D between interleaved fp16 tensors: four output rows per wave, operands reused from registers (conv_f16r4.hip.h) -- the
             // 4 x 32-tile kernel below reads 2 KB of LDS per MFMA and is LDS-bound at 0.3 of the matrix peak on these layers
             if (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.x_il8 && sc.y_il8 && !sc.zs_dev && sc.TY == 4 && sc.y_xstride == 1 &&

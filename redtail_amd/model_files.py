@@ -34,7 +34,7 @@ def stage_reference_weights(reference=None):
     todo = [(os.path.join(src_root, rel), os.path.join(WEIGHT_DIR, rel)) for rel in sorted(set(FILES.values()))]
     # the sample application's stereo pair (sample_app/data/img_{left,right}.png)
     todo += [(os.path.join(reference, "stereoDNN", "sample_app", "data", f), os.path.join(WEIGHT_DIR, "sample", f))
-             for f in ("img_left.png", "img_right.png")]
+             for f in ("img_left.png", "img_right.png", "img_left.bin", "img_right.bin")]
     # the golden tensors of the reference's plugin tests (stereoDNN/tests/data/*.bin), for oracle/_ref/nvstereo_tests
     data = os.path.join(reference, "stereoDNN", "tests", "data")
     if os.path.isdir(data):
@@ -55,6 +55,12 @@ def sample_image(side):
     if not os.path.exists(path):
         raise FileNotFoundError("%s is missing: run `python __graft_entry__.py` where /root/reference exists" % path)
     return path
+
+
+def sample_bin(side):
+    """the reference's own pre-processed network input for that image (sample_app/data/img_<side>.bin: 3 x 321 x 1025 float32), or None"""
+    path = os.path.join(WEIGHT_DIR, "sample", "img_%s.bin" % side)
+    return path if os.path.exists(path) else None
 
 
 def tests_data_dir():

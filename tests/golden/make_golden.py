@@ -41,6 +41,25 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "redtail_fixtures.npz")
     np.savez_compressed(dst, **out)
     print("wrote %s: %d tensors, %d bytes" % (dst, len(out), os.path.getsize(dst)))
+    sample_image(ref)
+
+
+BAND = (160, 288)       # destination rows kept from img_left.bin (their source rows straddle y = 256, where float32 coordinates coarsen)
+
+
+def sample_image(ref):
+    """The sample application's network input as the reference ships it: sample_app/data/img_left.png (1242 x 375, 8-bit) and
+    img_left.bin (3 x 321 x 1025 float32 CHW RGB in [0, 1]: what readImgFile, sample_app/main.cpp:83-98, is to produce from the PNG) --
+    the only known-answer vector for the pre-processing.  Kept: the decoded PNG and rows BAND of the .bin (the whole files are staged next
+    to the weights by redtail_amd/model_files.py and compared in full where they are present)."""
+    from PIL import Image
+    data = os.path.join(ref, "stereoDNN", "sample_app", "data")
+    png = np.asarray(Image.open(os.path.join(data, "img_left.png")))
+    assert png.shape == (375, 1242, 3) and png.dtype == np.uint8
+    chw = np.fromfile(os.path.join(data, "img_left.bin"), dtype="<f4").reshape(3, 321, 1025)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "redtail_sample_image.npz")
+    np.savez_compressed(dst, img_left_png_rgb=png, img_left_bin_rows=chw[:, BAND[0]:BAND[1]].copy(), band=np.int32(BAND))
+    print("wrote %s: %d bytes" % (dst, os.path.getsize(dst)))
 
 
 if __name__ == "__main__":

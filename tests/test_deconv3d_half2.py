@@ -165,11 +165,14 @@ SMALL_CASES = [
     (32, 1, (2, 5, 40), 3, 3, 1, capi.RT_ACT_ELU),         # depth pad 1; 40 blocks across: three 16-block groups, the last one ragged
     (64, 2, (2, 3, 9), 5, 4, 0, capi.RT_ACT_NONE),         # two output channels (rows 8..15 of the MFMA), two blocks of 32 input channels
     (32, 2, (1, 1, 1), 1, 1, 1, capi.RT_ACT_SIGMOID),      # a single voxel
+    (32, 1, (17, 3, 21), 35, 34, 0, capi.RT_ACT_NONE),     # 18 depth blocks: the depth walk (deconv3d_s2_ilw_kernel) takes them in two segments
 ]
 
 
 @pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,act", SMALL_CASES)
-def test_last_deconv3d_on_interleaved_input(backend, K, C, ydims, dfull, dkeep, pad_d, act):
+def test_last_deconv3d_on_interleaved_input(backend, monkeypatch, K, C, ydims, dfull, dkeep, pad_d, act):
+    """(K = 32: deconv3d_s2_ilw_kernel, the wave walks down the depth blocks with the shared slice in registers -- it must give the bits of
+    deconv3d_s2_il_kernel, one depth block per workgroup, which RT_SMALL_IL_WALK=0 selects)"""
     n = 2
     dy, hy, wy = ydims
     hx, wx = 2 * hy - 1, 2 * wy - 1
@@ -198,6 +201,15 @@ def test_last_deconv3d_on_interleaved_input(backend, K, C, ydims, dfull, dkeep, 
     out = empty(backend, ref.shape, False)
     plan.enqueue(dev16(backend, y), out, None, n)
     assert np.array_equal(host(backend, out), planar)
+    plan.destroy()
+    monkeypatch.setenv("RT_SMALL_IL_WALK", "0")
+    plan = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=act, dtype=capi.RT_F16,
+                                    transposed_in_dims=ydims, out_depth=dkeep)
+    plan.set_io_types(capi.RT_F16, capi.RT_F32)
+    plan.set_layouts(1, 0, 0)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), out, None, n)
+    assert np.array_equal(host(backend, out), got)
     plan.destroy()
 
 

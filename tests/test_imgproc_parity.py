@@ -1,6 +1,8 @@
 """GPU front-end / back-end of the sample application against the oracle restatement of
-readImgFile / the 16-bit PNG encoding (sample_app/main.cpp:83-98, 324-330).  The INTER_AREA filter is unpinned
-(OpenCV is not available here); the integer-factor case is additionally checked against a plain box average."""
+readImgFile / the 16-bit PNG encoding (sample_app/main.cpp:83-98, 324-330).  The area filter is pinned by the reference's own sample
+input (sample_app/data/img_left.bin: test_preprocess_reproduces_the_reference_sample_input here, and in tests/test_oracle_golden.py for
+the oracle); the integer-factor case is additionally checked against a plain box average."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -32,6 +34,16 @@ def test_preprocess(backend, src, dst):
     if src == (40, 66):      # integer factor 2: INTER_AREA is the 2x2 box average
         box = img.astype(np.float64).reshape(2, 20, 2, 33, 2, 3).mean((2, 4))[..., ::-1].transpose(0, 3, 1, 2) / 255
         assert np.abs(out - box).max() <= 2e-6
+
+
+def test_preprocess_reproduces_the_reference_sample_input(backend):
+    """rt_preprocess_bgr8 on the reference's sample_app/data/img_left.png against the network input the reference ships for it
+    (img_left.bin, rows 160..287 in the fixture): <= 1e-3 max, <= 2e-5 mean -- the bounds tests/test_oracle_golden.py holds the oracle to"""
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "redtail_sample_image.npz"))
+    png_rgb, ref_rows, (r0, r1) = f["img_left_png_rgb"], f["img_left_bin_rows"], tuple(int(v) for v in f["band"])
+    out = run_pre(backend, np.ascontiguousarray(png_rgb[None, :, :, ::-1]), 321, 1025)[0, :, r0:r1]
+    err = np.abs(out - ref_rows)
+    assert err.max() <= 1e-3 and err.mean() <= 2e-5, (err.max(), err.mean())
 
 
 def test_preprocess_rejects_upscaling(backend):

@@ -573,6 +573,43 @@ def test_nvsmall_full_size_real_fp16_weights(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_nvsmall_half2_batch8_full_size_every_pair():
+    """BASELINE config C5 AS IT IS TIMED (bench.py --model nvsmall --half2 --batch 8): NVSmall 1025x321, the reference's fp16 weight file,
+    half2 mode, one GPU's shard of eight DIFFERENT pairs.  Every pair of the batch must equal, bit for bit, what a batch-1 engine computes
+    for that pair alone (so the batch -- other launch shapes, other depth segmentation of the depth-walking Conv3D -- adds nothing), and the
+    first pair is bounded against both oracles exactly as test_nvsmall_full_size_real_fp16_weights bounds the batch-1 engine."""
+    lib = netlib("gpu")
+    weights = real_weights("nvsmall", fp16=True)
+    b, h, w = 8, 321, 1025
+    l, r = pairs(b, h, w)
+    path = model_files.weight_file("nvsmall", True)
+    net = lib.create("nvsmall", w, h, max_batch=b, weights_path=path, fp16_weights=True)
+    out = torch.full((b, 1, h, w), float("nan"), device="cuda")
+    net.execute(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), out, b)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    net.destroy()
+    assert not torch.isnan(out).any()
+    net1 = lib.create("nvsmall", w, h, max_batch=1, weights_path=path, fp16_weights=True)
+    for i in range(b):
+        o1 = torch.full((1, 1, h, w), float("nan"), device="cuda")
+        net1.execute(torch.from_numpy(l[i:i + 1]).cuda(), torch.from_numpy(r[i:i + 1]).cuda(), o1, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(o1.cpu(), out[i:i + 1]), (i, (o1.cpu() - out[i:i + 1]).abs().max().item())
+    net1.destroy()
+    assert not torch.equal(out[0], out[1])                    # the pairs do differ
+    with torch.no_grad():
+        ref = O.stereo3d(torch.from_numpy(l[:1]), torch.from_numpy(r[:1]), weights, O.NVSMALL_3D, 48)
+        ref16 = O.stereo3d(torch.from_numpy(l[:1]), torch.from_numpy(r[:1]), weights, O.NVSMALL_3D, 48, plugin_fp16=True)
+    err, d_ref, d_hip = (out[:1] - ref).abs(), (ref16 - ref).abs(), (out[:1] - ref16).abs()
+    print("NVSmall half2 batch 8, pair 0: max |disp - fp32-tensor oracle| = %.3g px (mean %.3g); reference-style fp16-plugin oracle: %.3g px from it, ours %.3g px from that"
+          % (err.max().item(), err.mean().item(), d_ref.max().item(), d_hip.max().item()))
+    assert d_hip.max().item() <= 2 * d_ref.max().item() and d_hip.mean().item() <= 2 * d_ref.mean().item()
+    assert err.max().item() <= 2 * d_ref.max().item() and err.mean().item() <= 2 * d_ref.mean().item()
+    assert err.max().item() <= 0.25 and err.mean().item() <= 4e-4, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,cfg,w,h,disp,batch,tol", [("nvsmall", "NVSMALL_3D", 1025, 321, 48, 4, 1e-3), ("resnet18", "RESNET18_3D", 1025, 321, 68, 4, 5e-3),
                                                           ("nvsmall", "NVSMALL_3D", 257, 129, 16, 8, 1e-3), ("resnet18", "RESNET18_3D", 257, 129, 12, 8, 1e-3)])
 def test_3d_models_batched(model, cfg, w, h, disp, batch, tol):

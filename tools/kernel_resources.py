@@ -5,7 +5,10 @@ import subprocess
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "redtail_amd/csrc/rt_capi.hip"
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redtail_amd import build  # noqa: E402  (the product's device flags: what is measured is what ships)
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + build.DEVICE_FLAGS + ["-c", src, "-o",
                       "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
