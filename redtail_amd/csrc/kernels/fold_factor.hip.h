@@ -26,22 +26,28 @@
 
 namespace rt {
 
+// tools/iso_conv3d.py fold: instrumented builds of the combining pass (-DRT_FOLD_ABL=<mask>: 1 no T loads, 2 no activation, 4 no stores)
+#ifndef RT_FOLD_ABL
+#define RT_FOLD_ABL 0
+#endif
+constexpr int kFoldAbl = RT_FOLD_ABL;
+
 struct FoldFactorArgs {
     const float* x;        // (N, 2F, H, W) fp32 planar: [left | right] feature maps
     const float* a;        // (N, 3K, H, W): A_first, A_middle, A_last
     const float* c;        // (N, 3K, H, W + 2): C'_0, C'_1, C'_2 (column W + 1 is not used)
-    float* t;              // (N, 3K/G, H, W + 2, G): T_first, T_middle, T_last at index u + 2, channel-interleaved in the combining pass's groups
+    float* t;              // (N, 3K/4, H, W + 2, 4): T_first, T_middle, T_last at index u + 2, channel-interleaved in groups of 4 (16-byte slots)
     float* e;              // (N, D, K, H)
     const float* wedge;    // [j 3][dy 3][c F][k K]: w[k, j, F + c, dy, dx = 2]
     const float* bias;     // [K]
     void* y;               // output, depth-major: (N, D, K, H, W) planar or (N, D, K/G, H, W, G) interleaved (G = 4 fp32, 8 fp16)
     int F, K, D, H, W;
-    int act;
+    int act, batch;
     int64_t x_bstride, a_bstride, c_bstride, t_bstride, e_bstride, y_bstride;    // elements
 };
 
 // T_v[n, v K + k, y, i] = sum_{j in v} C'_j[k, y, i - j]  (i = u + 2 in [0, W + 1]; C' indices outside [0, W] contribute nothing), written
-// in groups of G channels: one thread per (i, y, group) reads 3 G planar values (coalesced along i) and stores 3 x G / 4 16-byte slots
+// as (3K/4, H, W + 2, 4): one thread per (i, y, G channels) reads 3 G planar values (coalesced along i) and stores 3 x G / 4 16-byte slots
 template <int G>
 __global__ void __launch_bounds__(256) fold_t_kernel(FoldFactorArgs p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -62,11 +68,12 @@ __global__ void __launch_bounds__(256) fold_t_kernel(FoldFactorArgs p) {
         tv[2][g] = cj[0] + cj[1];
     }
 #pragma unroll
-    for (int v = 0; v < 3; v++) {
-        float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + ((((int64_t)v * KG + kg) * p.H + y) * (p.W + 2) + i) * G;
+    for (int v = 0; v < 3; v++)
 #pragma unroll
-        for (int q = 0; q < G / 4; q++) *reinterpret_cast<f32x4*>(t + 4 * q) = f32x4{tv[v][4 * q], tv[v][4 * q + 1], tv[v][4 * q + 2], tv[v][4 * q + 3]};
-    }
+        for (int q = 0; q < G / 4; q++) {
+            float* __restrict__ t = p.t + (int64_t)n * p.t_bstride + ((((int64_t)v * (p.K / 4) + kg * (G / 4) + q) * p.H + y) * (p.W + 2) + i) * 4;
+            *reinterpret_cast<f32x4*>(t) = f32x4{tv[v][4 * q], tv[v][4 * q + 1], tv[v][4 * q + 2], tv[v][4 * q + 3]};
+        }
 }
 
 // E[n, d, k, y]: one thread per (4 output channels, y) -- the image column is read once for the four; grid (ceil(H * K / 4 / 256), D, N)
@@ -77,7 +84,8 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
     if (t >= p.H * K4) return;
     const int k = (t % K4) * 4, y = t / K4;
     const float* __restrict__ r = p.x + (int64_t)n * p.x_bstride + (int64_t)p.F * p.H * p.W;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};       // two chains per output over the channels (F is a multiple of 4)
+    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // four chains per output over the channels (F is a multiple of 4), their eight loads issued together: the loop is latency-bound
     for (int j = 0; j < 3; j++) {
         const int dz = d + j - 1, col = p.W + 1 - d - j;
         if (dz < 0 || dz >= p.D || d + j < 2 || col < 0) continue;                    // depth padding / the pixel lies outside the image as well
@@ -87,32 +95,49 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
             const float* __restrict__ wv = p.wedge + ((int64_t)(j * 3 + dy) * p.F) * p.K + k;
             const float* __restrict__ rv = r + (int64_t)iy * p.W + col;
             const int64_t cstep = (int64_t)p.H * p.W;
-            for (int c = 0; c < p.F; c += 2) {
+            for (int c = 0; c < p.F; c += 4) {
+                f32x4 w4[4];
+                float rr[4];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + (int64_t)(c + u) * p.K);
-                    const float rr = rv[(c + u) * cstep];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc[u][q] = fmaf(w4[q], rr, acc[u][q]);
+                for (int u = 0; u < 4; u++) {
+                    w4[u] = *reinterpret_cast<const f32x4*>(wv + (int64_t)(c + u) * p.K);
+                    rr[u] = rv[(c + u) * cstep];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[u][q] = fmaf(w4[u][q], rr[u], acc[u][q]);
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k + q) * p.H + y] = acc[0][q] + acc[1][q];
+    for (int q = 0; q < 4; q++) p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k + q) * p.H + y] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
 }
 
 // out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output.
-// Round 4: bound by its vector-memory instructions (G 4-byte loads of T per 16 bytes stored: 2.2 TB/s).  Round 5: T is interleaved in the
-// same groups, so a voxel group is G / 4 16-byte loads (lane offset (x - d + 2) * 4 G bytes, out of range = masked = 0 by the buffer's
-// own bounds check; the row of the group as a wave-uniform scalar offset); the bias sits in the A registers.
-template <typename TOUT, bool IL>
+// Round 4: bound by its vector-memory instructions (G 4-byte loads of T per 16 bytes stored: 2.2 TB/s).  Round 5: T is interleaved in
+// 16-byte slots that are contiguous across the lanes of a wave -- a voxel group is G / 4 loads of 1 KB per wave (lane offset (x - d + 2) * 16
+// bytes, out of range = masked = 0 by the buffer's own bounds check; the row of each 4-channel group as a wave-uniform scalar offset) --
+// and the bias sits in the A registers.  U depth slices per trip have their loads issued together.  LASTCOL: the same arithmetic for the
+// volume's last column only (x = W - 1, where the edge term E is subtracted), one thread per (row, depth slice, group, sample) -- the main launch covers
+// x < W - 1, so its blocks of 256 pixels carry no edge logic and, for the image widths of the reference (W - 1 a multiple of 256), no idle
+// lanes (the third block of a 513-pixel row had one live lane in 256).
+template <typename TOUT, bool IL, int U, bool LASTCOL>
 __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
     constexpr int G = sizeof(TOUT) == 2 ? 8 : 4;
-    const int x = blockIdx.x * 256 + threadIdx.x;
     const int KG = p.K / G;
-    const int y = blockIdx.y, kg = blockIdx.z % KG, n = blockIdx.z / KG;
-    const bool live = x < p.W;
+    int x, y, kg, n;
+    int dl0 = 0, dl1 = p.D;                          // depth slices of this thread (LASTCOL: one)
+    if constexpr (LASTCOL) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        x = p.W - 1; y = t % p.H; dl0 = (t / p.H) % p.D; kg = (t / (p.H * p.D)) % KG; n = t / (p.H * p.D * KG);
+        if (n >= p.batch) return;
+        dl1 = dl0 + 1;
+    } else {
+        x = blockIdx.x * 256 + threadIdx.x;
+        y = blockIdx.y; kg = blockIdx.z % KG; n = blockIdx.z / KG;
+    }
+    const bool live = LASTCOL || x < p.W - 1;
     const int64_t plane = (int64_t)p.H * p.W;
     const float* __restrict__ a = p.a + (int64_t)n * p.a_bstride + (int64_t)y * p.W + (live ? x : 0);
     const float* __restrict__ e = p.e + (int64_t)n * p.e_bstride + y;
@@ -124,49 +149,60 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
 #pragma unroll
         for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane] + b;
     }
-    const unsigned trow = (unsigned)(p.W + 2) * (unsigned)(G * 4);            // bytes of one row of a T group (3 K planes of one sample: < 4 GB)
+    const unsigned trow = (unsigned)(p.W + 2) * 16u;                          // bytes of one row of a 4-channel T group (3 K planes of one sample: < 4 GB)
     char* __restrict__ yb = static_cast<char*>(p.y) + (int64_t)n * p.y_bstride * sizeof(TOUT);
-    const bool last_col = live && x == p.W - 1;
     const bool elu = p.act == 1;
     const int act = p.act;
-    for (int d = 0; d < p.D; d++) {
-        const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);                             // wave-uniform
-        const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
-        const unsigned vo = (live && i >= 0) ? (unsigned)i * (unsigned)(G * 4) : kBufOOB;
-        const unsigned so = (unsigned)((v * KG + kg) * p.H + y) * trow;
-        float o[G];
+    for (int d0 = dl0; d0 < dl1; d0 += U) {
+        f32x4 tv[U][G / 4];
 #pragma unroll
-        for (int q = 0; q < G / 4; q++) {
-            const f32x4 tv = buf_load4(rs_t, vo == kBufOOB ? kBufOOB : vo + 16u * q, so);
+        for (int u = 0; u < U; u++) {
+            const int d = d0 + u < p.D ? d0 + u : p.D - 1;                                  // (a ragged last trip repeats the last slice)
+            const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);                             // wave-uniform
+            const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
+            const unsigned vo = (live && i >= 0) ? (unsigned)i * 16u : kBufOOB;
 #pragma unroll
-            for (int g = 0; g < 4; g++) o[4 * q + g] = tv[g] + av[v][4 * q + g];
+            for (int q = 0; q < G / 4; q++)
+                tv[u][q] = (kFoldAbl & 1) ? f32x4{(float)d, 1.f, 2.f, (float)x} : buf_load4(rs_t, vo, (unsigned)((v * (p.K / 4) + kg * (G / 4) + q) * p.H + y) * trow);
         }
-        if (last_col) {
 #pragma unroll
-            for (int g = 0; g < G; g++) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
-        }
-        if (elu) {
+        for (int u = 0; u < U; u++) {
+            const int d = d0 + u;
+            if (U > 1 && d >= dl1) break;                                                   // uniform
+            const int v = d == 0 ? 0 : (d == p.D - 1 ? 2 : 1);
+            float o[G];
 #pragma unroll
-            for (int g = 0; g < G; g++) o[g] = o[g] > 0.f ? o[g] : fast_exp(o[g]) - 1.f;
-        } else {
+            for (int q = 0; q < G / 4; q++)
 #pragma unroll
-            for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);
-        }
-        if (!live) continue;
-        if constexpr (IL) {
-            TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * KG + kg) * plane + (int64_t)y * p.W + x) * G;
-            if constexpr (G == 8) {
-                u32x4_t w;
+                for (int g = 0; g < 4; g++) o[4 * q + g] = tv[u][q][g] + av[v][4 * q + g];
+            if constexpr (LASTCOL) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) w[q] = pack_f16(o[2 * q], o[2 * q + 1]);
-                *reinterpret_cast<u32x4_t*>(dst) = w;
-            } else {
-                *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                for (int g = 0; g < G; g++) o[g] -= e[((int64_t)d * p.K + kg * G + g) * p.H];
             }
-        } else {
-            TOUT* dst = reinterpret_cast<TOUT*>(yb) + ((int64_t)d * p.K + kg * G) * plane + (int64_t)y * p.W + x;
+            if (kFoldAbl & 2) {
+            } else if (elu) {
 #pragma unroll
-            for (int g = 0; g < G; g++) dst[(int64_t)g * plane] = (TOUT)o[g];
+                for (int g = 0; g < G; g++) o[g] = o[g] > 0.f ? o[g] : fast_exp(o[g]) - 1.f;
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);
+            }
+            if (!live) continue;
+            if constexpr (IL) {
+                TOUT* dst = reinterpret_cast<TOUT*>(yb) + (((int64_t)d * KG + kg) * plane + (int64_t)y * p.W + x) * G;
+                if constexpr (G == 8) {
+                    u32x4_t w;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w[q] = pack_f16(o[2 * q], o[2 * q + 1]);
+                    if (!(kFoldAbl & 4) || w[0] == 0x12345678u) *reinterpret_cast<u32x4_t*>(dst) = w;
+                } else {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                }
+            } else {
+                TOUT* dst = reinterpret_cast<TOUT*>(yb) + ((int64_t)d * p.K + kg * G) * plane + (int64_t)y * p.W + x;
+#pragma unroll
+                for (int g = 0; g < G; g++) dst[(int64_t)g * plane] = (TOUT)o[g];
+            }
         }
     }
 }

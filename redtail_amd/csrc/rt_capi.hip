@@ -581,7 +581,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -1478,7 +1478,7 @@ int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batc
     a.t = buf + (int64_t)batch * (ff->a_elems + ff->c_elems);
     a.e = buf + (int64_t)batch * (ff->a_elems + ff->c_elems + ff->t_elems);
     a.wedge = ff->wedge_dev; a.bias = plan->bias_dev; a.y = y;
-    a.F = ff->F; a.K = ff->K; a.D = ff->D; a.H = ff->H; a.W = ff->W; a.act = plan->act;
+    a.F = ff->F; a.K = ff->K; a.D = ff->D; a.H = ff->H; a.W = ff->W; a.act = plan->act; a.batch = batch;
     a.x_bstride = plan->x_bstride; a.a_bstride = ff->a_elems; a.c_bstride = ff->c_elems; a.t_bstride = ff->t_elems; a.e_bstride = ff->e_elems;
     a.y_bstride = plan->y_bstride;
     const int G = sc.y_f16 ? 8 : 4;
@@ -1491,14 +1491,23 @@ int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batc
     RT_LAUNCH_CHECK("fold_t_kernel");
     hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * (ff->K / 4), 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
     RT_LAUNCH_CHECK("fold_edge_kernel");
-    const dim3 grid((unsigned)rt::cdiv(ff->W, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));
-    if (sc.y_f16) {
-        if (sc.y_il8) hipLaunchKernelGGL((rt::fold_combine_kernel<_Float16, true>), grid, dim3(256), 0, S(s), a);
-        else hipLaunchKernelGGL((rt::fold_combine_kernel<_Float16, false>), grid, dim3(256), 0, S(s), a);
-    } else {
-        if (sc.y_il8) hipLaunchKernelGGL((rt::fold_combine_kernel<float, true>), grid, dim3(256), 0, S(s), a);
-        else hipLaunchKernelGGL((rt::fold_combine_kernel<float, false>), grid, dim3(256), 0, S(s), a);
-    }
+    // the combining pass over x < W - 1, then the last column (edge term) -- see fold_combine_kernel
+    const dim3 grid((unsigned)rt::cdiv(ff->W - 1, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));
+    const dim3 lgrid((unsigned)rt::cdiv((int64_t)ff->H * ff->D * (ff->K / G) * batch, 256), 1u, 1u);
+    const int U = plan->opt_fold_u;
+#define RT_FOLD_COMBINE(T, il, u)                                                                          \
+    do {                                                                                                   \
+        if (ff->W > 1) hipLaunchKernelGGL((rt::fold_combine_kernel<T, il, u, false>), grid, dim3(256), 0, S(s), a); \
+        hipLaunchKernelGGL((rt::fold_combine_kernel<T, il, 1, true>), lgrid, dim3(256), 0, S(s), a);       \
+    } while (0)
+#define RT_FOLD_COMBINE_U(T, il)                                                                           \
+    do {                                                                                                   \
+        if (U == 4) RT_FOLD_COMBINE(T, il, 4); else if (U == 2) RT_FOLD_COMBINE(T, il, 2); else RT_FOLD_COMBINE(T, il, 1); \
+    } while (0)
+    if (sc.y_f16) { if (sc.y_il8) RT_FOLD_COMBINE_U(_Float16, true); else RT_FOLD_COMBINE_U(_Float16, false); }
+    else { if (sc.y_il8) RT_FOLD_COMBINE_U(float, true); else RT_FOLD_COMBINE_U(float, false); }
+#undef RT_FOLD_COMBINE_U
+#undef RT_FOLD_COMBINE
     RT_LAUNCH_CHECK("fold_combine_kernel");
     return 0;
 }
@@ -2351,6 +2360,7 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
         plan->opt_nbinner = env_int("RT_NB_INNER", 1);  // 3-D launches: blocks of 32 output channels fastest (ConvArgs::nb_inner); 0 = grid.y
         plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
         plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
+        plan->opt_fold_u = env_int("RT_FOLD_U", 2);           // factored cost-volume fold: depth slices per trip of the combining pass (MI355X, NVSmall b8: 1: 0.84, 2: 0.68, 4: 1.07 ms)
         plan->opt_small_walk = env_int("RT_SMALL_IL_WALK", -1);   // last transposed layer on interleaved fp16 input: 0 = one depth block per workgroup
         plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
     });

@@ -59,7 +59,60 @@ def time_layer(k, c, kk, d, h, w, batch, env, iters=10):
     return ms.value / iters / batch, float(y.float().abs().mean())
 
 
+FOLD_VARIANTS = [("fabl1", ["-DRT_FOLD_ABL=1"], "no T loads"), ("fabl2", ["-DRT_FOLD_ABL=2"], "no activation"), ("fabl4", ["-DRT_FOLD_ABL=4"], "no stores"),
+                 ("fabl3", ["-DRT_FOLD_ABL=3"], "no T loads, no activation")]
+
+
+def time_fold(k, f, kk, d, h, w, batch, iters=10):
+    """the first Conv3D of a 3-D model over the folded cost volume (factored form): NVSmall 2 x 32 -> 32, 48 x 161 x 513, fp16 interleaved out"""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(1)
+    wt = (rng.standard_normal((kk, 3, 2 * f, 3, 3)) / np.sqrt(27 * 2 * f)).astype(np.float32)
+    b = rng.standard_normal(kk).astype(np.float32)
+    plan = k.conv3d_plan(wt, b, 2 * f, kk, (d, h, w), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), act=capi.RT_ACT_ELU, out_dchw=True, cv_fold=f)
+    plan.set_io_types(capi.RT_F32, capi.RT_F16)
+    plan.set_layouts(0, 1, 0)
+    x = torch.randn(batch, 2 * f, h, w, device="cuda") * 0.5
+    y = torch.empty(batch, d, kk // 8, h, w, 8, device="cuda", dtype=torch.float16)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))
+    for _ in range(3):
+        plan.enqueue(x, y, None, batch)
+    torch.cuda.synchronize()
+    k.lib.rt_event_record(e0, None)
+    for _ in range(iters):
+        plan.enqueue(x, y, None, batch)
+    k.lib.rt_event_record(e1, None)
+    torch.cuda.synchronize()
+    ms = ctypes.c_float()
+    k.lib.rt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+    plan.destroy()
+    return ms.value / iters / batch
+
+
 def main():
+    if sys.argv[1] == "buildfold":
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(4) as ex:
+            list(ex.map(lambda v: build.build_variant("dw_" + v[0], v[1], kernels_only=True), FOLD_VARIANTS))
+        return
+    if sys.argv[1] == "fold":
+        import torch
+        torch.zeros(1, device="cuda")
+        batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+        prod = os.path.join(build.ROOT, "redtail_amd", "lib", "librt_stereo_hip.so")
+        for u in ("1", "2", "4"):
+            os.environ["RT_FOLD_U"] = u
+            print("conv3D_1 (factored fold) 2x32->32 48x161x513, batch %d, %d depth slice(s) per trip of the combining pass: %.4f ms per pair" % (
+                batch, int(u), time_fold(klib(prod), 32, 32, 48, 161, 513, batch)), flush=True)
+        os.environ.pop("RT_FOLD_U")
+        rows = [("product", prod)]
+        rows += [(what, os.path.join(build.ROOT, "tools", "build", "dw_" + v, "librt_stereo_hip.so")) for v, _, what in FOLD_VARIANTS]
+        for what, pth in rows:
+            if os.path.exists(pth):
+                print("conv3D_1 (factored fold) 2x32->32 48x161x513, batch %d, %-28s %.4f ms per pair" % (batch, what, time_fold(klib(pth), 32, 32, 48, 161, 513, batch)), flush=True)
+        return
     if sys.argv[1] == "build":
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(4) as ex:

@@ -114,23 +114,39 @@ def main():
                    sources_sha16=kernel_sources_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     json.dump(traffic, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
 
-    # ---- one steady-state step as a timeline (last full step of the trace) -----------------------------
+    # ---- one steady-state NETWORK step as a timeline -----------------------------------------------------
+    # A step is what one context issues on its stream between two launches of the first layer (conv_s3_first_kernel: left_conv1 |
+    # right_conv1).  Round 4 printed "the last N launches" of the trace, which were bench.py's isolated-layer loop, not a step (VERDICT r04
+    # weak #8a): the step is now cut out of the busiest queue of the timed region by its first kernel.
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     try:
         per_step = json.loads([l for l in open(os.path.join(run, "bench_plain.json")) if l.startswith("{")][-1])["config"]["launches_per_step"]
     except Exception:
-        per_step = 48
-    last = rows[-per_step:]
-    base = int(last[0]["Start_Timestamp"])
+        per_step = 23
+    byq = collections.defaultdict(list)
+    for r in rows:
+        if short(r["Kernel_Name"]).startswith(("conv_", "corr_", "deconv", "softargmax", "fold_")):
+            byq[r.get("Queue_Id", "?")].append(r)
+    step, q_used = None, None
+    for q, qrows in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+        firsts = [i for i, r in enumerate(qrows) if short(r["Kernel_Name"]).startswith("conv_s3_first_kernel")]
+        # (one first-layer launch per step when the towers' first layers are merged, two when they are not)
+        spans = [(firsts[i], firsts[i + k]) for k in (1, 2) for i in range(len(firsts) - k) if firsts[i + k] - firsts[i] == per_step]
+        if spans:
+            a0, b0 = spans[len(spans) // 2]               # a step from the middle of the run
+            step, q_used = qrows[a0:b0], q
+            break
     with open(os.path.join(out, tag + "_timeline.txt"), "w") as f:
-        f.write("# last step of the traced run: start_us  dur_us  stream/queue  kernel\n")
-        for r in last:
-            f.write("%9.1f %8.1f  q%-3s %s\n" % ((int(r["Start_Timestamp"]) - base) / 1e3,
-                                               (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                               r.get("Queue_Id", "?"), short(r["Kernel_Name"])))
-        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
-        span = int(last[-1]["End_Timestamp"]) - base
-        f.write("# span %.1f us, sum of kernel durations %.1f us (two streams overlap)\n" % (span / 1e3, busy / 1e3))
+        if step is None:
+            f.write("# no complete network step (%d launches from one first-layer launch to the next) found on any queue of the trace\n" % per_step)
+        else:
+            base = int(step[0]["Start_Timestamp"])
+            f.write("# one network step (%d launches) of one context, queue %s, from the middle of the traced run: start_us  dur_us  kernel\n" % (per_step, q_used))
+            for r in step:
+                f.write("%9.1f %8.1f  %s\n" % ((int(r["Start_Timestamp"]) - base) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, short(r["Kernel_Name"])))
+            busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
+            span = int(step[-1]["End_Timestamp"]) - base
+            f.write("# span %.1f us, sum of kernel durations %.1f us (other contexts' launches run in between: six contexts share the GPU)\n" % (span / 1e3, busy / 1e3))
     print(json.dumps(traffic, indent=1))
     print("trace span %.1f ms for %d launches" % ((t1 - t0) / 1e6, len(rows)))
 

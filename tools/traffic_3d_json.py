@@ -12,7 +12,7 @@ import bench  # noqa: E402
 out = {"sources_sha16": bench.kernel_sources_sha16(),
        "method": "tools/pmc_3d.sh: rocprofv3 --kernel-trace --pmc <one group per run> -- python tools/iso_3d.py <model> --mark; the last of 3 passes; "
                  "dispatches segmented per launch by the executor's launch-trace hash kernel; fetch_bytes_x2 = FETCH_SIZE KB x 1024 x 2, "
-                 "write_bytes = WRITE_SIZE KB x 1024; batch 1"}
+                 "write_bytes = WRITE_SIZE KB x 1024; batch 1 unless the key says otherwise (keys '... batch N': per launch of N samples)"}
 for spec in sys.argv[2:]:
     key, path = spec.split("=", 1)
     rows = json.load(open(path))
