@@ -274,7 +274,7 @@ def bench_3d(lib, dev, model, half2, b, steps, warmup, nctx, blob, weights, desc
     Returns the JSON object (rank 0) or None."""
     w_img, h_img, max_disp, cfg_name = MODELS_3D[model]
     cfg = getattr(synth, cfg_name)
-    nctx = max(1, min(nctx, 2))                               # the volumes are large: at most two contexts
+    nctx = max(1, min(nctx, int(os.environ.get("RT_BENCH_3D_CONTEXTS", "3"))))      # three contexts (NVSmall half2 b8, MI355X: 2: 768, 3: 782, 4: 771 pairs/s; ~6 GB of tensors each)
     nets = [lib.create(model, w_img, h_img, max_batch=b, weights=blob, fp16_weights=half2) for _ in range(nctx)]
     ls, rs = zip(*(synth.synth_pair(h_img, w_img, 1234 + rank * 64 + i) for i in range(b)))
     left, right = torch.from_numpy(np.stack(ls)).to(dev), torch.from_numpy(np.stack(rs)).to(dev)
@@ -569,7 +569,7 @@ def secondary_lines(lib, dev):
 
     def three_d(model, half2, b, steps, warmup):
         weights, blob, desc = weights_3d(model, half2)
-        return bench_3d(lib, dev, model, half2, b, steps, warmup, 2, blob, weights, desc, check=True)
+        return bench_3d(lib, dev, model, half2, b, steps, warmup, 3, blob, weights, desc, check=True)
 
     add("C5: NVSmall half2, 1025x321, batch 8", lambda: three_d("nvsmall", True, 8, 24, 3))
     add("C4: ResNet-18 3D fp32, 1025x321, batch 4 (one GPU's shard of batch 32 over 8)", lambda: three_d("resnet18", False, 4, 20, 2))

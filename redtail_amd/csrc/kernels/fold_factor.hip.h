@@ -76,16 +76,18 @@ __global__ void __launch_bounds__(256) fold_t_kernel(FoldFactorArgs p) {
         }
 }
 
-// E[n, d, k, y]: one thread per (4 output channels, y) -- the image column is read once for the four; grid (ceil(H * K / 4 / 256), D, N)
+// E[n, d, k, y]: FOUR lanes per (4 output channels, y), each over a quarter of the input channels, summed with two DPP-free lane
+// exchanges -- the loop is a chain of dependent loads and was latency-bound at 288 trips per thread (0.14 ms per batch of 8 for 71 MFLOP);
+// grid (ceil(H * K / 256), D, N): 256 threads = 64 (k-quad, y) items x 4 channel quarters.
 __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
     const int d = blockIdx.y, n = blockIdx.z;
     const int K4 = p.K / 4;
-    if (t >= p.H * K4) return;
-    const int k = (t % K4) * 4, y = t / K4;
+    const bool live = t < p.H * K4;
+    const int k = live ? (t % K4) * 4 : 0, y = live ? t / K4 : 0;
     const float* __restrict__ r = p.x + (int64_t)n * p.x_bstride + (int64_t)p.F * p.H * p.W;
-    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    // four chains per output over the channels (F is a multiple of 4), their eight loads issued together: the loop is latency-bound
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};       // two chains per output over this lane's channels (F is a multiple of 4)
+    const int c0 = part * (p.F / 4), c1 = c0 + p.F / 4;
     for (int j = 0; j < 3; j++) {
         const int dz = d + j - 1, col = p.W + 1 - d - j;
         if (dz < 0 || dz >= p.D || d + j < 2 || col < 0) continue;                    // depth padding / the pixel lies outside the image as well
@@ -95,23 +97,29 @@ __global__ void __launch_bounds__(256) fold_edge_kernel(FoldFactorArgs p) {
             const float* __restrict__ wv = p.wedge + ((int64_t)(j * 3 + dy) * p.F) * p.K + k;
             const float* __restrict__ rv = r + (int64_t)iy * p.W + col;
             const int64_t cstep = (int64_t)p.H * p.W;
-            for (int c = 0; c < p.F; c += 4) {
-                f32x4 w4[4];
-                float rr[4];
+            for (int c = c0; c < c1; c += 2) {
+                f32x4 w4[2];
+                float rr[2];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    w4[u] = *reinterpret_cast<const f32x4*>(wv + (int64_t)(c + u) * p.K);
-                    rr[u] = rv[(c + u) * cstep];
+                for (int u = 0; u < 2; u++) {
+                    const int cc = c + u < c1 ? c + u : c;                              // (an odd quarter repeats its last channel with a zero factor)
+                    w4[u] = *reinterpret_cast<const f32x4*>(wv + (int64_t)cc * p.K);
+                    rr[u] = c + u < c1 ? rv[cc * cstep] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 2; u++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[u][q] = fmaf(w4[u][q], rr[u], acc[u][q]);
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k + q) * p.H + y] = (acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]);
+    for (int q = 0; q < 4; q++) {
+        float v = acc[0][q] + acc[1][q];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (live && part == 0) p.e[(int64_t)n * p.e_bstride + ((int64_t)d * p.K + k + q) * p.H + y] = v;
+    }
 }
 
 // out[d]: one thread per pixel and group of G output channels, all depths.  TOUT = float / _Float16; IL: (D, K/G, H, W, G) output.

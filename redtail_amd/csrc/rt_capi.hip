@@ -1489,7 +1489,7 @@ int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batc
     if (G == 8) hipLaunchKernelGGL(rt::fold_t_kernel<8>, tgrid, dim3(256), 0, S(s), a);
     else hipLaunchKernelGGL(rt::fold_t_kernel<4>, tgrid, dim3(256), 0, S(s), a);
     RT_LAUNCH_CHECK("fold_t_kernel");
-    hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * (ff->K / 4), 256), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
+    hipLaunchKernelGGL(rt::fold_edge_kernel, dim3((unsigned)rt::cdiv(ff->H * (ff->K / 4), 64), (unsigned)ff->D, (unsigned)batch), dim3(256), 0, S(s), a);
     RT_LAUNCH_CHECK("fold_edge_kernel");
     // the combining pass over x < W - 1, then the last column (edge term) -- see fold_combine_kernel
     const dim3 grid((unsigned)rt::cdiv(ff->W - 1, 256), (unsigned)ff->H, (unsigned)(batch * (ff->K / G)));

@@ -1,0 +1,16 @@
+#!/bin/bash
+# What the driver runs at round end, on the builder's box: the GPU test tier (with the skip reasons), smoke(), the default bench line and the driver's command
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/${1:-r05_full}; mkdir -p $O
+timeout 3000 python -m pytest tests/ -x -q -m gpu -rs > $O/pytest.log 2>&1; tail -n 50 $O/pytest.log | grep -v "^$" | tail -n 45
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -n 2 $O/smoke.log
+python bench.py > $O/bench_plain.json 2> $O/bench_plain.err; tail -n 2 $O/bench_plain.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> /dev/null
+python - <<PY
+import json
+for f in ("bench_plain", "bench_20_5"):
+    d = json.load(open("$O/%s.json" % f)); r = d["roofline"]
+    print(f, round(d["value"], 1), d["unit"], "frac", round(r["frac"], 4), r["bound"], "traffic", r.get("traffic"), "latency", d.get("latency_ms_per_pair"), "diff", d.get("contexts_max_abs_diff"))
+    for k, v in (d.get("secondary") or {}).items():
+        print("   ", k[:60], round(v.get("value", 0), 1) if isinstance(v, dict) and "value" in v else v.get("error", v) if isinstance(v, dict) else v)
+PY
