@@ -83,13 +83,6 @@ __device__ static __forceinline__ void buf_store2(f32x2_t v, buf_rsrc r, unsigne
 // below 2^31 and kBufOOB + soff is still out of range, so dropped lanes stay dropped.
 __device__ static __forceinline__ void buf_store4(f32x4 v, buf_rsrc r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff + soff, 0u, 0);
-#if defined(RT_STORE_NOP) && RT_STORE_NOP == 1      // probes of the round-3 nondeterminism hunt (profiles/r03_race_bisect.txt)
-    asm volatile("s_nop 3" ::: "memory");
-#elif defined(RT_STORE_NOP) && RT_STORE_NOP == 2
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#elif defined(RT_STORE_NOP) && RT_STORE_NOP == 3
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 }
 __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);

@@ -42,17 +42,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // with 1-8 spills), so the register-staged form is built.
 #define RT_WINO_LDS_DMA 0
 #endif
-// Probes of the round-4 hunt for the multi-context deviation of the interleaved instantiations (profiles/r04_race.txt; tools/race_locate.py):
-// 1 = the next chunk's global loads are issued AFTER the chunk's MFMAs (no vector-memory returns land while MFMAs execute),
-// 2 = ~128 idle cycles after each k-step's 16 MFMAs (they have drained before the next LDS reads are issued),
-// 3 = every LDS operand of a k-step is in registers before its first MFMA issues (no LDS return lands while MFMAs execute),
-// 4 = 32 idle cycles before each 16-byte store of the interleaved epilogue,
-// 5 = the interleaved residual is read with four 4-byte loads per pixel instead of one 16-byte load,
-// 6 = s_waitcnt vmcnt(0) after each 16-byte residual load (the four loads of a lane do not overlap),
-// 7 = 256 idle cycles between the last MFMA of the main loop and the epilogue's first read of an accumulator.   0 = the kernel as measured.
-#ifndef RT_WINO_PROBE
-#define RT_WINO_PROBE 0
-#endif
+// (The seven in-kernel probes of the round-4 hunt for the multi-context deviation of the interleaved instantiations -- idle cycles,
+// waits and operand orders around the MFMAs, stores and residual loads -- are described with their results in profiles/r04_race.txt;
+// they left the product source in round 5: git show 49a042d:redtail_amd/csrc/kernels/conv_wino.hip.h has them.)
 template <int NW>
 struct WinoCfg {
     static constexpr int CC = 8;                          // input channels per chunk (2 MFMA k-steps of 4)
@@ -237,15 +229,7 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-#if RT_WINO_PROBE == 5
-                f32x4 v;
-                for (int i = 0; i < 4; i++) v[i] = buf_load(rs_r, il_off(a, b) == kBufOOB ? kBufOOB : il_off(a, b) + 4u * i, (unsigned)(nblk * 32 * cs32) * 4u);
-#else
                 const f32x4 v = kAblResid ? f32x4{0.f, 1.f, 2.f, 3.f} : buf_load4(rs_r, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
-#endif
-#if RT_WINO_PROBE == 6 && !defined(HIPEMU)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 #pragma unroll
                 for (int i = 0; i < 4; i++) rr[i][a][b] = v[i];
             }
@@ -290,11 +274,6 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
             f32x4 a4[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) a4[q] = ubase[ub + (j * 16 + q) * 32];
-#if RT_WINO_PROBE == 3 && !defined(HIPEMU)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             // rows: w = B^T d  (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), two columns at a time
             f32x2 w[4][2];
 #pragma unroll
@@ -319,14 +298,6 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
             for (int q = 0; q < 16; q++)
                 acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q >> 2][q & 3], v[q], acc[q], 0, 0, 0);
-#if RT_WINO_PROBE == 3 && !defined(HIPEMU)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#if RT_WINO_PROBE == 2 && !defined(HIPEMU)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     };
 
@@ -344,21 +315,10 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
         if (ch) __syncthreads();       // everyone finished reading the previous chunk from LDS
         stage_to_lds();
         __syncthreads();
-#if RT_WINO_PROBE == 1
-        compute(WDMA ? (ch & 1) * (Cfg::U_ELEMS / 4) : 0);
-        asm volatile("" ::: "memory");
-        if (ch + 1 < nchunks) prefetch(ch + 1);
-#else
         if (ch + 1 < nchunks) prefetch(ch + 1);
         compute(WDMA ? (ch & 1) * (Cfg::U_ELEMS / 4) : 0);
-#endif
     }
 
-#if RT_WINO_PROBE == 7 && !defined(HIPEMU)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // ---- epilogue: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), activation, stores ---------------------------------
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, ybase, ESY));
     asm volatile("" ::: "memory");     // keep the recomputation below the loop
@@ -400,9 +360,6 @@ __global__ void __launch_bounds__(64 * NW, RT_WINO_MINW) conv_wino_f32_kernel(Co
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const f32x4 o = {yo[0][a][b], yo[1][a][b], yo[2][a][b], yo[3][a][b]};
-#if RT_WINO_PROBE == 4 && !defined(HIPEMU)
-                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
                     if (!kAblStore || o[0] == 12345.678f)
                         buf_store4(o, rs_y, il_off(a, b), (unsigned)(nblk * 32 * cs32) * 4u);
                 }

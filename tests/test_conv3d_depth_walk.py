@@ -14,10 +14,10 @@ from test_deconv3d_half2 import q16, h16, dev16, empty, host, il_cm, un_il_cm, i
 DW_CASES = [
     # c, k, d, h, w, channel-major output, residual (0 none, 1 interleaved), depth segments (0 = chosen by the plan)
     (16, 32, 5, 13, 37, False, 0, 0),      # one chunk per slice (resident), two 12-row tiles (the second with one row), two column tiles
-    (32, 32, 7, 25, 33, False, 1, 2),      # two chunks per slice (resident), skip tensor, 3 x 2 tiles: an odd tile count; two depth segments
+    (32, 32, 6, 14, 33, False, 1, 2),      # two chunks per slice (resident), skip tensor, 2 x 2 tiles; two depth segments
     (32, 64, 4, 12, 40, True, 0, 4),       # two blocks of output channels, channel-major (K/8, D, H, W, 8) output, one slice per segment
-    (48, 24, 3, 9, 20, False, 0, 0),       # three chunks per slice (streamed weights), Cout % 32 != 0, image smaller than a tile
-    (64, 64, 6, 14, 65, False, 1, 3),      # four chunks per slice (streamed), skip tensor, three column tiles, segments of 2
+    (48, 24, 3, 9, 70, False, 0, 0),       # three chunks per slice (streamed weights), Cout % 32 != 0, three column tiles: an odd tile count
+    (64, 32, 5, 13, 40, False, 1, 2),      # four chunks per slice (streamed), skip tensor, 2 x 2 tiles (an odd row), segments of 3 + 2
     (16, 8, 1, 5, 9, True, 0, 0),          # a single depth slice
     (32, 32, 2, 3, 34, False, 0, 2),       # two slices, two segments of one
 ]

@@ -133,7 +133,8 @@ def main():
     print("per pair at batch %d: ms, TFLOP/s of the direct form, fraction of 2.5 PF" % batch)
     for name, c, kk, d, h, w in SHAPES:
         gf = 2.0 * 27 * c * kk * d * h * w / 1e9
-        rows = [("r4 (per slice)", base, {"RT_F16_DW": "0"}), ("depth walk", base, {"RT_F16_DW": "1"})]
+        rows = [("4 x 32 tiles (conv_f16mma_kernel)", base, {"RT_F16_DW": "0", "RT_F16_R4": "0"}), ("r4 (per slice)", base, {"RT_F16_DW": "0"}),
+                ("depth walk", base, {"RT_F16_DW": "1"})]
         for ns in (1, 2, 3, 4):
             rows.append(("depth walk, %d segment(s)" % ns, base, {"RT_F16_DW": "1", "RT_DW_NSEG": str(ns)}))
         for v, _, what in VARIANTS:
