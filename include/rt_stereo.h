@@ -229,6 +229,14 @@ int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dtype);
 int rt_conv_plan_supports_il8(const rtConvPlan* plan);
 int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8);
 
+/* The soft-argmax that follows the last Conv3DTranspose of the 3-D models (disp_softargmax: reference lib/softargmax_plugin.cpp:167-205
+ * over the volume lib/conv3d_transpose_plugin.cpp:137-166 wrote) inside that layer's launch: mode 1 = soft-argmax, 2 = soft-argmin over the
+ * output depth, 0 = off.  rt_conv_enqueue then writes the (batch, 1, H, W) fp32 map to y (plain pitch W) and the (D, 1, H, W) volume is
+ * never stored.  Only the depth-walking form of that layer has it -- one output channel, 32 input channels, fp16 channel-interleaved input,
+ * fp32 output, no residual; any other plan returns RT_E_UNSUPPORTED and stays as it is (the caller then runs rt_softargmax on the volume).
+ * Call it last: rt_conv_plan_set_io_types / rt_conv_plan_set_layouts switch it off. */
+int rt_conv_plan_set_softarg(rtConvPlan* plan, int mode);
+
 typedef struct rtConv3dDesc {
     int C, K;               /* conv: input channels C, output channels K.  Transposed op: K = INPUT   */
                             /* channels (tensor KDHW), C = OUTPUT channels (tensor DCHW)             */

@@ -98,6 +98,7 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_set_io_types": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "rt_conv_plan_set_softarg": (c_int, [c_void_p, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_enqueue_hint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "rt_conv_plan_workspace_bytes": (ctypes.c_size_t, [c_void_p, c_int]),
@@ -305,6 +306,11 @@ class ConvPlan:
     def set_layouts(self, x_il8, y_il8, r_il8=False):
         """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
         self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")
+
+    def set_softarg(self, mode):
+        """end the launch in the soft-argmax (1) / soft-argmin (2) over the output depth (last Conv3DTranspose of a 3-D model): y becomes the
+        (batch, 1, H, W) map; raises RtError (RT_E_UNSUPPORTED) for a plan that has no such form"""
+        self.klib.check(self.klib.lib.rt_conv_plan_set_softarg(self.handle, int(mode)), "rt_conv_plan_set_softarg")
 
     def enqueue(self, x, y, residual=None, batch=1, stream=None, hints=0):
         self.klib.check(self.klib.lib.rt_conv_enqueue_hint(self.handle, _ptr(x), _ptr(y), _ptr(residual), batch, stream, hints),

@@ -483,6 +483,7 @@ private:
     void foldCostVolumes();
     void assignHalf3D();
     void assignInterleaved3D();
+    void fuseSoftargmax3D();
     void fuseResBlocks();
     void mergeSiamese();
     bool ok_ = false;
@@ -544,6 +545,7 @@ EngineImpl::EngineImpl(NetworkImpl& net, int max_batch, bool half2, ILogger& log
     if (ok_) foldCostVolumes();
     if (ok_) assignHalf3D();
     if (ok_) assignInterleaved3D();
+    if (ok_) fuseSoftargmax3D();        // after the layouts: only the depth-walking form of the last layer has the fused reduction
     if (ok_) mergeSiamese();
     if (ok_) applySampleStrides();
     if (ok_) assignStreams();           // final: the passes above removed and merged ops (waits and publish flags are recomputed)
@@ -1502,6 +1504,40 @@ void EngineImpl::assignHalf3D() {
 // instead of eight 2-byte loads, 8-byte stores instead of four 2-byte ones: 0.36 vs 0.54 ms for the 32 -> 32 layer of NVSmall
 // as a 2-D proxy, tools/dev/il_probe_f16.py); the folded-cost-volume Conv3D writes one; a fused Conv3DTranspose reads its skip
 // tensor that way.  Which tensors qualify follows from the launches' own capabilities (IStereoPlugin::ilCaps).
+// The soft-argmax at the end of the 3-D models (disp_softargmax over the last Conv3DTranspose's volume, nvsmall_1025x321_net.cpp:401-425)
+// reduces over the axis that layer's kernel walks: when the plan has the fused form (rt_conv_plan_set_softarg), the launch writes the
+// (1, H, W) map itself and the volume tensor -- 127 MB per pair at 1025 x 321, written once and read once -- is never allocated.
+void EngineImpl::fuseSoftargmax3D() {
+    if (knob("RT_NO_SOFTARG_FUSE") || knob("RT_NO_FUSION")) return;
+    for (size_t si = 0; si < ops_.size(); si++) {
+        const Op sa = ops_[si];
+        if (sa.kind != OpKind::kPlugin || sa.half_kind || sa.in.size() != 1) continue;
+        IStereoPlugin* sp = sa.plugin ? dynamic_cast<IStereoPlugin*>(sa.plugin) : nullptr;
+        if (!sp || sp->kind() != Kind::kSoftargmax) continue;
+        const int vol = root(sa.in[0]);
+        const TensorImpl& vt = *tensors_[vol];
+        if (vt.is_output || vt.is_input || vt.f16 || vt.il8 || vt.pitch || vt.bstride || vt.alias_of >= 0) continue;
+        int producer = -1, uses = 0;
+        for (size_t j = 0; j < ops_.size(); j++) {
+            if (j == si) continue;
+            for (int x : ops_[j].in) uses += root(x) == vol;
+            if (ops_[j].resid >= 0 && root(ops_[j].resid) == vol) uses++;
+            if (root(ops_[j].out) == vol) { uses += producer >= 0; producer = (int)j; }
+        }
+        if (uses != 0 || producer < 0 || producer > (int)si) continue;
+        Op& conv = ops_[producer];
+        if (conv.kind != OpKind::kConv3D || !conv.splugin || conv.splugin->kind() != Kind::kConv3DTranspose || conv.stream != sa.stream) continue;
+        if (!conv.splugin->setSoftarg(sp->softargmaxType() == SoftargmaxType::kMin ? 2 : 1)) continue;     // no fused form for this plan
+        conv.out = sa.out;
+        for (int w : sa.wait_on) conv.wait_on.push_back(root(w));
+        conv.lays.insert(conv.lays.end(), sa.lays.begin(), sa.lays.end());
+        const std::string sname = sa.name;
+        ops_.erase(ops_.begin() + si);
+        log_.log(ILogger::Severity::kINFO, (sname + ": folded into " + ops_[producer].name + " (the volume is never materialised)").c_str());
+        si--;
+    }
+}
+
 void EngineImpl::assignInterleaved3D() {
     if (knob("RT_NO_IL8") || knob("RT_NO_IL8_3D")) return;
     // half2 mode: the fp16 4-D tensors, groups of 8 channels.  fp32 engines (round 4): the fp32 4-D tensors between Conv3D launches,

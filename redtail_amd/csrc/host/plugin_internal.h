@@ -45,6 +45,9 @@ public:
     // 3 = output only together with the input), and their layouts (kept across setFusion)
     virtual int ilCaps() const { return 0; }
     virtual bool setLayouts(bool, bool, bool) { return false; }
+    // Conv3DTranspose: end the launch in the soft-argmax (1) / soft-argmin (2) over the output depth that follows it (rt_conv_plan_set_softarg;
+    // declared after the types and layouts, which reset it); false = the plan has no such form
+    virtual bool setSoftarg(int) { return false; }
     // (workspace: getWorkspaceSize(maxBatchSize) bytes private to the stream, or null -- the plan then uses a block of its own)
     virtual int enqueueFused(int, const void*, void*, const void*, void*, size_t, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}

@@ -346,12 +346,19 @@ public:
         if (rt_conv_plan_set_io_types(plan_, x16 ? RT_F16 : RT_F32, y16 ? RT_F16 : RT_F32) != 0) return false;
         x16_ = x16; y16_ = y16;
         xil_ = yil_ = ril_ = false;          // a change of the storage types resets the layouts
+        softarg_ = 0;
         return true;
     }
     int ilCaps() const override { return plan_ ? rt_conv_plan_supports_il8(plan_) : 0; }
     bool setLayouts(bool x, bool y, bool r) override {
         if (!plan_ || rt_conv_plan_set_layouts(plan_, x, y, r) != 0) return false;
         xil_ = x; yil_ = y; ril_ = r;
+        softarg_ = 0;
+        return true;
+    }
+    bool setSoftarg(int mode) override {
+        if (!plan_ || !transposed_ || rt_conv_plan_set_softarg(plan_, mode) != 0) return false;
+        softarg_ = mode;
         return true;
     }
     size_t getSerializationSize() override { return 0; }        // not serialisable, as in the reference
@@ -373,6 +380,7 @@ protected:
         RT_CHECKL(rc, log_);
         if (rc == 0 && (x16_ || y16_) && rt_conv_plan_set_io_types(plan_, x16_ ? RT_F16 : RT_F32, y16_ ? RT_F16 : RT_F32) != 0) x16_ = y16_ = false;
         if (rc == 0 && (xil_ || yil_ || ril_) && rt_conv_plan_set_layouts(plan_, xil_, yil_, ril_) != 0) xil_ = yil_ = ril_ = false;
+        if (rc == 0 && softarg_ && rt_conv_plan_set_softarg(plan_, softarg_) != 0) softarg_ = 0;
         return rc == 0;
     }
     virtual void fillDesc(rtConv3dDesc& d) const = 0;
@@ -385,6 +393,7 @@ protected:
     internal::ConvFusion fusion_;
     bool x16_ = false, y16_ = false;
     bool xil_ = false, yil_ = false, ril_ = false;
+    int softarg_ = 0;
     rtConvPlan* plan_ = nullptr;
     Dims x_dims_{}, y_dims_{};
     ILogger& log_;

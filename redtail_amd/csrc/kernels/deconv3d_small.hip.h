@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(256) deconv3d_s2_small_kernel(Deconv3dSmallArg
 //                                 x-phases of an output row are adjacent, stored as one 8-byte access; 16 lanes cover 128 bytes.
 // A wave owns 16 consecutive blocks along x and kSmallIlIters such groups; 8 MFMAs (K = 32) per group.
 constexpr int kSmallIlIters = 3;
+constexpr float kSaLog2e = 1.44269504088896341f;      // deconv3d_s2_ilw_kernel<SA>: the softmax runs on exp2
 typedef _Float16 f16x8_small __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p) {
@@ -258,6 +259,13 @@ __global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p
 // step), the next slice is requested before the current step's MFMAs (three register sets, the loop unrolled by three so that their roles
 // are static), and prologue and weight operands are paid once per walk.  Same arithmetic in the same order: bit-identical.
 // Grid: x = ceil(groups / 4) * segments, y = pairs of block rows, z = samples; p.Mz = depth blocks, seg_len blocks per segment.
+//
+// SA != 0 (1 = soft-argmax, 2 = soft-argmin; C = 1, one segment, no residual): the walk IS the reduction axis of the soft-argmax that follows
+// the last layer of the 3-D models (disp_softargmax, softargmax_plugin.cpp:167-205), so the (Dx, 1, Hx, Wx) fp32 volume is never written:
+// every lane keeps an online softmax (running maximum, sum of weights, weighted sum of the slice index) for its 2 x 2 x 2 outputs of one
+// depth parity, the two parities are merged with one lane exchange at the end, and p.y receives the (1, Hx, Wx) map (plain pitch Wx,
+// p.y_bstride = Hx * Wx).  NVSmall 1025 x 321: 127 MB per pair less written and read again.
+template <int SA>
 __global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs p, int seg_len, int nseg) {
     const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,6 +308,12 @@ __global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs 
 #pragma unroll
             for (int jx = 0; jx < 2; jx++) b[ry][jx] = buf_load4(rs_x, ok ? pos[ry][jx] : kBufOOB, ok ? (unsigned)iz * zbytes : 0u);
     };
+    // (SA) running maximum (a finite start: exp2(start - anything) = 0 without an inf - inf), sum of weights, weighted index sum
+    float sa_m[2][4], sa_s[2][4], sa_w[2][4];
+#pragma unroll
+    for (int row = 0; row < 2; row++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sa_m[row][j] = -1e30f; sa_s[row][j] = 0.f; sa_w[row][j] = 0.f; }
     auto block = [&](int mz, const f32x4 (&b0)[3][2], const f32x4 (&b1)[3][2]) __attribute__((always_inline)) {
         f32x4 acc[2] = {{bias, bias, bias, bias}, {bias, bias, bias, bias}};
 #pragma unroll
@@ -312,27 +326,46 @@ __global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs 
             }
         }
         const int oz = 2 * mz + fz, ox = 2 * mx;
+        if constexpr (SA != 0) {
+            // online softmax over the slices this lane sees (oz = fz, fz + 2, ...): exp2 on pre-scaled arguments; a slice beyond the kept
+            // depth enters as -inf (weight 0)
+            const bool z_ok = oz < p.Dx;
+            const float fzv = (float)oz;
 #pragma unroll
-        for (int row = 0; row < 2; row++) {
-            if (my0 + row >= nrows) break;                         // uniform
+            for (int row = 0; row < 2; row++)
 #pragma unroll
-            for (int fy = 0; fy < 2; fy++) {
-                const int oy = 2 * (my0 + row) + fy;
-                const bool row_ok = co < p.C && oz < p.Dx && oy < p.Hx;
-                const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
-                const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
-                const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
-                f32x2_t o = {acc[row][2 * fy], acc[row][2 * fy + 1]};
-                if (has_r) {
-                    const f32x2_t r2 = buf_load2(rs_r, v2, 0);
-                    const float r1 = buf_load(rs_r, v1, 0);
-                    o[0] += r2[0] + r1;
-                    o[1] += r2[1];
+                for (int j = 0; j < 4; j++) {
+                    const float v = apply_act_rt(acc[row][j], p.act) * (SA == 2 ? -kSaLog2e : kSaLog2e);
+                    const float xv = z_ok ? v : -INFINITY;
+                    const float mn = fmaxf(sa_m[row][j], xv);
+                    const float c = __builtin_amdgcn_exp2f(sa_m[row][j] - mn), e = __builtin_amdgcn_exp2f(xv - mn);
+                    sa_s[row][j] = sa_s[row][j] * c + e;
+                    sa_w[row][j] = sa_w[row][j] * c + e * fzv;
+                    sa_m[row][j] = mn;
                 }
-                o[0] = apply_act_rt(o[0], p.act);
-                o[1] = apply_act_rt(o[1], p.act);
-                buf_store2(o, rs_y, v2, 0);
-                buf_store(o[0], rs_y, v1, 0);
+        } else {
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+                if (my0 + row >= nrows) break;                         // uniform
+#pragma unroll
+                for (int fy = 0; fy < 2; fy++) {
+                    const int oy = 2 * (my0 + row) + fy;
+                    const bool row_ok = co < p.C && oz < p.Dx && oy < p.Hx;
+                    const unsigned off = (unsigned)(((oz * p.C + co) * p.Hx + oy) * p.yp + ox) * 4u;
+                    const unsigned v2 = (row_ok && ox + 1 < p.Wx) ? off : kBufOOB;        // both x-phases inside
+                    const unsigned v1 = (row_ok && ox + 1 == p.Wx) ? off : kBufOOB;       // only the even one (odd Wx)
+                    f32x2_t o = {acc[row][2 * fy], acc[row][2 * fy + 1]};
+                    if (has_r) {
+                        const f32x2_t r2 = buf_load2(rs_r, v2, 0);
+                        const float r1 = buf_load(rs_r, v1, 0);
+                        o[0] += r2[0] + r1;
+                        o[1] += r2[1];
+                    }
+                    o[0] = apply_act_rt(o[0], p.act);
+                    o[1] = apply_act_rt(o[1], p.act);
+                    buf_store2(o, rs_y, v2, 0);
+                    buf_store(o[0], rs_y, v1, 0);
+                }
             }
         }
     };
@@ -349,6 +382,22 @@ __global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs 
         if (mz + 2 >= z1) break;
         load_slice(s1, mz + p.bz + 4);
         block(mz + 2, s2, s0);
+    }
+    if constexpr (SA != 0) {
+        // merge the two depth parities (lanes q = 0 and q = 1 of the same 16 blocks), then the q = 0 lane writes its 2 x 2 x 2 pixels
+        const int ox = 2 * mx;
+#pragma unroll
+        for (int row = 0; row < 2; row++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float m1 = __shfl_xor(sa_m[row][j], 16), s1v = __shfl_xor(sa_s[row][j], 16), w1v = __shfl_xor(sa_w[row][j], 16);
+                const float mn = fmaxf(sa_m[row][j], m1);
+                const float c0 = __builtin_amdgcn_exp2f(sa_m[row][j] - mn), c1 = __builtin_amdgcn_exp2f(m1 - mn);
+                const float st = sa_s[row][j] * c0 + s1v * c1, wt = sa_w[row][j] * c0 + w1v * c1;
+                const int oy = 2 * (my0 + row) + (j >> 1), oxj = ox + (j & 1);
+                const bool ok = q == 0 && oy < p.Hx && oxj < p.Wx;
+                buf_store(wt / st, rs_y, ok ? (unsigned)(oy * p.Wx + oxj) * 4u : kBufOOB, 0);
+            }
     }
 }
 

@@ -581,6 +581,7 @@ struct rtConvPlan {
     // launch-time knobs of the environment (A/B and test switches), read once at the plan's first enqueue: getenv walks the
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
+    int softarg = 0;              // rt_conv_plan_set_softarg: 1 / 2 = the launch ends in a soft-argmax / soft-argmin over the output depth
     mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
@@ -2022,6 +2023,7 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
     RT_REQUIRE(plan, "rt_conv_plan_set_io_types: null plan");
     ExactScope exact_scope(plan->flags);       // re-planning (repack_f32: choose_tiling, s3first / s3p eligibility) under the plan's own options
     RT_REQUIRE((x_dtype == RT_F32 || x_dtype == RT_F16) && (y_dtype == RT_F32 || y_dtype == RT_F16), "rt_conv_plan_set_io_types: bad dtype");
+    plan->softarg = 0;
     if (!plan->is2d) {
         // 3-D plans (Conv3D / Conv3DTranspose): fp16 storage of the dense (D,C,H,W) / (K,D,H,W) tensors, the split-fp16 kernel
         // reads / writes them as they are (an fp16 input is its own high part); the small-output last layer reads fp16, writes fp32
@@ -2190,6 +2192,7 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
 extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
     RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
     ExactScope exact_scope(plan->flags);
+    plan->softarg = 0;                  // (a fused soft-argmax is declared last, on the final tensor types and layouts)
     if (!x_il8 && !y_il8 && !r_il8) {
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
@@ -2341,6 +2344,24 @@ extern "C" size_t rt_conv_plan_workspace_bytes(const rtConvPlan* plan, int batch
     return fold_factor_bytes(plan, batch);           // (a plan that has the factored form may still launch the gather form: the bytes are then unused)
 }
 
+// The soft-argmax over the output depth that follows the last Conv3DTranspose of a 3-D model, inside the launch (deconv3d_s2_ilw_kernel<SA>):
+// mode 1 = soft-argmax, 2 = soft-argmin, 0 = off.  rt_conv_enqueue then writes the (batch, 1, H, W) fp32 map to y (plain pitch W) and the
+// volume does not exist.  Only the depth-walking last layer has the form: one output channel, 32 input channels, an fp16 channel-interleaved
+// input, an fp32 output, no residual.  Anything else: RT_E_UNSUPPORTED and the plan is unchanged (the caller keeps rt_softargmax).
+// Declared LAST: rt_conv_plan_set_io_types / _set_layouts switch it off again.
+extern "C" int rt_conv_plan_set_softarg(rtConvPlan* plan, int mode) {
+    RT_REQUIRE(plan, "rt_conv_plan_set_softarg: null plan");
+    RT_REQUIRE(mode >= 0 && mode <= 2, "rt_conv_plan_set_softarg: mode must be 0, 1 (max) or 2 (min)");
+    if (mode == 0) { plan->softarg = 0; return 0; }
+    const bool ok = plan->is_deconv3d && plan->subs.size() == 1 && plan->subs[0].small3d == 1 && plan->subs[0].x_f16 && plan->subs[0].x_il8 &&
+                    !plan->subs[0].y_f16 && plan->subs[0].s3.K == 32 && plan->subs[0].s3.C == 1 && !plan->has_resid &&
+                    env_int("RT_SMALL_IL_WALK", -1) != 0 && env_int("RT_SOFTARG_FUSE", 1) != 0;
+    if (!ok) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_softarg: only the depth-walking last Conv3DTranspose (1 output channel, 32 interleaved fp16 "
+                         "input channels, fp32 output, no residual) ends in a soft-argmax");
+    plan->softarg = mode;
+    return 0;
+}
+
 extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                                     rtStream s, int hints) {
     return rt_conv_enqueue_ws(plan, x, y, residual, batch, nullptr, 0, s, hints);
@@ -2387,7 +2408,14 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                 const int groups = (int)rt::cdiv((a.Wx + 1) / 2, 16);
                 RT_REQUIRE(batch <= 65535, "rt_conv_enqueue: grid limit exceeded");
                 const int rowpairs = (int)rt::cdiv((a.Hx + 1) / 2, 2);
-                if (a.K == 32 && plan->opt_small_walk != 0) {
+                if (plan->softarg) {
+                    // the walk is the soft-argmax's reduction axis: one segment, y = the (batch, 1, Hx, Wx) map
+                    RT_REQUIRE(a.K == 32 && a.C == 1 && !a.resid && rowpairs <= 65535, "rt_conv_enqueue: plan lost the form its fused soft-argmax needs");
+                    a.y_bstride = (int64_t)a.Hx * a.Wx;
+                    dim3 gw((unsigned)rt::cdiv(groups, 4), (unsigned)rowpairs, (unsigned)batch);
+                    if (plan->softarg == 2) hipLaunchKernelGGL(rt::deconv3d_s2_ilw_kernel<2>, gw, dim3(256), 0, S(s), a, a.Mz, 1);
+                    else hipLaunchKernelGGL(rt::deconv3d_s2_ilw_kernel<1>, gw, dim3(256), 0, S(s), a, a.Mz, 1);
+                } else if (a.K == 32 && plan->opt_small_walk != 0) {
                     // the depth walk (deconv3d_s2_ilw_kernel): segments long enough to pay for their prologue (>= 8 depth blocks), as many as
                     // it takes to give every SIMD about two waves
                     const int64_t waves = (int64_t)groups * rowpairs * batch;
@@ -2396,7 +2424,7 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                     nseg = (int)rt::cdiv(a.Mz, seg_len);
                     RT_REQUIRE(rowpairs <= 65535, "rt_conv_enqueue: grid limit exceeded");
                     dim3 gw((unsigned)(rt::cdiv(groups, 4) * nseg), (unsigned)rowpairs, (unsigned)batch);
-                    hipLaunchKernelGGL(rt::deconv3d_s2_ilw_kernel, gw, dim3(256), 0, S(s), a, seg_len, nseg);
+                    hipLaunchKernelGGL(rt::deconv3d_s2_ilw_kernel<0>, gw, dim3(256), 0, S(s), a, seg_len, nseg);
                 } else {
                     dim3 g2((unsigned)(rt::cdiv(groups, 4 * rt::kSmallIlIters) * a.Mz), (unsigned)rowpairs, (unsigned)batch);
                     hipLaunchKernelGGL(rt::deconv3d_s2_il_kernel, g2, dim3(256), 0, S(s), a);

@@ -213,6 +213,53 @@ def test_last_deconv3d_on_interleaved_input(backend, monkeypatch, K, C, ydims, d
     plan.destroy()
 
 
+@pytest.mark.parametrize("ydims,dfull,dkeep,pad_d,act,mode,scale", [
+    ((3, 4, 19), 7, 6, 0, capi.RT_ACT_NONE, 2, 1.0),       # NVSmall / ResNet-18 3D: soft-argmin over the kept slices (the surplus one must not weigh in)
+    ((17, 3, 21), 35, 34, 0, capi.RT_ACT_NONE, 2, 8.0),    # 18 depth blocks, a sharply peaked volume
+    ((2, 5, 40), 3, 3, 1, capi.RT_ACT_ELU, 1, 1.0),        # soft-argmax, odd kept depth (the odd parity sees one slice fewer), an activation
+    ((9, 2, 3), 19, 18, 0, capi.RT_ACT_NONE, 2, 60.0),     # values far apart: all the weight on one slice, no overflow
+])
+def test_last_deconv3d_ends_in_softargmax(backend, ydims, dfull, dkeep, pad_d, act, mode, scale):
+    """rt_conv_plan_set_softarg: the depth walk of the last Conv3DTranspose keeps an online softmax and writes the (1, H, W) map of
+    disp_softargmax (lib/softargmax_plugin.cpp:167-205) -- against the oracle's soft-argmax of the oracle's volume, and against
+    rt_softargmax on the volume the unfused plan writes."""
+    n, K, C = 2, 32, 1
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y = q16(rnd(n, K, dy, hy, wy))
+    w = q16(rnd(K, 3, C, 3, 3) * np.float32(scale / np.sqrt(27 * K / 8)))
+    b = q16(rnd(C))
+    ps = (pad_d, 1, 1)
+    vol = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    vol = O.elu(vol) if act == capi.RT_ACT_ELU else vol
+    ref = O.softargmax(vol, mode == 2).numpy()                           # (n, 1, hx, wx)
+    plan = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=act, dtype=capi.RT_F16,
+                                    transposed_in_dims=ydims, out_depth=dkeep)
+    plan.set_io_types(capi.RT_F16, capi.RT_F32)
+    with pytest.raises(capi.RtError):
+        plan.set_softarg(mode)                                           # planar input: no fused form, the plan stays as it is
+    plan.set_layouts(1, 0, 0)
+    v = empty(backend, vol.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), v, None, n)
+    two = empty(backend, ref.shape, False)
+    backend.klib.softargmax(v, two, n, dkeep, hx, wx, mode == 2)
+    two = host(backend, two)
+    plan.set_softarg(mode)
+    out = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), out, None, n)
+    got = host(backend, out)
+    assert not np.isnan(got).any()
+    # fp16-rounded operands, fp32 accumulation: the volume differs from the float64 one by ~1e-4 relative; the map is an average of indices
+    tol = 2e-4 * dkeep * max(1.0, float(np.abs(vol.numpy()).max()))
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    assert np.abs(got - two).max() <= 2e-5 * dkeep, np.abs(got - two).max()
+    plan.set_softarg(0)                                                  # ... and off again: the volume, bit for bit
+    v2 = empty(backend, vol.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), v2, None, n)
+    assert np.array_equal(host(backend, v2), host(backend, v))
+    plan.destroy()
+
+
 def il_2d(a):
     """(N, C, H, W) -> (N, C/8, H, W, 8)"""
     n, c, h, w = a.shape

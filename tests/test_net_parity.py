@@ -279,6 +279,26 @@ def test_3d_fp32_interleaved_equals_planar(rt, monkeypatch, model, cfg, disp):
     assert np.abs(il - planar).max() <= 2e-5, np.abs(il - planar).max()
 
 
+def test_nvsmall_half2_softargmin_inside_the_last_layer(rt, monkeypatch):
+    """half2 NVSmall: disp_softargmax (nvsmall_1025x321_net.cpp:401-425; lib/softargmax_plugin.cpp:167-205) runs inside the depth walk of the
+    last Conv3DTranspose (rt_conv_plan_set_softarg, fuseSoftargmax3D in engine.cpp): one launch fewer, no volume tensor, the same map to
+    fp32 rounding of the online softmax; RT_NO_SOFTARG_FUSE=1 keeps the volume and the plugin's own launch."""
+    w = O.synth_weights_3d(O.NVSMALL_3D)
+    l, r = pairs(1, 17, 33) if rt.kind == "emu" else pairs(2, 33, 65)
+    fused, (_, n_fused) = run_net(rt, "nvsmall", w, l, r, max_disp=8, fp16_weights=True)
+    monkeypatch.setenv("RT_NO_SOFTARG_FUSE", "1")
+    plain, (_, n_plain) = run_net(rt, "nvsmall", w, l, r, max_disp=8, fp16_weights=True)
+    assert not np.isnan(fused).any()
+    assert n_fused == n_plain - 1, (n_fused, n_plain)
+    assert np.abs(fused - plain).max() <= 2e-5 * 8, np.abs(fused - plain).max()
+    wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in w.items()}
+    with torch.no_grad():
+        ref = O.stereo3d(torch.from_numpy(l), torch.from_numpy(r), wq, O.NVSMALL_3D, 8).numpy()
+    # (fp16 tensors on synthetic weights: the distance from the fp32-tensor oracle is the half2 engine's, with or without the fusion)
+    err_f, err_p = np.abs(fused - ref).max(), np.abs(plain - ref).max()
+    assert err_f <= err_p + 2e-4 and err_f <= 5e-2, (err_f, err_p)
+
+
 def test_resnet18_2d_half2_mode(rt, monkeypatch):
     """fp16 weight file = half2 mode (sample_app/main.cpp:256-262): activations between the fused launches are stored
     as fp16, arithmetic stays fp32.  Error against the fp32 oracle with the same (fp16-rounded) weights must stay inside
