@@ -269,6 +269,8 @@ template <int SA>
 __global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs p, int seg_len, int nseg) {
     const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (An XCD-aware order of the workgroups -- each XCD a contiguous run of the logical grid, so that neighbouring row pairs share their
+    //  common input row in one L2 -- was measured in round 5: deconv3D_3 of NVSmall at batch 8 0.516 -> 0.529 ms.  Not kept.)
     const int seg = blockIdx.x % nseg, bxg = blockIdx.x / nseg;
     const int my0 = 2 * blockIdx.y, n = blockIdx.z;
     const int ngroups = (int)cdiv((p.Wx + 1) / 2, 16);

@@ -31,6 +31,12 @@ namespace rt {
 #define RT_FOLD_ABL 0
 #endif
 constexpr int kFoldAbl = RT_FOLD_ABL;
+// (-DRT_FOLD_T_LDS=0: the combining pass reads every T slot from memory, as before round 5's last change)
+#ifndef RT_FOLD_T_LDS
+#define RT_FOLD_T_LDS 1
+#endif
+constexpr bool kFoldTLds = RT_FOLD_T_LDS != 0;
+constexpr int kFoldLdsD = 128;          // depth slices up to which a block's T window (256 + D slots of 16 bytes per channel quad) is kept in LDS
 
 struct FoldFactorArgs {
     const float* x;        // (N, 2F, H, W) fp32 planar: [left | right] feature maps
@@ -158,6 +164,27 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
         for (int v = 0; v < 3; v++) av[v][g] = a[(int64_t)(v * p.K + kg * G + g) * plane] + b;
     }
     const unsigned trow = (unsigned)(p.W + 2) * 16u;                          // bytes of one row of a 4-channel T group (3 K planes of one sample: < 4 GB)
+    // The middle slices (v = 1: all but the first and the last) read T(x - d) from ONE row per channel group, one slot further left per
+    // slice: the block's window of that row -- 256 + D slots -- sits in LDS for the whole walk.  Read from memory instead, a wave asks for
+    // the same kilobyte 47 times, shifted by 16 bytes, and with 32 waves on a CU the 32 KB L1 does not hold their rows: the loads went to the
+    // L2 (2 x the bytes of the output) and were a third of the pass (`no T loads`: 0.68 -> 0.43 ms per batch of 8).
+    constexpr int kTWin = 256 + kFoldLdsD;
+    __shared__ f32x4 t_lds[LASTCOL ? 1 : (G / 4) * kTWin];
+    const bool t_in_lds = !LASTCOL && kFoldTLds && p.D <= kFoldLdsD;           // uniform
+    if constexpr (!LASTCOL) {
+        if (t_in_lds) {
+            const int i0 = blockIdx.x * 256 - p.D + 2;                        // slot j of the window = T index i0 + j; j = tid + D - d at slice d
+#pragma unroll
+            for (int q = 0; q < G / 4; q++) {
+                const unsigned so = (unsigned)((1 * (p.K / 4) + kg * (G / 4) + q) * p.H + y) * trow;
+                for (int j = threadIdx.x; j < 256 + p.D; j += 256) {
+                    const int i = i0 + j;
+                    t_lds[q * kTWin + j] = buf_load4(rs_t, (i >= 0 && i < p.W + 2) ? (unsigned)i * 16u : kBufOOB, so);
+                }
+            }
+            __syncthreads();
+        }
+    }
     char* __restrict__ yb = static_cast<char*>(p.y) + (int64_t)n * p.y_bstride * sizeof(TOUT);
     const bool elu = p.act == 1;
     const int act = p.act;
@@ -170,8 +197,11 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
             const int i = x - d + 2;                                                        // index of T(x - d); < 0: the whole right half is masked (x < d - 2)
             const unsigned vo = (live && i >= 0) ? (unsigned)i * 16u : kBufOOB;
 #pragma unroll
-            for (int q = 0; q < G / 4; q++)
-                tv[u][q] = (kFoldAbl & 1) ? f32x4{(float)d, 1.f, 2.f, (float)x} : buf_load4(rs_t, vo, (unsigned)((v * (p.K / 4) + kg * (G / 4) + q) * p.H + y) * trow);
+            for (int q = 0; q < G / 4; q++) {
+                if (kFoldAbl & 1) tv[u][q] = f32x4{(float)d, 1.f, 2.f, (float)x};
+                else if (!LASTCOL && t_in_lds && v == 1) tv[u][q] = t_lds[q * kTWin + (int)threadIdx.x + p.D - d];
+                else tv[u][q] = buf_load4(rs_t, vo, (unsigned)((v * (p.K / 4) + kg * (G / 4) + q) * p.H + y) * trow);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {

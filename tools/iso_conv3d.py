@@ -60,7 +60,7 @@ def time_layer(k, c, kk, d, h, w, batch, env, iters=10):
 
 
 FOLD_VARIANTS = [("fabl1", ["-DRT_FOLD_ABL=1"], "no T loads"), ("fabl2", ["-DRT_FOLD_ABL=2"], "no activation"), ("fabl4", ["-DRT_FOLD_ABL=4"], "no stores"),
-                 ("fabl3", ["-DRT_FOLD_ABL=3"], "no T loads, no activation")]
+                 ("fabl3", ["-DRT_FOLD_ABL=3"], "no T loads, no activation"), ("fnolds", ["-DRT_FOLD_T_LDS=0"], "T from memory (no LDS window)")]
 
 
 def time_fold(k, f, kk, d, h, w, batch, iters=10):
