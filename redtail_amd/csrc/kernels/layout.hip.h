@@ -38,6 +38,30 @@ permute4d_kernel(const T* __restrict__ x, T* __restrict__ y, int o0, int o1, int
     }
 }
 
+// ... and the permutations that leave the innermost dimension(s) in place -- the Transform plugin of the 3-D models swaps the two OUTER
+// dimensions, (K, D, H, W) <-> (D, K, H, W) (reference lib/transform_plugin.cpp:60-75, cudnnTransformTensor): contiguous runs of `inner`
+// elements move as they are.  The element-per-thread kernel above spends three 64-bit divisions per element (NVSmall's volume: 2.8 TB/s of
+// read + write); here a block decodes its run once and every thread moves kPermU elements with their loads in flight together.
+// grid.x = chunks * o0 * o1 * o2, grid.y = samples; T = the moved unit (float, _Float16, or 16 bytes when everything is aligned).
+constexpr int kPermU = 8;
+template <typename T>
+__global__ void __launch_bounds__(256)
+permute_runs_kernel(const T* __restrict__ x, T* __restrict__ y, int o1, int o2, int64_t s0, int64_t s1, int64_t s2, int64_t inner, int chunks,
+                    int64_t total) {
+    const int chunk = blockIdx.x % chunks, run = blockIdx.x / chunks;       // run = (i0 * o1 + i1) * o2 + i2 in OUTPUT order
+    const int i2 = run % o2, t = run / o2, i1 = t % o1, i0 = t / o1;
+    const T* __restrict__ src = x + (int64_t)blockIdx.y * total + i0 * s0 + i1 * s1 + i2 * s2;
+    T* __restrict__ dst = y + (int64_t)blockIdx.y * total + (int64_t)run * inner;
+    const int64_t i = (int64_t)chunk * (256 * kPermU) + threadIdx.x;
+    T v[kPermU];
+#pragma unroll
+    for (int u = 0; u < kPermU; u++)
+        if (i + 256 * u < inner) v[u] = src[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < kPermU; u++)
+        if (i + 256 * u < inner) dst[i + 256 * u] = v[u];
+}
+
 // Tensor format conversion at a plugin boundary -- what TensorRT inserts ("reformat" layers) between an fp32 tensor and
 // an IPluginExt that asked for kHALF in kNCHW or kNC2HW2 (reference tests_main.cpp:301-321, 988-1026): kinds
 // 0 = fp32 NCHW, 1 = fp16 NCHW, 2 = fp16 NC2HW2 (channel pairs (2i, 2i+1) of a pixel in one 4-byte slot, odd C zero padded).

@@ -389,12 +389,23 @@ extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out
                   : launch_corr<true, false>(l, r, o, batch, C, H, W, D, out_bstride, S(s));
 }
 
+namespace { int env_int(const char* name, int dflt); }      // (development knobs, defined with the convolution plans below)
+
 extern "C" int rt_cost_volume(const void* left, const void* right, void* cv, int batch, int C, int H, int W, int D,
                               int dtype, rtStream s) {
     RT_REQUIRE(left && right && cv, "rt_cost_volume: null pointer");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_cost_volume: bad dims");
     RT_REQUIRE(H <= 65535 && (int64_t)batch * C <= 65535, "rt_cost_volume: grid too large");
     if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_cost_volume: only fp32 (as the reference, kernels.cu:140)");
+    if (C % 4 == 0 && reinterpret_cast<uintptr_t>(cv) % 16 == 0 && (int64_t)H * W + 4 < 0x7fffffff && C <= 65535 && batch <= 65535 &&
+        env_int("RT_NO_CV_X4", 0) == 0) {
+        // 16-byte stores: four consecutive plane elements per thread, aligned in the output (cost_volume_f32x4_kernel)
+        dim3 g4((unsigned)rt::cdiv(rt::cdiv((int64_t)H * W + 3, 4), 256), (unsigned)C, (unsigned)batch);
+        hipLaunchKernelGGL(rt::cost_volume_f32x4_kernel, g4, dim3(256), 0, S(s), static_cast<const float*>(left),
+                           static_cast<const float*>(right), static_cast<float*>(cv), C, H, W, D);
+        RT_LAUNCH_CHECK("cost volume kernel");
+        return 0;
+    }
     dim3 grid((unsigned)rt::cdiv(W, 256), (unsigned)H, (unsigned)(batch * C));
     hipLaunchKernelGGL(rt::cost_volume_f32_kernel, grid, dim3(256), 0, S(s), static_cast<const float*>(left),
                        static_cast<const float*>(right), static_cast<float*>(cv), C, H, W, D);
@@ -444,6 +455,33 @@ extern "C" int rt_permute4d(const void* x, void* y, int batch, int d0, int d1, i
     const int64_t in_str[4] = {(int64_t)d1 * d2 * d3, (int64_t)d2 * d3, (int64_t)d3, 1};
     const int64_t total = in_str[0] * d0;
     const int o[4] = {in_dims[order[0]], in_dims[order[1]], in_dims[order[2]], in_dims[order[3]]};
+    if (order[3] == 3 && (dtype == RT_F32 || dtype == RT_F16)) {
+        // the innermost dimension (with order[2] == 2 the innermost two) stays in place: contiguous runs move as they are
+        const bool two = order[2] == 2;
+        int64_t inner = two ? (int64_t)d2 * d3 : d3;
+        const int o2 = two ? 1 : o[2];
+        int64_t s0 = in_str[order[0]], s1 = in_str[order[1]], s2 = two ? 0 : in_str[order[2]], tot = total;
+        const int64_t esz = dtype == RT_F32 ? 4 : 2;
+        const int64_t runs = (int64_t)o[0] * o[1] * o2;
+        // 16-byte units when every run starts on a 16-byte boundary in both tensors
+        const bool v16 = (inner * esz) % 16 == 0 && (total * esz) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0;
+        if (v16) { const int64_t f = 16 / esz; inner /= f; s0 /= f; s1 /= f; s2 /= f; tot /= f; }
+        const int64_t chunks = rt::cdiv(inner, 256 * rt::kPermU);
+        if (chunks * runs <= 0x7fffffff && chunks <= 0x7fffffff) {
+            dim3 g((unsigned)(chunks * runs), (unsigned)batch);
+            if (v16)
+                hipLaunchKernelGGL((rt::permute_runs_kernel<rt::f32x4>), g, dim3(256), 0, S(s), static_cast<const rt::f32x4*>(x), static_cast<rt::f32x4*>(y),
+                                   o[1], o2, s0, s1, s2, inner, (int)chunks, tot);
+            else if (dtype == RT_F32)
+                hipLaunchKernelGGL((rt::permute_runs_kernel<float>), g, dim3(256), 0, S(s), static_cast<const float*>(x), static_cast<float*>(y),
+                                   o[1], o2, s0, s1, s2, inner, (int)chunks, tot);
+            else
+                hipLaunchKernelGGL((rt::permute_runs_kernel<_Float16>), g, dim3(256), 0, S(s), static_cast<const _Float16*>(x), static_cast<_Float16*>(y),
+                                   o[1], o2, s0, s1, s2, inner, (int)chunks, tot);
+            RT_LAUNCH_CHECK("permute kernel");
+            return 0;
+        }
+    }
     const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(rt::cdiv(total, 256), 4096));
     dim3 grid(bx, (unsigned)batch);
     if (dtype == RT_F32)

@@ -173,6 +173,25 @@ def test_cost_volume_random(backend):
     near(backend.host(out), O.cost_volume(T(l), T(r), 7).numpy(), 0)
 
 
+@pytest.mark.parametrize("n,c,h,w,D", [(2, 4, 5, 33, 7),      # plane 165 = 1 (mod 4): every channel another alignment, ragged first / last groups
+                                       (1, 8, 3, 18, 24),     # more disparities than columns (x < d everywhere in the late slices), plane = 2 (mod 4)
+                                       (2, 12, 2, 64, 5),     # aligned planes
+                                       (1, 4, 1, 3, 2)])      # a plane smaller than one group of four
+def test_cost_volume_16_byte_stores(backend, monkeypatch, n, c, h, w, D):
+    """C a multiple of 4: cost_volume_f32x4_kernel (four plane elements per thread, stores aligned in the OUTPUT) -- against the oracle
+    (lib/kernels.cu:50-97 semantics) and, bit for bit, against the element-per-thread kernel (RT_NO_CV_X4=1)."""
+    l, r = rnd(n, c, h, w), rnd(n, c, h, w)
+    ref = O.cost_volume(T(l), T(r), D).numpy()
+    out = backend.empty(ref.shape)
+    backend.klib.cost_volume(backend.dev(l), backend.dev(r), out, n, c, h, w, D)
+    got = backend.host(out).copy()
+    near(got, ref, 0)
+    monkeypatch.setenv("RT_NO_CV_X4", "1")
+    out = backend.empty(ref.shape)
+    backend.klib.cost_volume(backend.dev(l), backend.dev(r), out, n, c, h, w, D)
+    assert np.array_equal(backend.host(out), got)
+
+
 # ---- soft-argmax (tests_main.cpp:1032-1099) ---------------------------------------------------------
 @pytest.mark.parametrize("idx,is_min,tol", [("01", True, 2e-6), ("02", True, 1e-5), ("03", False, 2e-6)])
 def test_softargmax_golden(backend, golden, idx, is_min, tol):
@@ -200,6 +219,15 @@ def test_permute_pad_slice_concat(backend):
     y = backend.empty((2, 6, 3, 5, 4))
     backend.klib.permute4d(backend.dev(x), y, 2, (3, 4, 5, 6), (3, 0, 2, 1))
     near(backend.host(y), np.transpose(x, (0, 4, 1, 3, 2)), 0)
+    # runs that stay in place (permute_runs_kernel): the innermost two dimensions / the innermost one; 16-byte units and ragged ones;
+    # a run longer than one block's share (256 * 8 elements)
+    for dims, order in [((3, 4, 5, 8), (1, 0, 2, 3)), ((3, 4, 5, 7), (1, 0, 2, 3)), ((3, 4, 5, 8), (2, 0, 1, 3)), ((4, 3, 5, 6), (2, 1, 0, 3)),
+                        ((2, 3, 37, 61), (1, 0, 2, 3)), ((2, 3, 48, 64), (1, 0, 2, 3))]:
+        xx = rnd(2, *dims)
+        want = np.ascontiguousarray(np.transpose(xx, (0,) + tuple(1 + o for o in order)))
+        yy = backend.empty(want.shape)
+        backend.klib.permute4d(backend.dev(xx), yy, 2, dims, order)
+        near(backend.host(yy), want, 0)
     y = backend.empty((2, 4, 4, 5, 6))
     backend.klib.pad_d(backend.dev(x), y, 2, 3, 4 * 5 * 6, 1)
     near(backend.host(y), O.pad_d(T(x), 1).numpy(), 0)
