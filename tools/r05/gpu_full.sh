@@ -11,6 +11,7 @@ import json
 for f in ("bench_plain", "bench_20_5"):
     d = json.load(open("$O/%s.json" % f)); r = d["roofline"]
     print(f, round(d["value"], 1), d["unit"], "frac", round(r["frac"], 4), r["bound"], "traffic", r.get("traffic"), "latency", d.get("latency_ms_per_pair"), "diff", d.get("contexts_max_abs_diff"))
-    for k, v in (d.get("secondary") or {}).items():
-        print("   ", k[:60], round(v.get("value", 0), 1) if isinstance(v, dict) and "value" in v else v.get("error", v) if isinstance(v, dict) else v)
+    for e in (d.get("secondary") or []):
+        r2 = e.get("roofline") or {}
+        print("   ", (e.get("config") or {}).get("workload", e.get("id", "?"))[:72], round(e["value"], 1) if "value" in e else e.get("error"), "frac", r2.get("frac"), "traffic", r2.get("traffic"))
 PY
