@@ -102,11 +102,28 @@ __device__ static __forceinline__ void buf_store(float v, buf_rsrc r, unsigned v
 #ifdef HIPEMU
 __device__ static __forceinline__ void wait_vmem() {}
 template <int N> __device__ static __forceinline__ void wait_vmem_but() {}
+static inline void sload2_i32(const void* base, int off0, int off1, int& a, int& b) {
+    a = *reinterpret_cast<const int*>(static_cast<const char*>(base) + off0);
+    b = *reinterpret_cast<const int*>(static_cast<const char*>(base) + off1);
+}
+static inline void sload2_i64(const void* base, int off0, int off1, long long& a, long long& b) {
+    a = *reinterpret_cast<const long long*>(static_cast<const char*>(base) + off0);
+    b = *reinterpret_cast<const long long*>(static_cast<const char*>(base) + off1);
+}
 __device__ static __forceinline__ void lds_barrier() { __syncthreads(); }
 __device__ static __forceinline__ unsigned pack_f16(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16);
 }
 #else
+// Two dwords / two qwords of a READ-ONLY table by scalar loads, whatever the compiler thinks of the surrounding code: inside a loop that
+// stores it will not use s_load on its own (it cannot prove the table unclobbered) and falls back to vector loads -- a vmcnt wait in the
+// middle of a counted LDS-DMA pipeline (deconv_f16pw_kernel).  base: wave-uniform pointer; byte offsets: uniform, multiples of 4 / 8.
+__device__ static __forceinline__ void sload2_i32(const void* base, int off0, int off1, int& a, int& b) {
+    asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(base), "s"(off0), "s"(off1) : "memory");
+}
+__device__ static __forceinline__ void sload2_i64(const void* base, int off0, int off1, long long& a, long long& b) {
+    asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(base), "s"(off0), "s"(off1) : "memory");
+}
 __device__ static __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N> __device__ static __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ static __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) deconv3d_s2_il_kernel(Deconv3dSmallArgs p
 // depth parity, the two parities are merged with one lane exchange at the end, and p.y receives the (1, Hx, Wx) map (plain pitch Wx,
 // p.y_bstride = Hx * Wx).  NVSmall 1025 x 321: 127 MB per pair less written and read again.
 template <int SA>
-__global__ void __launch_bounds__(256) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs p, int seg_len, int nseg) {
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv3d_s2_ilw_kernel(Deconv3dSmallArgs p, int seg_len, int nseg) {
     const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (An XCD-aware order of the workgroups -- each XCD a contiguous run of the logical grid, so that neighbouring row pairs share their

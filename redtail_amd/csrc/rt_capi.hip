@@ -620,7 +620,7 @@ struct rtConvPlan {
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
     int softarg = 0;              // rt_conv_plan_set_softarg: 1 / 2 = the launch ends in a soft-argmax / soft-argmin over the output depth
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2, opt_f16p_walk = -1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -2420,6 +2420,7 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
         plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
         plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
         plan->opt_fold_u = env_int("RT_FOLD_U", 2);           // factored cost-volume fold: depth slices per trip of the combining pass (MI355X, NVSmall b8: 1: 0.84, 2: 0.68, 4: 1.07 ms)
+        plan->opt_f16p_walk = env_int("RT_F16P_WALK", -1);        // transposed fp16 layers, four phases per workgroup: -1 walk down the class's depths (segments chosen), 0 one depth per workgroup, n > 0: n segments
         plan->opt_small_walk = env_int("RT_SMALL_IL_WALK", -1);   // last transposed layer on interleaved fp16 input: 0 = one depth block per workgroup
         plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
     });
@@ -2540,6 +2541,28 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
             RT_REQUIRE(batch <= 65535 && (int64_t)batch * sc.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
             dim3 g = a.z_inner ? dim3((unsigned)(tiles * sc.nz), (unsigned)nblk, (unsigned)batch) : dim3((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * sc.nz));
             if (plan->opt_trace) fprintf(stderr, "[rt] deconv_f16p grid %u x %u x %u\n", g.x, g.y, g.z);
+            if (plan->opt_f16p_walk != 0 && (!plan->has_resid || sc.r_il8)) {       // (a planar skip tensor -- not what the executor uses -- stays with the per-depth kernel)
+                // the walk (deconv_f16pw_kernel): a workgroup keeps its tile and takes a segment of the class's output depths.  Segments as
+                // long as the grid allows: cost = rounds over the chip's 3 workgroups per CU x (slices per segment + one slice's worth of
+                // fill and drain)
+                const int64_t slots = (int64_t)3 * device_cus(), base = (int64_t)tiles * nblk * batch;
+                int nseg = 1;
+                double best = 1e30;
+                for (int ns = 1; ns <= sc.nz; ns++) {
+                    const int seg = (int)rt::cdiv(sc.nz, ns);
+                    if ((int)rt::cdiv(sc.nz, seg) != ns) continue;
+                    const double cost = (double)rt::cdiv(base * ns, slots) * (seg + 1.0);
+                    if (cost < best - 1e-9) { best = cost; nseg = ns; }
+                }
+                if (plan->opt_f16p_walk > 0) nseg = std::min(plan->opt_f16p_walk, sc.nz);          // (RT_F16P_WALK=<n>: n segments)
+                a.dw_seg = (int)rt::cdiv(sc.nz, nseg); a.dw_nseg = sc.nz; a.nz = (int)rt::cdiv(sc.nz, a.dw_seg);
+                RT_REQUIRE((int64_t)batch * a.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
+                dim3 gw = a.z_inner ? dim3((unsigned)(tiles * a.nz), (unsigned)nblk, (unsigned)batch) : dim3((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * a.nz));
+                if (plan->opt_trace) fprintf(stderr, "[rt] deconv_f16pw grid %u x %u x %u, %d slices per segment\n", gw.x, gw.y, gw.z, a.dw_seg);
+                hipLaunchKernelGGL(rt::deconv_f16pw_kernel, gw, dim3(256), 0, S(s), a);
+                RT_LAUNCH_CHECK("deconv_f16pw_kernel");
+                continue;
+            }
             hipLaunchKernelGGL(rt::deconv_f16p_kernel, g, dim3(256), 0, S(s), a);
             RT_LAUNCH_CHECK("deconv_f16p_kernel");
             continue;

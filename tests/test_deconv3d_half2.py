@@ -159,6 +159,58 @@ def test_conv3d_writes_channel_major_interleaved(backend, c, k, d, h, w, stride)
     plan.destroy()
 
 
+WALK_CASES = [
+    # K, C, (Dy, Hy, Wy), out depth computed (full), kept, pad_d, skip, cdhw, segments
+    (16, 8, (3, 4, 19), 7, 6, 0, True, True, 0),        # NVSmall's decoder pattern; segments chosen by the plan
+    (32, 32, (5, 6, 33), 11, 10, 0, True, True, 2),     # five slices per class in two segments (3 + 2), two column tiles, two row tiles
+    (32, 64, (4, 5, 35), 9, 8, 0, True, False, 1),      # two blocks of 32 output channels, one segment, a ragged column tile, no Transform
+    (24, 40, (2, 3, 17), 3, 3, 1, False, True, 3),      # no skip tensor, ragged channel counts, more segments asked for than slices
+    (48, 16, (6, 9, 40), 13, 12, 0, True, True, 4),     # three chunks per slice (even class), six (odd): the ring position at a slice's end varies
+]
+
+
+@pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw,nseg", WALK_CASES)
+def test_conv3d_transpose_f16_walks_down_the_depths(backend, monkeypatch, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw, nseg):
+    """deconv_f16pw_kernel: a workgroup keeps its tile of the input plane and walks a segment of its class's output depths (chunks by LDS-DMA
+    two ahead, the next slice's loads under the epilogue) -- against the oracle, and bit for bit against deconv_f16p_kernel (one workgroup per
+    tile and depth; RT_F16P_WALK=0), whatever the segmentation (RT_F16P_WALK=<n>)."""
+    n = 2
+    dy, hy, wy = ydims
+    hx, wx = 2 * hy - 1, 2 * wy - 1
+    y = q16(rnd(n, K, dy, hy, wy))
+    w = q16(rnd(K, 3, C, 3, 3) * np.float32(1 / np.sqrt(27 * K / 8)))
+    b = q16(rnd(C))
+    sk = q16(rnd(n, dkeep, C, hx, wx)) if skip else None
+    ps = (pad_d, 1, 1)
+    ref = O.conv3d_transpose_tf(T(y).double(), T(w).double(), T(b).double(), (dfull, C, hx, wx), (2, 2, 2), ps, ps)[:, :dkeep]
+    if skip:
+        ref = ref + T(sk).double()
+    ref = O.elu(ref)
+    if cdhw:
+        ref = O.transform(ref)
+    ref = ref.numpy()
+    tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
+    oshape = (n, C // 8, dkeep, hx, wx, 8) if cdhw else (n, dkeep, C // 8, hx, wx, 8)
+
+    def run(walk):
+        monkeypatch.setenv("RT_F16P_WALK", walk)
+        p = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
+                                     has_residual=skip, dtype=capi.RT_F16, transposed_in_dims=ydims, out_depth=dkeep)
+        p.set_io_types(capi.RT_F16, capi.RT_F16)
+        p.set_layouts(1, 1, 1 if skip else 0)
+        out = empty(backend, oshape, True)
+        p.enqueue(dev16(backend, il_cm(y)), out, dev16(backend, il_dm(sk)) if skip else None, n)
+        res = host(backend, out)
+        p.destroy()
+        return res
+    per_depth = run("0")
+    walk = run(str(nseg) if nseg else "-1")
+    assert not np.isnan(walk).any()
+    got = un_il_cm(walk) if cdhw else un_il_dm(walk)
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    assert np.array_equal(walk, per_depth)
+
+
 SMALL_CASES = [
     # K, C, (Dy, Hy, Wy), out depth computed, kept, pad_d, act
     (32, 1, (3, 4, 19), 7, 6, 0, capi.RT_ACT_NONE),        # NVSmall / ResNet-18 3D: 32 channels -> 1, depth pad 0, the surplus slice dropped
