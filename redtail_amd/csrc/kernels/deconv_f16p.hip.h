@@ -257,8 +257,12 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16p_kernel(Con
 //     left to the compiler they are VECTOR loads behind a vmcnt(0) inside a loop that stores (and a buffer resource built from them gets a
 //     waterfall loop); kept in LDS, every read of them gets a compiler-made vmcnt(0) too, because an LDS-DMA is in flight somewhere.  The
 //     bias stays in registers for the same reason.
-// Same chunk and tap order per accumulator: bit-identical to the kernel above.  p.nz = depth segments, p.dw_seg = slices per segment,
-// p.dw_nseg = slices of the class (p.zs has that many entries).  Skip tensor: interleaved or none (a planar one: the kernel above).
+//   * BOTH classes in one launch: the even output depth 2 m reads input slice m, the odd one 2 m + 1 input slices m and m + 1; as two launches
+//     the input travels from HBM three times (440 MB fetched per pair for NVSmall's deconv3D_2 against 318 MB of input + skip tensor); a walk
+//     that takes slice m of the even class and then slice m of the odd class finds the second and third reading in the L2.
+// Same chunk and tap order per accumulator: bit-identical to the kernel above.  p.nz = depth segments, p.dw_seg = slice indices per
+// segment, p.dw_nseg = slice indices in all (the longer class), p.dw_cpc = slices of class A (p.zs), b = class B.  Skip tensor: interleaved
+// or none (a planar one: the kernel above).
 struct DeconvF16PWCfg {
     static constexpr int TY = 4, TX = 32, CC = 16;
     static constexpr int PR = TY + 1, PC = TX + 1, GSLOTS = PR * PC;   // 5 x 33 patch pixels per channel group
@@ -267,7 +271,15 @@ struct DeconvF16PWCfg {
     static constexpr int BUF = 2 * GREG + W_SLOTS + 64;                // + the idle piece: 1024 slots = 16 KB
 };
 
-__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(ConvArgs p) {
+// the launch's second class of output depths (the odd ones beside the even ones): its own weights, slices and gather table; zs == nullptr: none
+struct DeconvWalkB {
+    const float* w;
+    const ZSlice* zs;
+    const int* ch_off;
+    int CinPad, nz;
+};
+
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(ConvArgs p, DeconvWalkB b) {
     using Cfg = DeconvF16PWCfg;
     constexpr unsigned ES = 2;
     constexpr int PC = Cfg::PC, GREG = Cfg::GREG, BUF = Cfg::BUF;
@@ -282,9 +294,12 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
     const int ty0 = (tile / p.tiles_x) * Cfg::TY;
     const int nblk = blockIdx.y;
     const char* __restrict__ xb = elem_ptr(p.x, (int64_t)n * p.x_bstride, ES);
-    const int nchunks = p.CinPad / Cfg::CC;
+    // class A = p (p.dw_cpc slices), class B = b (b.nz slices, or none): the walk takes slice m of A, then slice m of B, for m in its segment
+    const int nchA = p.CinPad / Cfg::CC, nchB = b.zs ? b.CinPad / Cfg::CC : 0;
+    const int nzA = p.dw_cpc, nzB = b.zs ? b.nz : 0;
     const int z0 = seg * p.dw_seg, z1 = z0 + p.dw_seg < p.dw_nseg ? z0 + p.dw_seg : p.dw_nseg;
-    const int nq = (z1 - z0) * nchunks;
+    auto clampn = [&](int nz) { const int v = nz - z0; return v < 0 ? 0 : (v > z1 - z0 ? z1 - z0 : v); };
+    const int nq = clampn(nzA) * nchA + clampn(nzB) * nchB;
     const bool has_r = p.resid != nullptr;
 
     // ---- LDS-DMA duties.  Patch piece k of a group covers patch slots 64 k .. 64 k + 63 (slot = row * 33 + column; beyond 165 and outside
@@ -297,16 +312,21 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
         const int iy = ty0 + pr, ix = tx0 + pc;
         pvoff[k] = (s < Cfg::GSLOTS && iy < p.Hi && ix < p.Wi) ? (unsigned)(iy * p.x_pitch + ix) * 16u : kBufOOB;
     }
-    const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.w) + ((int64_t)nblk * nchunks) * Cfg::W_SLOTS * 16;
-    const buf_rsrc rs_w = make_buf(wsrc);
+    const buf_rsrc rs_wA = make_buf(reinterpret_cast<const char*>(p.w) + ((int64_t)nblk * nchA) * Cfg::W_SLOTS * 16);
+    const buf_rsrc rs_wB = make_buf(reinterpret_cast<const char*>(b.w) + ((int64_t)nblk * nchB) * Cfg::W_SLOTS * 16, b.zs != nullptr);
     const unsigned wlane = (unsigned)lane * 16u;
-    int iq_z = z0, iq_c = 0;                                           // the next chunk to request: slice, chunk of its slice
+    int iq_m = z0, iq_cls = z0 < nzA ? 0 : 1, iq_c = 0;                // the next chunk to request: slice index, class, chunk of its slice
     const int* tabq;                                                   // ... and its slice's row of the gather table
-    {
+    auto load_row = [&]() __attribute__((always_inline)) {
         int row, unused;
-        sload2_i32(p.zs, iq_z * (int)sizeof(ZSlice) + (int)offsetof(ZSlice, ch_row), iq_z * (int)sizeof(ZSlice) + (int)offsetof(ZSlice, ch_row), row, unused);
-        tabq = p.ch_off + (int64_t)row * p.CinPad;
-    }
+        const bool use_b = iq_cls != 0 && nzB > 0;                     // (past the walk's end the state names a slice that does not exist: any valid row)
+        const int nzc = use_b ? nzB : nzA;
+        const int zm = iq_m < nzc ? iq_m : nzc - 1;
+        const int zo = zm * (int)sizeof(ZSlice) + (int)offsetof(ZSlice, ch_row);
+        sload2_i32(use_b ? b.zs : p.zs, zo, zo, row, unused);
+        tabq = (use_b ? b.ch_off : p.ch_off) + (int64_t)row * (use_b ? b.CinPad : p.CinPad);
+    };
+    load_row();
     auto dma = [&](buf_rsrc rs, f32x4* dst, unsigned voff, unsigned soff) __attribute__((always_inline)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, RT_LDS_PTR(dst), 16, voff, soff, 0, 0);
     };
@@ -318,6 +338,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
         const unsigned s0 = (unsigned)o0 * ES, s1 = (unsigned)o1 * ES;
         f32x4* const g1 = g0 + GREG;
         f32x4* const sw = g0 + 2 * GREG;
+        const buf_rsrc rs_w = iq_cls ? rs_wB : rs_wA;
         const unsigned wso = (unsigned)iq_c * (unsigned)(Cfg::W_SLOTS * 16);
         if (wv == 0) {
             dma(r0, g0, pvoff[0], s0); dma(r0, g0 + 64, pvoff[1], s0); dma(r0, g0 + 128, pvoff[2], s0);
@@ -333,14 +354,20 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
             for (int j = 6; j < 9; j++) dma(rs_w, sw + 64 * j, wlane + 1024u * j, wso);
             dma(rs_w, sw + 64 * 9, kBufOOB, 0u);                      // the idle piece (zeros into the buffer's padding): four operations per wave and chunk
         }
-        if (++iq_c == nchunks) {
-            iq_c = 0;
-            if (++iq_z < z1) {
-                int row, unused;
-                sload2_i32(p.zs, iq_z * (int)sizeof(ZSlice) + (int)offsetof(ZSlice, ch_row), iq_z * (int)sizeof(ZSlice) + (int)offsetof(ZSlice, ch_row), row, unused);
-                tabq = p.ch_off + (int64_t)row * p.CinPad;
-            }
-        }
+        // next chunk; at a slice's end slice m of class B follows slice m of class A, then slice m + 1.  Branch-free scalar arithmetic: as
+        // nested control flow the compiler carried the class through a VECTOR register -- one that a DMA in flight still named as its
+        // address -- and put a vmcnt(0) in front of the write (ISA of the first two-class version)
+        // (0 / 1 from sign bits, not from comparisons: a boolean widened to an integer goes through v_cndmask + v_readfirstlane)
+        iq_c++;
+        const int nch = nchA + iq_cls * (nchB - nchA);
+        const int endc = (int)((unsigned)(nch - 1 - iq_c) >> 31);      // iq_c >= nch
+        const int to_b = endc & (iq_cls ^ 1) & (int)((unsigned)(iq_m - nzB) >> 31);      // class A just ended and slice m of class B exists
+        const int adv = endc & (to_b ^ 1);
+        iq_c -= endc * iq_c;
+        iq_m += adv;
+        const int ge_a = (int)((unsigned)(nzA - 1 - iq_m) >> 31);      // iq_m >= nzA: only class B has this slice
+        iq_cls = to_b + (to_b ^ 1) * (adv * ge_a + (adv ^ 1) * iq_cls);
+        if (endc) load_row();                                          // (past the segment's end: a row that is never used)
     };
 
     // ---- output addressing: as in deconv_f16p_kernel (one v_permlane32_swap per dword turns the two half-waves' 8-byte pieces into whole
@@ -377,7 +404,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
     issue(ring0);
     if (nq > 1) issue(ring1);
 
-    int q = 0, ch = 0, sl = 0;                                         // chunk of the walk, chunk of its slice, slice of the segment
+    int q = 0, ch = 0, cm = z0, ccls = z0 < nzA ? 0 : 1;               // chunk of the walk, chunk of its slice, the slice being computed: index, class
     bool fresh = false;                                                // everything requested before this point has landed (set by an epilogue)
     // one chunk of the pipeline at ring position R: wait for my pieces, barrier, request the chunk two ahead, MFMAs; the last chunk of a slice
     // requests the skip tensor before its MFMAs and ends in the slice's epilogue
@@ -391,13 +418,13 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
         fresh = false;
         lds_barrier();
         if (q + 2 < nq) issue(wr);
-        const bool last = ch == nchunks - 1;                           // uniform
+        const bool last = ch == (ccls ? nchB : nchA) - 1;              // uniform
         u32x4_t skip[2][4];                                            // interleaved skip tensor: [py][q] = the slot's 8 channels; lands under the MFMAs
         int64_t ybase = 0;
         if (last) {
             long long yo, ro;
-            const int zb = (z0 + sl) * (int)sizeof(ZSlice);
-            sload2_i64(p.zs, zb + (int)offsetof(ZSlice, y_off_il8), zb + (int)offsetof(ZSlice, r_off_il8), yo, ro);
+            const int zb = cm * (int)sizeof(ZSlice);
+            sload2_i64(ccls ? b.zs : p.zs, zb + (int)offsetof(ZSlice, y_off_il8), zb + (int)offsetof(ZSlice, r_off_il8), yo, ro);
             ybase = (int64_t)n * p.y_bstride + yo;
             const int64_t rbase = (int64_t)n * p.r_bstride + ro;
 #pragma unroll
@@ -440,7 +467,9 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
         }
         q++;
         if (!last) { ch++; return; }
-        ch = 0; sl++;
+        ch = 0;
+        if (ccls == 0 && cm < nzB) ccls = 1;
+        else { cm++; ccls = cm < nzA ? 0 : 1; }
         // ---- epilogue of the slice.  Everything requested so far (the skip tensor, the pieces of the next two chunks) is waited for before
         // the first store: stores count on vmcnt too and may complete out of order with loads -- no counted wait can tell them apart.
         wait_vmem();

@@ -620,7 +620,7 @@ struct rtConvPlan {
     // whole environment, and five look-ups per launch were a third of the host's time per launch
     mutable std::once_flag env_once;   // the launch-time knobs below are read once per plan, by whichever context launches it first
     int softarg = 0;              // rt_conv_plan_set_softarg: 1 / 2 = the launch ends in a soft-argmax / soft-argmin over the output depth
-    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2, opt_f16p_walk = -1;
+    mutable int opt_xcd = 1, opt_trace = 0, opt_rb_tiles = 0, opt_rbs_seg = 0, opt_s3p_grid = 0, opt_ksplit = -1, opt_r4 = -1, opt_zinner = 1, opt_nbinner = 1, opt_dw = -1, opt_dw_nseg = 0, opt_small_walk = -1, opt_fold_u = 2, opt_f16p_walk = -1, opt_f16p_classes = 1;
     float* bias_dev = nullptr;
     float* zeros_dev = nullptr;
     int act = 0, has_resid = 0, dtype = RT_F32;
@@ -2420,12 +2420,15 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
         plan->opt_dw = env_int("RT_F16_DW", -1);         // -1: where it applies (3x3x3 stride-1 Conv3D between interleaved fp16 tensors), 0: never
         plan->opt_dw_nseg = env_int("RT_DW_NSEG", 0);   // depth segments per tile pair (0: chosen from the grid)
         plan->opt_fold_u = env_int("RT_FOLD_U", 2);           // factored cost-volume fold: depth slices per trip of the combining pass (MI355X, NVSmall b8: 1: 0.84, 2: 0.68, 4: 1.07 ms)
+        plan->opt_f16p_classes = env_int("RT_F16P_CLASSES", 1);   // ... 1: both depth classes (even / odd output depths) in one walk, 0: a launch per class
         plan->opt_f16p_walk = env_int("RT_F16P_WALK", -1);        // transposed fp16 layers, four phases per workgroup: -1 walk down the class's depths (segments chosen), 0 one depth per workgroup, n > 0: n segments
         plan->opt_small_walk = env_int("RT_SMALL_IL_WALK", -1);   // last transposed layer on interleaved fp16 input: 0 = one depth block per workgroup
         plan->opt_r4 = env_int("RT_F16_R4", -1);         // -1: where it pays (3-D plans), 0: never, 1: every 3x3 stride-1 fp16 launch on interleaved tensors
     });
     if (fold_factor_active(plan)) return enqueue_fold_factor(plan, x, y, batch, workspace, workspace_bytes, s, hints);
+    bool skip_sub = false;               // the previous sub-plan's launch covered this one too (two depth classes of a transposed layer in one walk)
     for (const SubConv& sc : plan->subs) {
+        if (skip_sub) { skip_sub = false; continue; }
         if (sc.small3d) {
             rt::Deconv3dSmallArgs a = sc.s3;
             a.x = static_cast<const float*>(x); a.y = static_cast<float*>(y); a.w = sc.w_dev; a.bias = plan->bias_dev;
@@ -2545,21 +2548,36 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                 // the walk (deconv_f16pw_kernel): a workgroup keeps its tile and takes a segment of the class's output depths.  Segments as
                 // long as the grid allows: cost = rounds over the chip's 3 workgroups per CU x (slices per segment + one slice's worth of
                 // fill and drain)
+                // Both depth classes in ONE walk (slice m of the even class, then slice m of the odd one: their input slices are the same and
+                // the next): the second sub-plan rides along when it is the same launch in everything but weights, slices and gather table
+                rt::DeconvWalkB wb{};
+                const SubConv* sb = (&sc == &plan->subs[0] && plan->subs.size() == 2) ? &plan->subs[1] : nullptr;
+                if (sb && plan->opt_f16p_classes != 0 && sb->dp4 && sb->f16mma && sb->x_il8 && sb->y_il8 && sb->x_f16 && sb->y_f16 && sb->r_il8 == sc.r_il8 &&
+                    sb->Hi == sc.Hi && sb->Wi == sc.Wi && sb->Ho == sc.Ho && sb->Wo == sc.Wo && sb->Cout == sc.Cout && sb->x_pitch == sc.x_pitch &&
+                    sb->y_cstride == sc.y_cstride && sb->y_ystride == sc.y_ystride && sb->r_cstride == sc.r_cstride) {
+                    wb.w = static_cast<const float*>(sb->w_dev); wb.zs = sb->zs_dev; wb.ch_off = sb->choff_dev; wb.CinPad = sb->CinPad; wb.nz = sb->nz;
+                    skip_sub = true;
+                }
+                const int nzw = std::max(sc.nz, wb.zs ? wb.nz : 0);                             // slice indices of the walk
+                const double per_m = wb.zs ? (double)(sc.CinPad + wb.CinPad) / sc.CinPad : 1.0; // work per slice index, in slices of this class
                 const int64_t slots = (int64_t)3 * device_cus(), base = (int64_t)tiles * nblk * batch;
+                // (among segmentations within 5 % of the cheapest, the one with the most segments: rounds of long walks do not stay in step and
+                //  their tail is a whole walk long -- NVSmall deconv3D_2 at batch 8: 1 segment 1.31 ms, 4 segments 1.26, both "cost" 146-152)
                 int nseg = 1;
                 double best = 1e30;
-                for (int ns = 1; ns <= sc.nz; ns++) {
-                    const int seg = (int)rt::cdiv(sc.nz, ns);
-                    if ((int)rt::cdiv(sc.nz, seg) != ns) continue;
-                    const double cost = (double)rt::cdiv(base * ns, slots) * (seg + 1.0);
-                    if (cost < best - 1e-9) { best = cost; nseg = ns; }
-                }
-                if (plan->opt_f16p_walk > 0) nseg = std::min(plan->opt_f16p_walk, sc.nz);          // (RT_F16P_WALK=<n>: n segments)
-                a.dw_seg = (int)rt::cdiv(sc.nz, nseg); a.dw_nseg = sc.nz; a.nz = (int)rt::cdiv(sc.nz, a.dw_seg);
+                auto seg_cost = [&](int ns) {
+                    const int seg = (int)rt::cdiv(nzw, ns);
+                    return (int)rt::cdiv(nzw, seg) != ns ? 1e30 : (double)rt::cdiv(base * ns, slots) * (seg * per_m + 1.0);
+                };
+                for (int ns = 1; ns <= nzw; ns++) best = std::min(best, seg_cost(ns));
+                for (int ns = 1; ns <= nzw; ns++)
+                    if (seg_cost(ns) <= 1.05 * best) nseg = ns;
+                if (plan->opt_f16p_walk > 0) nseg = std::min(plan->opt_f16p_walk, nzw);            // (RT_F16P_WALK=<n>: n segments)
+                a.dw_seg = (int)rt::cdiv(nzw, nseg); a.dw_nseg = nzw; a.dw_cpc = sc.nz; a.nz = (int)rt::cdiv(nzw, a.dw_seg);
                 RT_REQUIRE((int64_t)batch * a.nz <= 65535, "rt_conv_enqueue: grid limit exceeded");
                 dim3 gw = a.z_inner ? dim3((unsigned)(tiles * a.nz), (unsigned)nblk, (unsigned)batch) : dim3((unsigned)tiles, (unsigned)nblk, (unsigned)(batch * a.nz));
-                if (plan->opt_trace) fprintf(stderr, "[rt] deconv_f16pw grid %u x %u x %u, %d slices per segment\n", gw.x, gw.y, gw.z, a.dw_seg);
-                hipLaunchKernelGGL(rt::deconv_f16pw_kernel, gw, dim3(256), 0, S(s), a);
+                if (plan->opt_trace) fprintf(stderr, "[rt] deconv_f16pw grid %u x %u x %u, %d slice indices per segment, %d class(es)\n", gw.x, gw.y, gw.z, a.dw_seg, wb.zs ? 2 : 1);
+                hipLaunchKernelGGL(rt::deconv_f16pw_kernel, gw, dim3(256), 0, S(s), a, wb);
                 RT_LAUNCH_CHECK("deconv_f16pw_kernel");
                 continue;
             }

@@ -172,8 +172,8 @@ WALK_CASES = [
 @pytest.mark.parametrize("K,C,ydims,dfull,dkeep,pad_d,skip,cdhw,nseg", WALK_CASES)
 def test_conv3d_transpose_f16_walks_down_the_depths(backend, monkeypatch, K, C, ydims, dfull, dkeep, pad_d, skip, cdhw, nseg):
     """deconv_f16pw_kernel: a workgroup keeps its tile of the input plane and walks a segment of its class's output depths (chunks by LDS-DMA
-    two ahead, the next slice's loads under the epilogue) -- against the oracle, and bit for bit against deconv_f16p_kernel (one workgroup per
-    tile and depth; RT_F16P_WALK=0), whatever the segmentation (RT_F16P_WALK=<n>)."""
+    two ahead, the next slice's loads under the epilogue), both classes in one launch or one each -- against the oracle, and bit for bit against
+    deconv_f16p_kernel (one workgroup per tile and depth; RT_F16P_WALK=0), whatever the segmentation (RT_F16P_WALK=<n>)."""
     n = 2
     dy, hy, wy = ydims
     hx, wx = 2 * hy - 1, 2 * wy - 1
@@ -192,8 +192,9 @@ def test_conv3d_transpose_f16_walks_down_the_depths(backend, monkeypatch, K, C, 
     tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
     oshape = (n, C // 8, dkeep, hx, wx, 8) if cdhw else (n, dkeep, C // 8, hx, wx, 8)
 
-    def run(walk):
+    def run(walk, classes="1"):
         monkeypatch.setenv("RT_F16P_WALK", walk)
+        monkeypatch.setenv("RT_F16P_CLASSES", classes)
         p = backend.klib.conv3d_plan(h16(w), h16(b), C, K, (dfull, hx, wx), (3, 3, 3), (2, 2, 2), ps, ps, act=capi.RT_ACT_ELU, out_dchw=cdhw,
                                      has_residual=skip, dtype=capi.RT_F16, transposed_in_dims=ydims, out_depth=dkeep)
         p.set_io_types(capi.RT_F16, capi.RT_F16)
@@ -209,6 +210,9 @@ def test_conv3d_transpose_f16_walks_down_the_depths(backend, monkeypatch, K, C, 
     got = un_il_cm(walk) if cdhw else un_il_dm(walk)
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
     assert np.array_equal(walk, per_depth)
+    # (the default takes both depth classes -- even and odd output depths -- in one launch, slice m of the one, then slice m of the other;
+    #  RT_F16P_CLASSES=0: a launch per class)
+    assert np.array_equal(run(str(nseg) if nseg else "-1", "0"), per_depth)
 
 
 SMALL_CASES = [
