@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16R4_WAVES) conv_f16r
     const bool has_r = p.resid != nullptr;
     const int ox = tx0 + l31;
     const int act = p.act;
+    // (the activation as a compile-time constant of the epilogue: `apply_act_fast(x, act)` on a run-time `act` is a scalar branch tree per VALUE)
+    auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;                         // -1: whatever p.act says, per value
 #pragma unroll
     for (int y = 0; y < RPW; y++) {
         const int oy = ty0 + wv * RPW + y;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16R4_WAVES) conv_f16r
             u32x2_t o;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = apply_act_fast(acc[y][4 * q + e], act);
+            for (int e = 0; e < 4; e++) v[e] = apply_act_fast(acc[y][4 * q + e], ACT < 0 ? act : ACT);
 #pragma unroll
             for (int e = 0; e < 2; e++)
                 o[e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * e]) |
@@ -205,6 +208,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(RT_F16R4_WAVES) conv_f16r
             __builtin_amdgcn_raw_buffer_store_b64(o, rs, yvoff, (unsigned)(cs * cs32) * ES, 0);
         }
     }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 0) epilogue(std::integral_constant<int, 0>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 }  // namespace rt

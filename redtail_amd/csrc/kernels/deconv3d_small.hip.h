@@ -333,11 +333,19 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv3d_s2_ilw_kernel
             // depth enters as -inf (weight 0)
             const bool z_ok = oz < p.Dx;
             const float fzv = (float)oz;
+            // (one uniform branch per step: `apply_act_rt(x, p.act)` on the run-time activation is a scalar branch tree per VALUE -- 50 branches
+            //  per step in the ISA -- and the layer the reference's networks put here has no activation)
+            if (p.act != 0) {
+#pragma unroll
+                for (int row = 0; row < 2; row++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[row][j] = apply_act_rt(acc[row][j], p.act);
+            }
 #pragma unroll
             for (int row = 0; row < 2; row++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float v = apply_act_rt(acc[row][j], p.act) * (SA == 2 ? -kSaLog2e : kSaLog2e);
+                    const float v = acc[row][j] * (SA == 2 ? -kSaLog2e : kSaLog2e);
                     const float xv = z_ok ? v : -INFINITY;
                     const float mn = fmaxf(sa_m[row][j], xv);
                     const float c = __builtin_amdgcn_exp2f(sa_m[row][j] - mn), e = __builtin_amdgcn_exp2f(xv - mn);
@@ -363,8 +371,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv3d_s2_ilw_kernel
                         o[0] += r2[0] + r1;
                         o[1] += r2[1];
                     }
-                    o[0] = apply_act_rt(o[0], p.act);
-                    o[1] = apply_act_rt(o[1], p.act);
+                    if (p.act != 0) {
+                        o[0] = apply_act_rt(o[0], p.act);
+                        o[1] = apply_act_rt(o[1], p.act);
+                    }
                     buf_store2(o, rs_y, v2, 0);
                     buf_store(o[0], rs_y, v1, 0);
                 }

@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16p_kernel(Con
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------------
     auto h2f = [](unsigned u, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> (16 * hi))); };
+    // (the activation as a compile-time constant of the epilogue: on a run-time `act`, apply_act_fast is a scalar branch tree per VALUE)
+    auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;                         // -1: whatever p.act says, per value
 #pragma unroll
     for (int py = 0; py < 2; py++) {
         if (has_r && !r_il8) {                     // planar skip tensor (not what the executor uses): per-element loads at the lane's own pixels
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16p_kernel(Con
             for (int px = 0; px < 2; px++)
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const float x0 = apply_act_fast(v[px][2 * e], act), x1 = apply_act_fast(v[px][2 * e + 1], act);
+                    const float x0 = apply_act_fast(v[px][2 * e], ACT < 0 ? act : ACT), x1 = apply_act_fast(v[px][2 * e + 1], ACT < 0 ? act : ACT);
                     o[px][e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x0) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)x1) << 16);
                 }
             // inverse exchange: a = px0 pieces, b = px1 pieces -> lower half-wave: (a', b') = px0's (own ch 0-3, upper's ch 4-7) ...
@@ -236,6 +239,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16p_kernel(Con
             if (!(kDpAbl & 2) || slot[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(slot, rs, slot_off[py] + (unsigned)(cs * cs32) * ES, 0u, 0);
         }
     }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 0) epilogue(std::integral_constant<int, 0>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 
@@ -474,6 +481,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
         // the first store: stores count on vmcnt too and may complete out of order with loads -- no counted wait can tell them apart.
         wait_vmem();
         fresh = true;
+        // (the activation as a compile-time constant of the epilogue: `apply_act_fast(x, act)` on a run-time `act` is a scalar branch tree
+        //  PER VALUE -- 64 of them per lane and slice, 400 instructions per 8 outputs in the ISA of the first version)
+        auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;                     // -1: whatever p.act says, per value
 #pragma unroll
         for (int py = 0; py < 2; py++) {
 #pragma unroll
@@ -499,7 +510,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
                 for (int px = 0; px < 2; px++)
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
-                        const float x0 = apply_act_fast(v[px][2 * e], act), x1 = apply_act_fast(v[px][2 * e + 1], act);
+                        const float x0 = apply_act_fast(v[px][2 * e], ACT < 0 ? act : ACT), x1 = apply_act_fast(v[px][2 * e + 1], ACT < 0 ? act : ACT);
                         o[px][e] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x0) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)x1) << 16);
                     }
                 // inverse exchange: lanes 0-31 hold pixel 2 mx (ch 0-1, 4-5 in t0; 2-3, 6-7 in t1), lanes 32-63 pixel 2 mx + 1
@@ -510,6 +521,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(3) deconv_f16pw_kernel(Co
                 __builtin_amdgcn_raw_buffer_store_b128(slot, rs, slot_off[py] + (unsigned)(cs * cs32) * ES, 0u, 0);
             }
         }
+        };
+        if (act == 1) epilogue(std::integral_constant<int, 1>{});      // ELU: every layer of the reference's networks that reaches this kernel
+        else if (act == 0) epilogue(std::integral_constant<int, 0>{});
+        else epilogue(std::integral_constant<int, -1>{});
         init_acc();
     };
     for (;;) {

@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(Conv
     const buf_rsrc rs_y = make_buf(elem_ptr(p.y, ybase, 4));
     const buf_rsrc rs_r = make_buf(elem_ptr(p.resid, rbase, 4), has_r);
     const bool right_edge = tx0 + Cfg::TX >= p.Wi;                    // wave-uniform: the tile holds the last output column (odd width: no pair)
+    // (the activation as a compile-time constant of the epilogue: on a run-time `act`, apply_act_fast is a scalar branch tree per VALUE)
+    auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(actc)::value;                         // -1: whatever p.act says, per value
 #pragma unroll
     for (int py = 0; py < 2; py++) {
         const int oy = 2 * my + py, ox = 2 * mx;
@@ -203,8 +206,8 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(Conv
                 // (conv_s3_kernel's epilogue, operation for operation: main + cross, then + (bias + skip))
                 const float v0 = fmaf(acc_c[2 * py][4 * q + e], kSplitInv, acc_m[2 * py][4 * q + e]);
                 const float v1 = fmaf(acc_c[2 * py + 1][4 * q + e], kSplitInv, acc_m[2 * py + 1][4 * q + e]);
-                o0[e] = apply_act_fast(v0 + (bv[e] + sk[0][q][e]), act);
-                o1[e] = apply_act_fast(v1 + (bv[e] + sk[1][q][e]), act);
+                o0[e] = apply_act_fast(v0 + (bv[e] + sk[0][q][e]), ACT < 0 ? act : ACT);
+                o1[e] = apply_act_fast(v1 + (bv[e] + sk[1][q][e]), ACT < 0 ? act : ACT);
             }
             if constexpr (YIL) {
                 // the lane's 4 channels are one 16-byte slot of each of its two pixels
@@ -226,6 +229,10 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(2) deconv_s3p_kernel(Conv
             }
         }
     }
+    };
+    if (act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (act == 0) epilogue(std::integral_constant<int, 0>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 }  // namespace rt
