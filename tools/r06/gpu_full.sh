@@ -1,7 +1,7 @@
 #!/bin/bash
 # What the driver runs at round end, on the builder's box: the GPU test tier (with the skip reasons), smoke(), the default bench line and the driver's command
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/${1:-r05_full}; mkdir -p $O
+O=gpurun_out/${1:-r06_full}; mkdir -p $O
 timeout 3000 python -m pytest tests/ -x -q -m gpu -rs > $O/pytest.log 2>&1; tail -n 50 $O/pytest.log | grep -v "^$" | tail -n 45
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -n 2 $O/smoke.log
 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err; tail -n 2 $O/bench_plain.err
