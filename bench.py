@@ -209,6 +209,12 @@ def isolated_dominant(k, b, half2, launches=50, fused=False, hints=0):
         plan.set_layouts(1, 1, 1)
     dt = torch.float16 if half2 else torch.float32
     x = torch.randn(b, 32, HALF_H, 640, device="cuda").to(dt)
+    if fused and not half2 and plan.supports_split():
+        # the typical tower block reads and writes PRE-SPLIT tensors (rt_resblock_plan_set_split): (C/8, H, pitch, [8 hi | 8 lo]) fp16 pairs
+        plan.set_split(1, 1)
+        g = x.reshape(b, 4, 8, HALF_H, 640).permute(0, 1, 3, 4, 2)
+        hi = g.half()
+        x = torch.cat([hi, ((g - hi.float()) * 2048.0).half()], dim=-1).contiguous().view(torch.float32)
     r, y = (x if fused else torch.randn_like(x)), torch.empty_like(x)
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     k.lib.rt_event_create(ctypes.byref(e0)); k.lib.rt_event_create(ctypes.byref(e1))

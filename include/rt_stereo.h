@@ -195,6 +195,16 @@ int rt_deconv2d_plan_create(rtConvPlan** plan, const rtConv2dDesc* desc, const v
 int rt_resblock_plan_create(rtConvPlan** plan, const rtConv2dDesc* d1, const void* w1, const void* b1,
                             const rtConv2dDesc* d2, const void* w2, const void* b2);
 
+/* Pre-split tensors between the blocks of a feature tower (not in the reference: TensorRT owns its internal formats): per sample
+ * (C/8, H, pitch, [8 x fp16 hi | 8 x fp16 lo]) with x = hi + lo * 2^-11 -- the operands of the split-fp16 matrix instructions as stored
+ * values, 4 bytes per element like the fp32 tensor it replaces (same pitch, same sample stride).  A block that READS one fills its LDS by
+ * direct global -> LDS loads; a block that WRITES one splits its results in the epilogue.  Only the tower block takes them (32 -> 32 -> 32
+ * channels, ELU after both convolutions of resblockN, reference resnet18_2D_513x257_net.cpp:66-575, on channel-interleaved fp32 tensors:
+ * rt_conv_plan_set_layouts(plan, 1, 1, 1) first); rt_resblock_plan_supports_split says whether this plan does.  The skip connection of a
+ * block with x_split is taken from the split tensor (22 bits). */
+int rt_resblock_plan_supports_split(const rtConvPlan* plan);
+int rt_resblock_plan_set_split(rtConvPlan* plan, int x_split, int y_split);
+
 /* Row pitch (in elements, >= the row length; 0 = dense) of the input and of the output/residual planes of a 2-D
  * plan.  Not in the reference (TensorRT owns its internal layouts): lets the executor keep internal activations
  * 128-byte aligned per row.  Tensors are then (N, C, H, pitch) in memory with W valid columns. */

@@ -99,6 +99,8 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rt_conv_plan_set_softarg": (c_int, [c_void_p, c_int]),
+    "rt_resblock_plan_supports_split": (c_int, [c_void_p]),
+    "rt_resblock_plan_set_split": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_conv_enqueue_hint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "rt_conv_plan_workspace_bytes": (ctypes.c_size_t, [c_void_p, c_int]),
@@ -306,6 +308,13 @@ class ConvPlan:
     def set_layouts(self, x_il8, y_il8, r_il8=False):
         """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
         self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")
+
+    def supports_split(self):
+        return bool(self.klib.lib.rt_resblock_plan_supports_split(self.handle))
+
+    def set_split(self, x_split, y_split):
+        """pre-split tensors (C/8, H, pitch, [8 hi | 8 lo]) as input / output of a tower block"""
+        self.klib.check(self.klib.lib.rt_resblock_plan_set_split(self.handle, int(x_split), int(y_split)), "rt_resblock_plan_set_split")
 
     def set_softarg(self, mode):
         """end the launch in the soft-argmax (1) / soft-argmin (2) over the output depth (last Conv3DTranspose of a 3-D model): y becomes the

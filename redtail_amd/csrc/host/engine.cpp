@@ -69,6 +69,7 @@ struct TensorImpl : public ITensor {
     int pitch = 0;              // row pitch in elements of an internal (C,H,W) tensor, 0 = dense
     bool f16 = false;           // stored as fp16 (half2 mode); only tensors that only layout-aware launches touch
     bool il8 = false;           // channel-interleaved, (C/8, H, pitch, 8) in fp16, (C/4, H, pitch, 4) in fp32: only layout-aware launches touch it
+    bool split = false;         // fp32 il8 tensor stored PRE-SPLIT, (C/8, H, pitch, [8 x fp16 hi | 8 x fp16 lo]): between two tower blocks (fuseResBlocks)
     int cpad = 0;               // channels ALLOCATED per sample when > dims.d[0]: an interleaved tensor that hosts a folded concatenation
                                 // (its own channels, then the other members' groups); the sample stride of everything that touches it
     // siamese towers (mergeSiamese): this right-tower tensor lives in the second half of its left-tower twin's buffer -- `batch`
@@ -1142,6 +1143,41 @@ void EngineImpl::fuseResBlocks() {
     if (fused)
         log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(fused) + " residual blocks fused into one launch each; " +
                                             std::to_string(ops_.size()) + " launches").c_str());
+    // Tensors that only travel from one tower block to the next are stored PRE-SPLIT (rt_resblock_plan_set_split, conv_rbd.hip.h): the
+    // producing block writes the fp16 hi / lo operand pairs its successor's matrix instructions consume, the successor fills its LDS by
+    // direct global -> LDS loads.  Such a tensor has exactly one reader -- a tower block that takes it as input and skip connection -- and
+    // is no binding; the first block of a tower (fp32 input) and the last one (fp32 output) stay at the edges.  RT_NO_RBD=1: none.
+    if (!fused || knob("RT_NO_RBD")) return;
+    auto tower = [&](const Op& op) { return op.kind == OpKind::kConv && op.plan && rt_resblock_plan_supports_split(op.plan) != 0; };
+    int nsplit = 0;
+    for (size_t ia = 0; ia < ops_.size(); ia++) {
+        const Op& a = ops_[ia];
+        if (!tower(a) || root(a.out) != a.out) continue;
+        TensorImpl& t = *tensors_[a.out];
+        if (t.is_output || t.is_input || t.bstride != 0 || t.cpad != 0 || !t.il8 || t.f16) continue;
+        int readers = 0;
+        bool ok = true;
+        for (size_t j = 0; j < ops_.size(); j++) {
+            const Op& b = ops_[j];
+            bool reads = b.resid >= 0 && root(b.resid) == t.id;
+            for (int x : b.in) reads = reads || root(x) == t.id;
+            if (!reads) continue;
+            readers++;
+            ok = ok && j > ia && tower(b) && b.in.size() == 1 && root(b.in[0]) == t.id && b.resid >= 0 && root(b.resid) == t.id;
+        }
+        if (readers == 1 && ok) { t.split = true; nsplit++; }
+    }
+    if (!nsplit) return;
+    for (Op& op : ops_) {
+        if (!tower(op)) continue;
+        const bool xs = tensors_[root(op.in[0])]->split, ys = tensors_[root(op.out)]->split;
+        if ((xs || ys) && rt_resblock_plan_set_split(op.plan, xs, ys) != 0) {
+            log_.log(ILogger::Severity::kERROR, rt_last_error_string());
+            ok_ = false;
+            return;
+        }
+    }
+    log_.log(ILogger::Severity::kINFO, ("engine: " + std::to_string(nsplit) + " tensors between tower blocks stored pre-split (fp16 hi / lo operand pairs)").c_str());
 }
 
 // Siamese towers in ONE launch per layer.  The two feature towers of every Stereo DNN share their weights (the reference exports
@@ -1216,7 +1252,7 @@ void EngineImpl::mergeSiamese() {
     auto pairable = [&](int l, int r) {
         if (l < 0 || r < 0 || l == r) return false;
         const TensorImpl &a = *tensors_[l], &b = *tensors_[r];
-        return plain(a) && plain(b) && same_dims(a.dims, b.dims) && a.pitch == b.pitch && a.f16 == b.f16 && a.il8 == b.il8 && b.cpad == 0;
+        return plain(a) && plain(b) && same_dims(a.dims, b.dims) && a.pitch == b.pitch && a.f16 == b.f16 && a.il8 == b.il8 && a.split == b.split && b.cpad == 0;
     };
     // 3. op pairs: convolution plans covering twin layers, all of whose tensors pair up
     int merged = 0;
@@ -1997,7 +2033,8 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
         while (eng_.tensors_[t]->alias_of >= 0 && eng_.tensors_[t]->alias_off == 0 && eng_.tensors_[t]->bstride == 0) t = eng_.tensors_[t]->alias_of;
         const TensorImpl& ti = *eng_.tensors_[t];
         if (ti.alias_of >= 0 || ti.bstride != 0 || ti.dims.nbDims != 3) continue;       // a channel range of another buffer: checked where it is produced
-        const int C = ti.dims.d[0], H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W, G = ti.il8 ? (ti.f16 ? 8 : 4) : 1;
+        // (a pre-split tensor is scanned as the fp16 values it holds: 16 per pixel and group of 8 channels)
+        const int C = ti.split ? 2 * ti.dims.d[0] : ti.dims.d[0], H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W, G = ti.split ? 16 : (ti.il8 ? (ti.f16 ? 8 : 4) : 1);
         float mx = 0.f;
         int64_t bad = 0;
         // (the host of an interleaved concatenation: its own channels sample by sample -- the groups behind them belong to other members)
@@ -2007,7 +2044,7 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
             float m1 = 0.f;
             int64_t b1 = 0;
             const char* px = static_cast<const char*>(addr(tin, batch, bindings)) + (size_t)n * EngineImpl::sampleElems(ti) * (ti.f16 ? 2 : 4);
-            if (rt_check_range(px, rows, (int64_t)G * W, (int64_t)G * P, ti.f16 ? RT_F16 : RT_F32, limit, &m1, &b1, st) != 0) {
+            if (rt_check_range(px, rows, (int64_t)G * W, (int64_t)G * P, (ti.f16 || ti.split) ? RT_F16 : RT_F32, limit, &m1, &b1, st) != 0) {
                 eng_.log_.log(ILogger::Severity::kERROR, (op.name + ": range check failed: " + rt_last_error_string()).c_str());
                 return false;
             }

@@ -42,6 +42,9 @@ struct S3RBSCfg {
     static constexpr int NK_WL = (WL_SLOTS + 255) / 256;
 };
 
+// Y_SPLIT: the output is written as the PRE-SPLIT tensor (C/8, H, pitch, [8 x fp16 hi | 8 x scaled fp16 lo]) the DMA-fed block reads
+// (conv_rbd.hip.h): the first block of a tower, whose input is the fp32 tensor of the 5x5 layer.
+template <bool Y_SPLIT>
 __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
     using Cfg = S3RBSCfg;
     const ConvArgs& p = a.c;
@@ -270,7 +273,15 @@ __global__ void __launch_bounds__(512) conv_s3rbs_kernel(RBArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     o[e] = apply_act_fast(fmaf(acc_c[4 * q + e], kSplitInv, acc_m[4 * q + e]) + (bv[e] + rr[q][e]), 1);
-                buf_store4(o, rs_y, vo, (unsigned)(8 * q * cs_y) * 4u);          // see common.hip.h: no register soffset on 16-byte stores
+                if (Y_SPLIT) {
+                    // lane (pixel, kg) holds channels 8 q + 4 kg .. + 3: the kg-th half of group q's 16-byte hi slot and of its lo slot
+                    const S3Split sp = s3_split(o);
+                    const unsigned vs = (col_ok && prow >= 0) ? (unsigned)(prow * p.y_ystride + ox) * 32u + 8u * kg : kBufOOB;
+                    buf_store2(__builtin_bit_cast(f32x2_t, sp.hi), rs_y, vs, (unsigned)(8 * q * cs_y) * 4u);
+                    buf_store2(__builtin_bit_cast(f32x2_t, sp.lo), rs_y, vs, (unsigned)(8 * q * cs_y) * 4u + 16u);
+                } else {
+                    buf_store4(o, rs_y, vo, (unsigned)(8 * q * cs_y) * 4u);          // see common.hip.h: no register soffset on 16-byte stores
+                }
             }
         };
         for (int s = 0; s < nstep; s++) {

@@ -34,6 +34,7 @@
 #include "kernels/deconv_f16p.hip.h"
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
+#include "kernels/conv_rbd.hip.h"
 #include "kernels/deconv_s3p.hip.h"
 #include "kernels/fold_factor.hip.h"
 #include "kernels/cost_volume.hip.h"
@@ -636,6 +637,11 @@ struct rtConvPlan {
     float* rb_w1_dev = nullptr;
     float* rb_bias1_dev = nullptr;
     int rb_act1 = 0, rb_cmid = 0;
+    // ... and, for the tower form (32 -> 32 -> 32), both convolutions' slabs with the output channels in conv_s3rbd_kernel's row order,
+    // and whether the block's input / output is a pre-split tensor (rt_resblock_plan_set_split)
+    float* rbd_w1_dev = nullptr;
+    float* rbd_w2_dev = nullptr;
+    int x_split = 0, y_split = 0;
     int w_f16 = 0;                                // the weights were given as fp16 (trt_weights_fp16.bin)
     // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
     int is_conv3d = 0, is_deconv3d = 0;
@@ -1104,6 +1110,8 @@ void free_plan(rtConvPlan* p) {
     if (p->bias_dev) (void)hipFree(p->bias_dev);
     if (p->rb_w1_dev) (void)hipFree(p->rb_w1_dev);
     if (p->rb_bias1_dev) (void)hipFree(p->rb_bias1_dev);
+    if (p->rbd_w1_dev) (void)hipFree(p->rbd_w1_dev);
+    if (p->rbd_w2_dev) (void)hipFree(p->rbd_w2_dev);
     delete p;
 }
 
@@ -1213,9 +1221,53 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
             hipMemcpy(plan->rb_bias1_dev, ba.data(), ba.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(RT_E_NOMEM, "rt_resblock_plan_create: device allocation failed");
     }
+    // the tower form: the same slabs with output channel co in row rbd_row(co) of the A operands (conv_rbd.hip.h: lane (pixel, kg) of
+    // an accumulator owns channels 8 kg .. + 7 and 16 + 8 kg .. + 7)
+    if (!rc && d1->Cin == 32 && d1->Cout == 32 && d2->Cout == 32) {
+        auto rbd_row = [](int co) { return 8 * (2 * (co >> 4) + ((co >> 2) & 1)) + 4 * ((co >> 3) & 1) + (co & 3); };
+        auto pack = [&](const std::vector<float>& w, float** dev) {
+            std::vector<uint16_t> slab((size_t)18 * 2 * 64 * 8, 0);
+            for (int co = 0; co < 32; co++)
+                for (int ci = 0; ci < 32; ci++)
+                    for (int t = 0; t < 9; t++) {
+                        uint16_t hi, lo;
+                        split_f16(w[((size_t)co * 32 + ci) * 9 + t], hi, lo);
+                        const size_t sl = (size_t)(ci / 16) * 9 + t;
+                        const int kg = (ci % 16) / 8, e = ci % 8, row = rbd_row(co);
+                        slab[(((sl * 2 + 0) * 2 + kg) * 32 + row) * 8 + e] = hi;
+                        slab[(((sl * 2 + 1) * 2 + kg) * 32 + row) * 8 + e] = lo;
+                    }
+            if (hipMalloc((void**)dev, slab.size() * 2) != hipSuccess || hipMemcpy(*dev, slab.data(), slab.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(RT_E_NOMEM, "rt_resblock_plan_create: device allocation failed");
+            return 0;
+        };
+        rc = pack(wa, &plan->rbd_w1_dev);
+        if (!rc) rc = pack(wb, &plan->rbd_w2_dev);
+    }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
     return 0;
+}
+
+// Pre-split tensors between the tower blocks (conv_rbd.hip.h): (C/8, H, pitch, [8 x fp16 hi | 8 x scaled fp16 lo]) per sample, the operands
+// of the split-fp16 MFMAs as stored values, x = hi + lo * 2^-11 -- the same 4 bytes per element and the same strides as the fp32 tensor.
+// x_split: the block reads one (and takes its skip connection from it), y_split: it writes one.
+extern "C" int rt_resblock_plan_supports_split(const rtConvPlan* plan);
+extern "C" int rt_resblock_plan_set_split(rtConvPlan* plan, int x_split, int y_split) {
+    RT_REQUIRE(plan, "rt_resblock_plan_set_split: null plan");
+    if (!x_split && !y_split) { plan->x_split = plan->y_split = 0; return 0; }
+    if (!rt_resblock_plan_supports_split(plan))
+        return fail(RT_E_UNSUPPORTED, "rt_resblock_plan_set_split: only the tower block takes pre-split tensors (32 -> 32 -> 32 channels, ELU after both "
+                                       "convolutions, fp32 channel-interleaved tensors: call rt_conv_plan_set_layouts(1, 1, 1) first)");
+    plan->x_split = x_split != 0; plan->y_split = y_split != 0;
+    return 0;
+}
+
+extern "C" int rt_resblock_plan_supports_split(const rtConvPlan* plan) {
+    if (!plan || plan->subs.size() != 1 || !plan->rbd_w1_dev || env_int("RT_NO_RBD", 0) != 0) return 0;
+    const SubConv& sc = plan->subs[0];
+    return sc.rb && sc.x_il8 && sc.y_il8 && !sc.x_f16 && !sc.y_f16 && plan->cin == 32 && plan->rb_cmid == 32 && sc.Cout == 32 && plan->rb_act1 == 1 &&
+           plan->act == 1 && !(plan->flags & RT_CONV_EXACT_FP32);
 }
 
 extern "C" int rt_deconv2d_plan_create(rtConvPlan** out, const rtConv2dDesc* d, const void* weights, const void* bias) {
@@ -2231,6 +2283,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
     RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
     ExactScope exact_scope(plan->flags);
     plan->softarg = 0;                  // (a fused soft-argmax is declared last, on the final tensor types and layouts)
+    plan->x_split = plan->y_split = 0;  // (so are pre-split tensors: rt_resblock_plan_set_split)
     if (!x_il8 && !y_il8 && !r_il8) {
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
@@ -2663,8 +2716,16 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                 seg = seg < 4 ? 4 : (seg > 240 ? 240 : (seg + 3) / 4 * 4);
                 ra.seg = seg;
                 dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, seg)), 1u, (unsigned)batch);
-                if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rbs grid %u x %u\n", sgrid.x, sgrid.z);
-                hipLaunchKernelGGL(rt::conv_s3rbs_kernel, sgrid, dim3(512), 0, S(s), ra);      // ELU / ELU, as in every tower block
+                if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rb%c grid %u x %u split %d -> %d\n", plan->x_split ? 'd' : 's', sgrid.x, sgrid.z, plan->x_split, plan->y_split);
+                if (plan->x_split) {                    // pre-split input: the DMA-fed block (its own row order of the weight slabs)
+                    ra.w1 = plan->rbd_w1_dev; ra.c.w = plan->rbd_w2_dev;
+                    if (plan->y_split) hipLaunchKernelGGL(rt::conv_s3rbd_kernel<true>, sgrid, dim3(512), 0, S(s), ra);
+                    else hipLaunchKernelGGL(rt::conv_s3rbd_kernel<false>, sgrid, dim3(512), 0, S(s), ra);
+                    RT_LAUNCH_CHECK("conv_s3rbd_kernel");
+                    continue;
+                }
+                if (plan->y_split) hipLaunchKernelGGL(rt::conv_s3rbs_kernel<true>, sgrid, dim3(512), 0, S(s), ra);
+                else hipLaunchKernelGGL(rt::conv_s3rbs_kernel<false>, sgrid, dim3(512), 0, S(s), ra);      // ELU / ELU, as in every tower block
                 RT_LAUNCH_CHECK("conv_s3rbs_kernel");
                 continue;
             }

@@ -460,8 +460,9 @@ def test_resnet18_2d_full_size_layouts(monkeypatch, half2):
         net.destroy()
     if half2:
         assert torch.equal(outs[0], outs[1])
-    else:       # fp32: the correlation of interleaved feature maps runs on the matrix cores, of planar ones on the vector ALU
-        assert (outs[0] - outs[1]).abs().max().item() <= 2e-6
+    else:       # fp32: the correlation of interleaved feature maps runs on the matrix cores, of planar ones on the vector ALU; and (round 6)
+                # the tensors between the fused tower blocks of the interleaved engine are stored pre-split: 22 bits (conv_rbd.hip.h)
+        assert (outs[0] - outs[1]).abs().max().item() <= 5e-6
     if half2:
         wq = {k: np.asarray(v).astype(np.float16).astype(np.float32) for k, v in weights.items()}
         with torch.no_grad():

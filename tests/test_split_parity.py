@@ -296,6 +296,101 @@ def test_split_resblock(backend, c, cmid, h, w, batch, pitch, il):
     assert np.abs(out - two).max() <= 6e-6, np.abs(out - two).max()
 
 
+# ---- the tower block on PRE-SPLIT tensors (conv_rbd.hip.h) ---------------------------------------------------------------------
+def to_split(a):
+    """(N, C, H, P) fp32 -> the pre-split tensor (N, C/8, H, P, [8 hi | 8 lo]) as an fp32-typed array (N, C/8, H, P, 8):
+    hi = fp16(v), lo = fp16((v - hi) * 2^11) (include/rt_stereo.h: rt_resblock_plan_set_split)"""
+    n, c, h, p = a.shape
+    g = a.reshape(n, c // 8, 8, h, p).transpose(0, 1, 3, 4, 2).astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        hi = g.astype(np.float16)
+        lo = ((g - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    return np.ascontiguousarray(np.concatenate([hi, lo], axis=-1)).view(np.float32)
+
+
+def from_split(a):
+    """the values a pre-split tensor holds, hi + lo * 2^-11, as (N, C, H, P) fp32"""
+    h16 = np.ascontiguousarray(a).view(np.float16)
+    n, g, h, p, _ = h16.shape
+    v = h16[..., :8].astype(np.float32) + h16[..., 8:].astype(np.float32) * np.float32(1 / 2048)
+    return v.transpose(0, 1, 4, 2, 3).reshape(n, g * 8, h, p)
+
+
+RBD_CASES = [
+    # h, w, batch, pitch
+    (16, 30, 1, 32),       # exactly one strip and one segment
+    (17, 31, 1, 0),        # one row / one column past them, dense odd rows
+    (37, 61, 2, 64),       # three segments (16 + 16 + 5), three strips (30 + 30 + 1), two images
+    (5, 100, 1, 128),      # shorter than a segment
+    (1, 1, 1, 0),          # single pixel
+    (33, 7, 1, 32),        # narrower than a strip
+    (70, 35, 1, 64),       # two 32-row segments and a rest: the x ring wraps more than once, the t ring's mirror rows are used
+]
+
+
+@pytest.mark.parametrize("x_split,y_split", [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize("h,w,batch,pitch", RBD_CASES)
+def test_split_resblock_presplit_tensors(backend, h, w, batch, pitch, x_split, y_split):
+    """the tower block reading and / or writing pre-split tensors -- conv_s3rbd_kernel (LDS-DMA fed) when it reads one,
+    conv_s3rbs_kernel's split-writing epilogue when it only writes one -- against an fp64 evaluation of the two layers on the values
+    the input tensor holds, and against the fp32-tensor form of the same plan.  The stored pair must be the split of the value it stands
+    for (hi = fp16(v)): the next block's matrix instructions consume it as is."""
+    c = 32
+    x = rnd(batch, c, h, w)
+    w1, b1 = rnd(c, c, 3, 3) * np.float32(1 / np.sqrt(c * 9)), rnd(c)
+    w2, b2 = rnd(c, c, 3, 3) * np.float32(1 / np.sqrt(c * 9)), rnd(c)
+    P = pitch or w
+    xs = to_split(pitched(x, P))
+    xv = from_split(xs)[..., :w] if x_split else x             # what the block computes on: 22 bits of x
+    assert np.abs(xv - x).max() <= 2.0 ** -21 * np.abs(x).max()
+    X = torch.from_numpy(xv).double()
+    t = O.elu(O.conv2d(X, torch.from_numpy(w1).double(), torch.from_numpy(b1).double(), 1, 1))
+    ref = O.elu(O.conv2d(t, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), 1, 1) + X).numpy()
+    plan = backend.klib.resblock_plan(w1, b1, w2, b2, c, c, h, w)
+    if pitch:
+        plan.set_pitch(pitch, pitch)
+    assert not plan.supports_split()                            # planar tensors: no
+    plan.set_layouts(1, 1, 1)
+    assert plan.supports_split()
+    outs = []
+    for xsp, ysp in ((x_split, y_split), (0, 0)):
+        plan.set_split(xsp, ysp)
+        xin = backend.dev(xs if xsp else to_il(pitched(x, P), 4))
+        y = backend.empty((batch, c // 8, h, P, 8) if ysp else (batch, c // 4, h, P, 4))
+        plan.enqueue(xin, y, xin, batch)
+        raw = backend.host(y).copy()
+        if ysp:
+            h16 = np.ascontiguousarray(raw).view(np.float16)
+            if P > w:
+                assert np.isnan(raw[:, :, :, w:, :]).all(), "padding columns were written"     # (still the fp32 NaNs of backend.empty)
+            out = from_split(raw)[..., :w]
+            hi = h16[:, :, :, :w, :8].transpose(0, 1, 4, 2, 3).reshape(batch, c, h, w)
+            # hi is a nearest fp16 of the value the pair stands for (at an exact tie the rounding of lo may put it on the other side)
+            assert (np.abs(hi.astype(np.float32) - out) <= np.spacing(np.abs(hi)).astype(np.float32) * np.float32(0.5 + 2.0 ** -10)).all()
+        else:
+            out = from_il(raw)
+            if P > w:
+                assert np.isnan(out[..., w:]).all(), "padding columns were written"
+            out = out[..., :w]
+        outs.append(out)
+    plan.destroy()
+    assert np.abs(outs[0] - ref).max() <= 6e-6, np.abs(outs[0] - ref).max()
+    # the fp32-tensor form of the same block: same arithmetic up to the order of summation and the 22-bit input / output
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-5, np.abs(outs[0] - outs[1]).max()
+
+
+def test_split_resblock_refuses_presplit_tensors_where_it_has_no_kernel(backend):
+    w1, b1 = rnd(16, 16, 3, 3), rnd(16)
+    plan = backend.klib.resblock_plan(w1, b1, w1, b1, 16, 16, 8, 32) if backend.klib.has_experimental() else None
+    if plan is None:
+        pytest.skip("the per-tile form (conv_s3rb_kernel) is compiled with RT_EXPERIMENTAL only")
+    plan.set_layouts(1, 1, 1)
+    assert not plan.supports_split()
+    with pytest.raises(capi.RtError):
+        plan.set_split(1, 1)
+    plan.destroy()
+
+
 # ---- correlation + soft-argmax on the matrix cores (corr_mfma.hip.h) ------------------------------------------------------
 @pytest.mark.parametrize("shape,D,is_min,pitch", [((2, 32, 9, 140), 48, False, 160), ((1, 32, 5, 129), 64, False, 0),
                                                   ((1, 16, 7, 37), 6, True, 64), ((2, 8, 3, 33), 13, False, 0),

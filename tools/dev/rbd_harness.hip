@@ -201,7 +201,7 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "rbd (new), fp32 out, seg %d", seg);
             timeit(nm, [&](hipStream_t st) { hipLaunchKernelGGL(rt::conv_s3rbd_kernel<false>, g, dim3(512), 0, st, an); }, 50);
             snprintf(nm, sizeof nm, "rbs (old), seg %d", seg);
-            timeit(nm, [&](hipStream_t st) { hipLaunchKernelGGL(rt::conv_s3rbs_kernel, g, dim3(512), 0, st, ao); }, 50);
+            timeit(nm, [&](hipStream_t st) { hipLaunchKernelGGL(rt::conv_s3rbs_kernel<false>, g, dim3(512), 0, st, ao); }, 50);
         }
         // in company: 4 streams, each a chain of launches (64-row segments: 126 workgroups per launch)
         {
@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < 4; k++) {
                         rt::RBArgs a = args(newk, newk ? dxs : dx4, ys[k], seg);
                         if (newk) hipLaunchKernelGGL(rt::conv_s3rbd_kernel<true>, g, dim3(512), 0, st[k], a);
-                        else hipLaunchKernelGGL(rt::conv_s3rbs_kernel, g, dim3(512), 0, st[k], a);
+                        else hipLaunchKernelGGL(rt::conv_s3rbs_kernel<false>, g, dim3(512), 0, st[k], a);
                     }
                 for (int k = 0; k < 4; k++) CK(hipStreamSynchronize(st[k]));
                 CK(hipEventRecord(e1, 0));
@@ -239,7 +239,7 @@ int main(int argc, char** argv) {
             for (int rep = 0; rep < 3; rep++) {
                 CK(hipMemset(ddbg, 0, 1024 * 2 * 16 * 8));
                 if (newk) hipLaunchKernelGGL(rt::conv_s3rbd_kernel<true>, g, dim3(512), 0, 0, a);
-                else hipLaunchKernelGGL(rt::conv_s3rbs_kernel, g, dim3(512), 0, 0, a);
+                else hipLaunchKernelGGL(rt::conv_s3rbs_kernel<false>, g, dim3(512), 0, 0, a);
                 CK(hipDeviceSynchronize());
             }
             const int nwg = g.x * g.z;
