@@ -1066,8 +1066,8 @@ void EngineImpl::planIssueOrder() {
 
 // Residual blocks in one launch: conv3x3 (+ELU) -> conv3x3 + skip (+ELU) with the skip connection being the block's input
 // (reference resnet18_2D_513x257_net.cpp:66-575, 8 blocks per feature tower) become one rt_resblock_plan: the intermediate
-// tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  Not in half2 mode, where the two layers run on fp16
-// operands with fp16 tensors in between.
+// tensor never leaves the CU (conv_split.hip.h, conv_s3rb_kernel).  In half2 mode the two layers run on fp16 operands with an fp16
+// tensor in between; the fused form (conv_rbh.hip.h) rounds the intermediate to fp16 in LDS and is bit-identical to them.
 void EngineImpl::fuseResBlocks() {
     // Default: the blocks the STREAMING kernel serves (conv_rbs.hip.h: 32 -> 32 -> 32 channels, ELU after both, channel-interleaved fp32
     // tensors) on images large enough to fill the GPU with its strips x segments -- measured on MI355X, round 2, ResNet-18 2D at
@@ -1078,7 +1078,9 @@ void EngineImpl::fuseResBlocks() {
     // (tests, A/B), RT_RB=0 / RT_NO_RB none.
     const char* e = knob("RT_RB");
     const bool force = e && atoi(e) != 0;
-    if ((e && !force) || knob("RT_NO_FUSION") || knob("RT_NO_RB") || knob("RT_NO_S3") || exact_fp32_ || (half2_ && !knob("RT_NO_F16"))) return;
+    // half2 mode (round 6): the same block on fp16 tensors and fp16 operands, conv_f16rbd_kernel -- bit-identical to its two layers
+    const bool h2 = half2_ && !knob("RT_NO_F16");
+    if ((e && !force) || knob("RT_NO_FUSION") || knob("RT_NO_RB") || knob("RT_NO_S3") || exact_fp32_ || (h2 && (knob("RT_NO_RBH") || knob("RT_NO_F16MMA")))) return;
     int fused = 0;
     for (size_t ia = 0; ia < ops_.size(); ia++) {
         Op& a = ops_[ia];
@@ -1112,7 +1114,8 @@ void EngineImpl::fuseResBlocks() {
         const TensorImpl &x = *tensors_[root(a.in[0])], &y = *tensors_[root(b.out)];
         {
             bool ok = d1.Cin == 32 && d1.Cout == 32 && d2.Cout == 32 && a.act == RT_ACT_ELU && b.act == RT_ACT_ELU;
-            ok = ok && x.il8 && y.il8 && !x.f16 && !y.f16;                        // what the streaming kernel reads and writes
+            ok = ok && x.il8 && y.il8 && x.f16 == h2 && y.f16 == h2;              // what the streaming kernels read and write
+            if (h2 && !ok) continue;                                              // (half2: no other form of the fused block)
             // forced: also small images, and -- in RT_EXPERIMENTAL builds of the kernel library -- every other block through the per-tile form
             if (force ? (!ok && !rt_has_experimental()) : !(ok && ((d1.Win + 29) / 30) * ((d1.Hin + 15) / 16) >= 200)) continue;   // default: enough strips x segments for every CU
         }

@@ -35,6 +35,7 @@
 #include "kernels/conv_split.hip.h"
 #include "kernels/conv_rbs.hip.h"
 #include "kernels/conv_rbd.hip.h"
+#include "kernels/conv_rbh.hip.h"
 #include "kernels/deconv_s3p.hip.h"
 #include "kernels/fold_factor.hip.h"
 #include "kernels/cost_volume.hip.h"
@@ -642,6 +643,9 @@ struct rtConvPlan {
     float* rbd_w1_dev = nullptr;
     float* rbd_w2_dev = nullptr;
     int x_split = 0, y_split = 0;
+    // ... and as fp16 operands, same row order, for the half2 form of the block (conv_f16rbd_kernel: both tensors fp16)
+    float* rbh_w1_dev = nullptr;
+    float* rbh_w2_dev = nullptr;
     int w_f16 = 0;                                // the weights were given as fp16 (trt_weights_fp16.bin)
     // 3-D plans: what rt_conv_plan_set_io_types / _supports_il8 need to know (Conv3D: w_canon holds the weights as (K, V*C, R, S))
     int is_conv3d = 0, is_deconv3d = 0;
@@ -1112,6 +1116,8 @@ void free_plan(rtConvPlan* p) {
     if (p->rb_bias1_dev) (void)hipFree(p->rb_bias1_dev);
     if (p->rbd_w1_dev) (void)hipFree(p->rbd_w1_dev);
     if (p->rbd_w2_dev) (void)hipFree(p->rbd_w2_dev);
+    if (p->rbh_w1_dev) (void)hipFree(p->rbh_w1_dev);
+    if (p->rbh_w2_dev) (void)hipFree(p->rbh_w2_dev);
     delete p;
 }
 
@@ -1243,6 +1249,22 @@ extern "C" int rt_resblock_plan_create(rtConvPlan** out, const rtConv2dDesc* d1,
         };
         rc = pack(wa, &plan->rbd_w1_dev);
         if (!rc) rc = pack(wb, &plan->rbd_w2_dev);
+        // half2 form: the weights rounded to fp16 (what repack_f16mma gives the layer-by-layer kernel), [chunk * 9 + tap][k-group][row][8]
+        auto pack16 = [&](const std::vector<float>& w, float** dev) {
+            std::vector<uint16_t> slab((size_t)18 * 64 * 8, 0);
+            for (int co = 0; co < 32; co++)
+                for (int ci = 0; ci < 32; ci++)
+                    for (int t = 0; t < 9; t++) {
+                        const _Float16 hv = (_Float16)w[((size_t)co * 32 + ci) * 9 + t];
+                        const size_t sl = (size_t)(ci / 16) * 9 + t;
+                        std::memcpy(&slab[((sl * 2 + (ci % 16) / 8) * 32 + rbd_row(co)) * 8 + ci % 8], &hv, 2);
+                    }
+            if (hipMalloc((void**)dev, slab.size() * 2) != hipSuccess || hipMemcpy(*dev, slab.data(), slab.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(RT_E_NOMEM, "rt_resblock_plan_create: device allocation failed");
+            return 0;
+        };
+        if (!rc) rc = pack16(wa, &plan->rbh_w1_dev);
+        if (!rc) rc = pack16(wb, &plan->rbh_w2_dev);
     }
     if (rc) { free_plan(plan); return rc; }
     *out = plan;
@@ -2181,6 +2203,12 @@ extern "C" int rt_conv_plan_set_io_types(rtConvPlan* plan, int x_dtype, int y_dt
             sc.x_f16 = 0; sc.y_f16 = 1;
             continue;
         }
+        // the tower block in half2 mode: both tensors fp16, fp16 operands, one launch (conv_f16rbd_kernel; interleaved tensors, checked at enqueue)
+        if (sc.rb && xf && yf && plan->rbh_w1_dev && plan->cin == 32 && plan->rb_cmid == 32 && sc.Cout == 32 && plan->rb_act1 == 1 && plan->act == 1 &&
+            env_int("RT_NO_F16MMA", 0) == 0 && env_int("RT_NO_RBH", 0) == 0) {
+            sc.x_f16 = sc.y_f16 = 1;
+            continue;
+        }
         if (sc.s3p || sc.split3 || sc.s3first || sc.rb) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: the split-fp16 kernels take fp32 tensors (both fp16: fp16 operands instead)");
         if (sc.small3d) { if (!(sc.small3d == 2 && xf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: unsupported combination for the small-output kernel"); }
         else if (sc.wino) { if (!(xf && yf)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_io_types: Winograd layers take fp16 on both sides"); }
@@ -2717,6 +2745,12 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                 ra.seg = seg;
                 dim3 sgrid((unsigned)(ra.c.tiles_x * (int)rt::cdiv(sc.Ho, seg)), 1u, (unsigned)batch);
                 if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rb%c grid %u x %u split %d -> %d\n", plan->x_split ? 'd' : 's', sgrid.x, sgrid.z, plan->x_split, plan->y_split);
+                if (sc.x_f16) {                         // half2 mode: fp16 tensors, fp16 operands
+                    ra.w1 = plan->rbh_w1_dev; ra.c.w = plan->rbh_w2_dev;
+                    hipLaunchKernelGGL(rt::conv_f16rbd_kernel, sgrid, dim3(512), 0, S(s), ra);
+                    RT_LAUNCH_CHECK("conv_f16rbd_kernel");
+                    continue;
+                }
                 if (plan->x_split) {                    // pre-split input: the DMA-fed block (its own row order of the weight slabs)
                     ra.w1 = plan->rbd_w1_dev; ra.c.w = plan->rbd_w2_dev;
                     if (plan->y_split) hipLaunchKernelGGL(rt::conv_s3rbd_kernel<true>, sgrid, dim3(512), 0, S(s), ra);
@@ -2729,6 +2763,8 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
                 RT_LAUNCH_CHECK("conv_s3rbs_kernel");
                 continue;
             }
+            if (sc.x_f16 || sc.y_f16)
+                return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue: the half2 form of the residual block takes channel-interleaved fp16 tensors only (rt_conv_plan_set_layouts(1, 1, 1))");
 #ifdef RT_EXPERIMENTAL
             dim3 rgrid((unsigned)(a.tiles_x * tiles_y), 1u, (unsigned)batch);
             if (plan->opt_trace) fprintf(stderr, "[rt] conv_s3rb x%d y%d grid %u x %u\n", sc.x_il8, sc.y_il8, rgrid.x, rgrid.z);

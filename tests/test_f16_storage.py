@@ -142,6 +142,48 @@ def test_conv2d_f16_interleaved(backend, cin, cout, h, w, resid, x_il8, y_il8, r
     plan.destroy()
 
 
+@pytest.mark.parametrize("h,w,batch,pitch", [(16, 30, 1, 64), (17, 31, 1, 64), (37, 61, 2, 64), (5, 100, 1, 128), (1, 1, 1, 64), (33, 7, 1, 64),
+                                             (70, 35, 1, 64)])
+def test_resblock_f16_fused_is_bit_identical_to_its_two_layers(backend, h, w, batch, pitch):
+    """the tower block of half2 mode in ONE launch (conv_f16rbd_kernel: fp16 tensors by LDS-DMA, fp16 operands, the intermediate rounded
+    to fp16 in LDS) against the two launches of conv_f16mma_kernel it replaces -- same roundings, same order of summation: the same bits
+    -- and against the oracle on the fp16-rounded operands.  Strips of 30 columns x segments of 16 / 32 rows, image edges, batch."""
+    c, act = 32, capi.RT_ACT_ELU
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x = q16(rnd(batch, c, h, w))
+    w1, b1 = q16(rnd(c, c, 3, 3) * np.float32(1 / np.sqrt(c * 9))), rnd(c)
+    w2, b2 = q16(rnd(c, c, 3, 3) * np.float32(1 / np.sqrt(c * 9))), rnd(c)
+    xin = dev16(backend, to_il8(pitched(x, pitch)))
+
+    def layer(wt, b, src, resid):
+        plan = backend.klib.conv2d_plan(wt, b, c, c, h, w, 3, 1, 1, act=act, has_residual=resid is not None)
+        plan.set_pitch(pitch, pitch)
+        plan.set_io_types(capi.RT_F16, capi.RT_F16)
+        plan.set_layouts(1, 1, 1 if resid is not None else 0)
+        y = empty16(backend, (batch, c // 8, h, pitch, 8))
+        plan.enqueue(src, y, resid, batch)
+        plan.destroy()
+        return y
+
+    t = layer(w1, b1, xin, None)
+    two = host(backend, layer(w2, b2, t, xin))
+    plan = backend.klib.resblock_plan(w1, b1, w2, b2, c, c, h, w)
+    plan.set_pitch(pitch, pitch)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    plan.set_layouts(1, 1, 1)
+    assert not plan.supports_split()                    # pre-split tensors are the fp32 engines'
+    y = empty16(backend, (batch, c // 8, h, pitch, 8))
+    plan.enqueue(xin, y, xin, batch)
+    one = host(backend, y)
+    plan.destroy()
+    assert np.isnan(one[:, :, :, w:, :]).all(), "padding columns were written"
+    assert np.array_equal(one[:, :, :, :w, :], two[:, :, :, :w, :]), np.abs(one[:, :, :, :w, :] - two[:, :, :, :w, :]).max()
+    tt = q16(O.elu(O.conv2d(T(x), T(w1), T(b1), 1, 1)).numpy())
+    ref = O.elu(O.conv2d(T(tt), T(w2), T(b2), 1, 1) + T(x)).numpy()
+    out = from_il8(one)[..., :w]
+    assert np.abs(out - ref).max() <= 4e-3 * max(1.0, float(np.abs(ref).max()))     # (an fp16 rounding of t that falls the other way, and of y)
+
+
 def test_interleaved_layout_is_refused_where_it_does_not_exist(backend):
     plan = backend.klib.conv2d_plan(rnd(32, 32, 3, 3), rnd(32), 32, 32, 9, 20, 3, 2, 1)       # stride 2
     plan.set_pitch(64, 64)

@@ -324,6 +324,21 @@ def test_resnet18_2d_half2_mode(rt, monkeypatch):
     assert np.array_equal(planar, half)
 
 
+def test_resnet18_2d_half2_fused_residual_blocks(rt, monkeypatch):
+    """half2 mode with every tower block as ONE launch (RT_RB=1 forces the fusion on an image this small; at 1257 x 369 it is the default):
+    conv_f16rbd_kernel rounds the intermediate to fp16 in LDS as the layer-by-layer path rounds it in HBM and sums in the same order --
+    the disparity map has the same bits, from 8 launches fewer (8 merged blocks x 2 layers -> 8 launches).  sample_app/main.cpp:228-266."""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1 if rt.kind == "emu" else 2, 41, 73)
+    base, (_, n0) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    monkeypatch.setenv("RT_RB", "1")
+    for seg in ("16", "32"):
+        monkeypatch.setenv("RT_RBS_SEG", seg)
+        out, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+        assert n1 == n0 - 8, (n0, n1)
+        assert np.array_equal(out, base), np.abs(out - base).max()
+
+
 def test_nvtiny_fp16_weight_file(rt, monkeypatch):
     """a 3-D model built from an fp16 weight file (NVSmall only ships trt_weights_fp16.bin): the executor tries half2
     mode, the cost-volume plugin cannot take fp16 tensors, every plan already switched must go back to fp32 --
