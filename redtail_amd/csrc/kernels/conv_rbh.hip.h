@@ -8,7 +8,10 @@
 // conv_s3rbd_kernel (conv_rbd.hip.h) with everything the fp32 form needs the split for taken out:
 //   * the channel-interleaved fp16 tensors (C/8, H, pitch, 8) ARE the B operands: the x ring is filled by `buffer_load_dwordx4 ... lds`,
 //     9 one-KB pieces per 4-row step (36 columns per ring row so that a batch is a whole number of pieces; 34 are fetched);
-//     16-byte records of consecutive pixels are bank-conflict free as they lie;
+//     16-byte records of consecutive pixels are bank-conflict free as they lie.  A step is ~1.5 k cycles here -- about one HBM latency --
+//     so batches are requested TWO steps ahead, by the conv1 waves only: they store nothing, so `s_waitcnt vmcnt(pieces just issued)`
+//     is exactly "the older batch has landed" (loads return in order among themselves), and the conv2 waves cross the barriers with
+//     their stores in flight;
 //   * ONE MFMA per tap and 16-channel chunk; the fp16 weights of a wave's convolution (18 KB) stay in 72 VGPRs, nothing else is staged;
 //   * t is rounded to fp16 into its LDS ring exactly as the layer-by-layer path rounds it into HBM, the skip connection enters the
 //     accumulator before the first MFMA (bias + x, as conv_f16mma_kernel initialises it), and the MFMAs run chunk-major, taps inside,
@@ -22,17 +25,19 @@ namespace rt {
 struct F16RBDCfg {
     static constexpr int NW = 8, NT = 512;
     static constexpr int SW = 30, XCOL = 36, TCOL = 32, STEP = 4;
-    static constexpr int RX = 16, RT = 10;
+    static constexpr int RX = 20, RT = 10;                      // x ring: window 6 + skip rows 4 + TWO landing batches
     static constexpr int GXB = XCOL * 16, XROWB = 4 * GXB;      // 576, 2304
     static constexpr int GTB = TCOL * 16, TROWB = 4 * GTB;      // 512, 2048
     static constexpr int BSLOTS = STEP * XROWB / 16;            // 576 = 9 pieces of 64
     static constexpr int NPIECE = BSLOTS / 64;
-    static constexpr int PPW = (NPIECE + NW - 1) / NW;          // 2: piece w, and wave 0 the ninth
+    static constexpr int PPW = (NPIECE + 3) / 4;                // the four conv1 waves move the pieces: w, w + 4, and wave 0 the ninth
     static constexpr int W_SLOTS = 18 * 64;
     static_assert(BSLOTS % 64 == 0, "a batch is a whole number of DMA pieces");
 };
 
-__global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBArgs a) {
+// 128 registers and 71 KB of LDS: TWO workgroups per CU, four waves per SIMD -- a wave's 18 MFMAs of a row are one dependent chain (the
+// order of summation of the layer-by-layer kernel), and what hides that chain's latency is other waves.
+__global__ void __launch_bounds__(512) RT_WAVES_PER_EU(4) conv_f16rbd_kernel(RBArgs a) {
     using Cfg = F16RBDCfg;
     const ConvArgs& p = a.c;
     constexpr int RX = Cfg::RX, RT = Cfg::RT, GXB = Cfg::GXB, XROWB = Cfg::XROWB, GTB = Cfg::GTB, TROWB = Cfg::TROWB, PPW = Cfg::PPW;
@@ -40,7 +45,9 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
 
     __shared__ __attribute__((aligned(1024))) char sX[RX * XROWB];
     __shared__ __attribute__((aligned(1024))) char sT[(RT + 2) * TROWB];       // rows 10, 11 mirror rows 0, 1: conv2's 3-row window never wraps
-    __shared__ __attribute__((aligned(1024))) f32x4 sWst[2 * Cfg::W_SLOTS];    // prologue only: the two weight slabs on their way to registers
+    // prologue only: the two weight slabs on their way to registers pass through ring rows nothing else uses yet -- conv1's through the
+    // t ring, conv2's through the last 8 rows of the x ring (batches -1, 0, 1 land in its rows 0 .. 11)
+    static_assert(Cfg::W_SLOTS * 16 <= (RT + 2) * TROWB && Cfg::W_SLOTS * 16 <= 8 * XROWB, "weight staging fits the idle ring rows");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,44 +72,47 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
     const int last1 = (y1 - t0) / 4;
     const int row_hi = (y1 + 1 < H - 1 ? y1 + 1 : H - 1);
 
-    // ---- DMA duties (conv_rbd.hip.h): batch b = x rows t0 + 1 + 4 b .. + 3 -> ring slots (4 b + 4) & 15 .. + 3, ring order [row][group][pixel]
+    // ---- DMA duties (conv_rbd.hip.h): batch b = x rows t0 + 1 + 4 b .. + 3 -> ring slots (4 b + 4) % 20 .. + 3, ring order [row][group][pixel]
     const buf_rsrc rs_x = make_buf(elem_ptr(p.x, (int64_t)n * p.x_bstride, ES));
     const unsigned gsb_x = (unsigned)p.x_cstride * 16u, rowb_x = (unsigned)p.x_pitch * 16u;
     unsigned xvo[PPW];
     int xnb[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; j++) {
-        const int k = (wv + 8 * j) * 64 + lane;
+        const int k = (wr + 4 * j) * 64 + lane;
         const int r = k / (XROWB / 16), rem = k - r * (XROWB / 16);
         const int g = rem / Cfg::XCOL, px = rem - g * Cfg::XCOL;
         const int ix = c0 - 2 + px;
-        const bool valid = wv + 8 * j < Cfg::NPIECE && px < 34 && ix >= 0 && ix < W;
+        const bool valid = is1 && wr + 4 * j < Cfg::NPIECE && px < 34 && ix >= 0 && ix < W;
         xvo[j] = valid ? (unsigned)g * gsb_x + (unsigned)(t0 + 1 + r) * rowb_x + (unsigned)ix * 16u : kBufOOB;
         const int d = row_hi - (t0 + 1 + r);
         xnb[j] = valid && d >= 0 ? (d >> 2) + 1 : 0;
     }
     auto issue_batch = [&](int b) __attribute__((always_inline)) {
         const unsigned so = (unsigned)(4 * b) * rowb_x;
-        char* dst = sX + ((4 * b + 4) & (RX - 1)) * XROWB;
+        char* dst = sX + ((4 * b + 4) % RX) * XROWB;
 #pragma unroll
         for (int j = 0; j < PPW; j++)
-            if (wv + 8 * j < Cfg::NPIECE) rbd_dma16(rs_x, dst + (wv + 8 * j) * 1024, b < xnb[j] ? xvo[j] : kBufOOB, so);
+            if (wr + 4 * j < Cfg::NPIECE) rbd_dma16(rs_x, dst + (wr + 4 * j) * 1024, b < xnb[j] ? xvo[j] : kBufOOB, so);
     };
 
-    // ---- prologue: batches -1 (rows t0 - 1, t0 if they exist) and 0, this wave's convolution's weights, its bias
+    // ---- prologue: batches -1 (rows t0 - 1, t0 if they exist), 0 and 1, this wave's convolution's weights, its bias
+    if (is1) {
 #pragma unroll
-    for (int j = 0; j < PPW; j++) {
-        if (wv + 8 * j >= Cfg::NPIECE) continue;
-        const int r = ((wv + 8 * j) * 64 + lane) / (XROWB / 16);
-        const bool ok = xvo[j] != kBufOOB && r >= 2 && t0 - 3 + r >= 0;
-        rbd_dma16(rs_x, sX + (wv + 8 * j) * 1024, ok ? xvo[j] - 4u * rowb_x : kBufOOB, 0u);
+        for (int j = 0; j < PPW; j++) {
+            if (wr + 4 * j >= Cfg::NPIECE) continue;
+            const int r = ((wr + 4 * j) * 64 + lane) / (XROWB / 16);
+            const bool ok = xvo[j] != kBufOOB && r >= 2 && t0 - 3 + r >= 0;
+            rbd_dma16(rs_x, sX + (wr + 4 * j) * 1024, ok ? xvo[j] - 4u * rowb_x : kBufOOB, 0u);
+        }
+        issue_batch(0);
+        issue_batch(1);
     }
-    issue_batch(0);
     {
         // slab of a convolution (rt_capi.hip): [chunk * 9 + tap][lane] 16-byte slots, output channels in conv_s3rbd_kernel's row order
         const buf_rsrc rs_w = make_buf(is1 ? a.w1 : p.w);
         for (int t = wr; t < 18; t += 4)
-            rbd_dma16(rs_w, reinterpret_cast<char*>(sWst + (is1 ? 0 : Cfg::W_SLOTS)) + t * 1024, (unsigned)lane * 16u, (unsigned)t * 1024u);
+            rbd_dma16(rs_w, (is1 ? sT : sX + 12 * XROWB) + t * 1024, (unsigned)lane * 16u, (unsigned)t * 1024u);
     }
     f32x16 biasv;
     {
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
     __syncthreads();
     f16x8 wh[18];
     {
-        const f32x4* whs = sWst + (is1 ? 0 : Cfg::W_SLOTS) + lane;
+        const f32x4* whs = reinterpret_cast<const f32x4*>(is1 ? sT : sX + 12 * XROWB) + lane;
 #pragma unroll
         for (int t = 0; t < 18; t++) wh[t] = __builtin_bit_cast(f16x8, whs[t * 64]);
     }
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
     // B operand of (window row r, column shift s, chunk c): ring row + c * 2 groups + this lane's (k-group, pixel l31 + s)
     const int bo = kg * (is1 ? GXB : GTB) + l31 * 16;
     // taps run chunk-major like conv_f16mma_kernel's (t = chunk * 9 + tap): same order of summation.  Reads run PF taps ahead.
-    constexpr int PF = 3;
+    constexpr int PF = 1;
     auto contract = [&](auto ring1, int first, f32x16 init) __attribute__((always_inline)) -> f32x16 {
         constexpr bool R1 = decltype(ring1)::value;
         constexpr int NR = R1 ? RX : RT, ROWB = R1 ? XROWB : TROWB, GB = R1 ? GXB : GTB;
@@ -163,7 +173,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
         for (int e = 0; e < 4; e++) o[e] = pack_f16(apply_act_fast(acc[8 * g + 2 * e], 1), apply_act_fast(acc[8 * g + 2 * e + 1], 1));
         return o;
     };
-    __syncthreads();                                    // every wave has its weights: the staging area is dead (the rings are separate)
+    __syncthreads();                                    // every wave has its weights: the ring rows they passed through are free
 
     if (is1) {
         // ================= conv1 waves: x ring -> t ring =================
@@ -172,10 +182,11 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
         const bool strip_edge = c0 == 0 || c0 + 31 > W;
         const int tl = kg * GTB + l31 * 16;
         for (int s = 0; s < nstep; s++) {
-            if (s + 1 <= last1) issue_batch(s + 1);
+            const bool more = s + 2 <= last1;           // conv1 of step s + 2 needs batch s + 2
+            if (more) issue_batch(s + 2);
             if (s <= last1) {
                 const int row = t0 + 4 * s + wr;
-                const f32x16 acc = contract(std::true_type(), (4 * s + wr + 2) & (RX - 1), biasv);
+                const f32x16 acc = contract(std::true_type(), (4 * s + wr + 2) % RX, biasv);
                 const bool row_in = row >= 0 && row < H;
                 u32x4_t o[2];
 #pragma unroll
@@ -196,7 +207,10 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
                     for (int g = 0; g < 2; g++) *reinterpret_cast<u32x4_t*>(trow + RT * TROWB + g * (2 * GTB)) = o[g];
                 }
             }
-            wait_vmem();
+            // batch s + 1 has landed when at most the pieces of batch s + 2 are outstanding
+            if (!more) wait_vmem();
+            else if (wr == 0) wait_vmem_but<3>();
+            else wait_vmem_but<2>();
             lds_barrier();
         }
     } else {
@@ -214,12 +228,11 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
             for (int g = 0; g < 2; g++) buf_store4(__builtin_bit_cast(f32x4, elu_pack(acc, g)), rs_y, vo, (unsigned)(2 * g) * cs_y * 16u);
         };
         for (int s = 0; s < nstep; s++) {
-            if (s + 1 <= last1) issue_batch(s + 1);
             if (s >= 2) epilogue2();                    // rows of step s - 1
             if (s >= 1) {
                 const int row = t0 + 4 * s - 5 + wr;
-                // accumulator = bias + skip connection (fp32 additions, as conv_f16mma_kernel starts), x out of the ring: slot (row - t0 + 3) & 15
-                const char* xs = sX + ((4 * s - 2 + wr) & (RX - 1)) * XROWB + xl;
+                // accumulator = bias + skip connection (fp32 additions, as conv_f16mma_kernel starts), x out of the ring: slot (row - t0 + 3) % 20
+                const char* xs = sX + ((4 * s - 2 + wr) % RX) * XROWB + xl;
                 f32x16 init;
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
@@ -231,7 +244,6 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16rbd_kernel(RBA
                 acc = contract(std::false_type(), (4 * s + wr + 4) % RT, init);
                 prow = (row >= y0 && row < y1) ? row : -1;
             }
-            wait_vmem();
             lds_barrier();
         }
         epilogue2();

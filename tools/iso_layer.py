@@ -2,7 +2,7 @@
 """The dominant layer alone: 3x3 32->32 @629x185 (+bias, +residual, +ELU) on the executor's tensor layouts, or the fused
 residual block, launched back to back on an idle GPU.  For rocprofv3 passes (tools/pmc_layer.sh) and quick timings.
 
-    python tools/iso_layer.py [conv|block] [launches] [batch] [hints]      (hints 1 = RT_HINT_THROUGHPUT: 64-row segments of the block)
+    python tools/iso_layer.py [conv|block] [launches] [batch] [hints] [half2]      (hints 1 = RT_HINT_THROUGHPUT: 64-row segments of the block)
 """
 import ctypes
 import os
@@ -19,6 +19,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "conv"
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 b = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 hints = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+half2 = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 k = capi.KernelLib()
 H, W = 185, 629
 rng = np.random.default_rng(1)
@@ -29,8 +30,12 @@ if kind == "block":
 else:
     plan = k.conv2d_plan(wt, bias, 32, 32, H, W, 3, 1, 1, act=capi.RT_ACT_ELU, has_residual=True)
 plan.set_pitch(640, 640)
+if half2:
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
 plan.set_layouts(1, 1, 1)
 x = torch.randn(b, 32, H, 640, device="cuda")
+if half2:
+    x = x.half()
 y = torch.empty_like(x)
 r = x if kind == "block" else torch.randn_like(x)
 for _ in range(3):
@@ -45,4 +50,4 @@ k.lib.rt_event_record(e1, None)
 torch.cuda.synchronize()
 ms = ctypes.c_float()
 k.lib.rt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-print("%s batch %d hints %d: %.2f us per launch (%d launches back to back)" % (kind, b, hints, ms.value * 1e3 / launches, launches))
+print("%s batch %d hints %d half2 %d: %.2f us per launch (%d launches back to back)" % (kind, b, hints, half2, ms.value * 1e3 / launches, launches))
