@@ -114,7 +114,7 @@ def measured_traffic(half2=False, fused=None):
     if not files:
         return None, None
     t = json.load(open(files[-1]))
-    if fused is not None and ("conv_s3rbs" in t.get("kernel", "")) != fused:
+    if fused is not None and ("conv_s3rb" in t.get("kernel", "")) != fused:
         return None, None                                   # the PMC pass was taken with the other kernel as the dominant one
     if t.get("sources_sha16") not in (None, kernel_sources_sha16()):
         return None, "%s is stale: taken on kernel sources %s, these are %s" % (os.path.relpath(files[-1], ROOT), t.get("sources_sha16"), kernel_sources_sha16())
@@ -531,7 +531,7 @@ def bench_2d_config(lib, dev, w, h, b, half2, nctx, spc, steps, warmup, sync):
         kernel = "conv_f16mma_kernel<3,3,1> 3x3 32->32 @%dx%d (+bias,+residual,+ELU), fp16 tensors and operands, fp32 accumulate" % (w2, h2)
     elif fused:
         unit_work, peak, unit, bound = 3.0 * 2.0 * layer_flops, MFMA_F16_PEAK_TFLOPS, "TFLOP/s", "mfma"
-        kernel = "conv_s3rbs_kernel: residual block @%dx%d in one launch (3 fp16 MFMA products per multiply)" % (w2, h2)
+        kernel = "conv_s3rbd_kernel / conv_s3rbs_kernel: residual block @%dx%d in one launch (3 fp16 MFMA products per multiply)" % (w2, h2)
     else:
         unit_work, peak, unit, bound = 4.0 * (3 * 32 * h2 * w2 + 32 * 32 * 9 + 32), HBM_PEAK_GBS, "GB/s", "hbm"
         kernel = "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @%dx%d (+bias,+residual,+ELU), fp32 tensors, 3-term fp16 split" % (w2, h2)

@@ -322,7 +322,8 @@ int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const v
  * factored form keeps four small maps per sample).  The caller owns it -- an execution context passes its workspace, as TensorRT hands a
  * plugin's getWorkspaceSize() bytes to enqueue (reference lib/conv3d_plugin.cpp:179-185, 187-190) -- so that contexts sharing a plan do
  * not share scratch: 16-byte aligned device memory of at least that size, private to the stream until the launches have run.
- * rt_conv_enqueue / _hint on such a plan use a block owned by the plan instead: one stream at a time. */
+ * rt_conv_enqueue / _hint on such a plan use blocks owned by the plan instead, one per stream they are called with (safe across streams;
+ * a block grows after its stream has drained, which a stream capture cannot record: capturing callers pass a workspace). */
 size_t rt_conv_plan_workspace_bytes(const rtConvPlan* plan, int batch);
 int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch, void* workspace,
                        size_t workspace_bytes, rtStream stream, int hints);

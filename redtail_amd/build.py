@@ -68,7 +68,14 @@ def check_no_packed_f32(lib):
         import check_no_packed_f32 as guard
     finally:
         sys.path.pop(0)
-    counts, bad, kernels = guard.check(lib)
+    try:
+        counts, bad, kernels = guard.check(lib)
+    except BaseException:
+        # a guard that could not run (missing llvm-objdump, a failed unbundle) must not leave an unchecked library behind: the next
+        # build would find it up to date and skip the check
+        if os.path.exists(lib):
+            os.remove(lib)
+        raise
     print("packed-fp32 guard: %d kernels, v_pk_{add,mul,fma}_f32 in %d allow-listed kernels, %d violations" % (kernels, len(counts) - len(bad), len(bad)))
     if bad:
         os.remove(lib)

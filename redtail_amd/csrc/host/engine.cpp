@@ -426,7 +426,7 @@ public:
     DataType getBindingDataType(int) const override { return DataType::kFLOAT; }
     int getMaxBatchSize() const override { return max_batch_; }
     int getNbLayers() const override { return (int)ops_.size(); }
-    std::size_t getWorkspaceSize() const override { return workspace_bytes_; }
+    std::size_t getWorkspaceSize() const override { return 2 * workspace_bytes_; }      // what a context allocates: one block per execution stream
     IHostMemory* serialize() const override;
     IExecutionContext* createExecutionContext() override {
         for (auto& l : layers_)

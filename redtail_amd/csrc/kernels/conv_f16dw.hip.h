@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
             prd = prd == NPB - 1 ? 0 : prd + 1;
             q++;
         }
-        if (t == D - 1) epilogue(std::integral_constant<int, A1>(), t, true);      // the volume's last slice has no slice behind it
+        // the volume's last slice has no slice behind it (only the segment that OWNS it stores it: a segment ending at D - 1 walks to input D - 1 too)
+        if (t == D - 1 && d1 == D) epilogue(std::integral_constant<int, A1>(), t, true);
     };
 
     init_acc(std::integral_constant<int, 0>());

@@ -297,18 +297,21 @@ template <bool FUSED, bool ISMIN, bool H2 = false, typename T = float>
 int launch_corr(const float* l, const float* r, float* out, int batch, int C, int H, int W, int D, int64_t obs,
                 hipStream_t st, int in_pitch = 0, int out_pitch = 0) {
     const int ip = in_pitch ? in_pitch : W, op = out_pitch ? out_pitch : W;
-    const int dt = std::min(16, rt::round_up((int)rt::cdiv(D, 4), 4));
+    // disparities per wave (4 waves per workgroup).  The volume-writing form splits a deep volume into blocks of 16 disparities, all in
+    // one launch (see corr_f32_kernel); the fused form keeps the whole depth in one workgroup (its soft-argmax reduces over it).
+    int dt = std::min(16, rt::round_up((int)rt::cdiv(D, 4), 4));
     if (FUSED && D > 4 * dt) return fail(RT_E_UNSUPPORTED, "fused corr+softargmax supports max_disp <= 64 (got %d)", D);
-    dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)batch);
-    for (int d_base = 0; d_base < D; d_base += 4 * dt) {
-        switch (dt) {
-            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
-        }
-        RT_LAUNCH_CHECK("corr cost volume kernel");
+    if (!FUSED && D > 16) dt = 4;
+    const int d_blocks = FUSED ? 1 : (int)rt::cdiv(D, 4 * dt);
+    RT_REQUIRE((int64_t)batch * d_blocks <= 65535, "corr cost volume: batch x disparity blocks exceeds the grid limit");
+    dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)(batch * d_blocks));
+    switch (dt) {
+        case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
+        case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
+        case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
+        default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
     }
+    RT_LAUNCH_CHECK("corr cost volume kernel");
     return 0;
 }
 }  // namespace
@@ -608,11 +611,10 @@ struct FoldFactor {
     int64_t a_elems = 0, c_elems = 0, t_elems = 0, e_elems = 0;      // per sample
     // Scratch (A, C', T, E: rt_conv_plan_workspace_bytes) belongs to the CALLER: an execution context passes its own workspace
     // (rt_conv_enqueue_ws; IPlugin::getWorkspaceSize / enqueue's `workspace`, as the reference's plugins receive theirs,
-    // lib/conv3d_plugin.cpp:179-185).  rt_conv_enqueue without one -- the operator-level tests and tools -- falls back to a block owned by
-    // the plan, ONE per plan: such callers drive a plan from one stream at a time.
+    // lib/conv3d_plugin.cpp:179-185).  rt_conv_enqueue without one -- the operator-level tests and tools -- falls back to blocks owned by
+    // the plan, one per STREAM it is enqueued on (launches of one stream are ordered; two streams never share scratch).
     std::mutex mu;
-    void* own = nullptr;
-    size_t own_bytes = 0;
+    std::map<rtStream, std::pair<void*, size_t>> own;      // the fallback blocks: one per stream the plan was enqueued on without a workspace
 };
 
 struct rtConvPlan {
@@ -1108,7 +1110,7 @@ void free_plan(rtConvPlan* p) {
         if (p->ff->pl) free_plan(p->ff->pl);
         if (p->ff->pr) free_plan(p->ff->pr);
         if (p->ff->wedge_dev) (void)hipFree(p->ff->wedge_dev);
-        if (p->ff->own) (void)hipFree(p->ff->own);
+        for (auto& kv : p->ff->own) if (kv.second.first) (void)hipFree(kv.second.first);
         delete p->ff;
     }
     if (p->bias_dev) (void)hipFree(p->bias_dev);
@@ -1573,14 +1575,23 @@ int enqueue_fold_factor(const rtConvPlan* plan, const void* x, void* y, int batc
     const SubConv& sc = plan->subs[0];
     const size_t need = fold_factor_bytes(plan, batch);
     float* buf = static_cast<float*>(ws);
-    if (!buf) {               // no caller workspace: the plan's own block (see FoldFactor)
+    if (!buf) {
+        // no caller workspace: a block owned by the plan, ONE PER STREAM (launches of one stream are ordered, so they may share scratch;
+        // two streams never do).  A block only grows, and only after the work its stream still has in flight on the old one is done;
+        // that wait and the allocation cannot be captured into a graph: a capturing caller brings its own workspace (rt_conv_enqueue_ws).
         std::lock_guard<std::mutex> lock(ff->mu);
-        if (ff->own_bytes < need) {
-            if (ff->own) { (void)hipDeviceSynchronize(); (void)hipFree(ff->own); ff->own = nullptr; ff->own_bytes = 0; }
-            if (hipMalloc(&ff->own, need) != hipSuccess) return fail(RT_E_NOMEM, "conv3d (factored cost volume): %zu bytes of scratch", need);
-            ff->own_bytes = need;
+        std::pair<void*, size_t>& blk = ff->own[s];
+        if (blk.second < need) {
+#ifndef HIPEMU
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(S(s), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+                return fail(RT_E_UNSUPPORTED, "conv3d (factored cost volume): the plan's own scratch cannot grow inside a stream capture -- pass a workspace (rt_conv_enqueue_ws)");
+#endif
+            if (blk.first) { (void)hipStreamSynchronize(S(s)); (void)hipFree(blk.first); blk = {nullptr, 0}; }
+            if (hipMalloc(&blk.first, need) != hipSuccess) { blk = {nullptr, 0}; return fail(RT_E_NOMEM, "conv3d (factored cost volume): %zu bytes of scratch", need); }
+            blk.second = need;
         }
-        buf = static_cast<float*>(ff->own);
+        buf = static_cast<float*>(blk.first);
     } else {
         RT_REQUIRE(ws_bytes >= need, "rt_conv_enqueue_ws: workspace of %zu bytes, the plan needs %zu for batch %d", ws_bytes, need, batch);
         RT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "rt_conv_enqueue_ws: workspace must be 16-byte aligned");

@@ -130,3 +130,17 @@ def synth_pair(h, w, seed=1234):
     right = np.where(valid[None], right, 0.0)
     # fancy indexing above leaves `right` in an HWC-strided layout: hand out dense CHW arrays
     return np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(right, dtype=np.float32)
+
+
+def synth_disparity(h, w):
+    """Ground truth of synth_pair: the disparity (in pixels) of every LEFT-image pixel.  synth_pair defines the field on the right view,
+    right[y, x] = left[y, x + d(y, x)]; a left pixel x_l is seen at the x_r with x_r + d(y, x_r) = x_l and its disparity is d(y, x_r) --
+    solved by fixed-point iteration (d is smooth, |dd/dx| < 0.05).  0 = no ground truth (the match falls outside the right image), the
+    KITTI convention (redtail_amd/kitti.py)."""
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    field = lambda x: (4 + 60 * (yy / h) + 8 * np.sin(2 * np.pi * x / w)) * (w / 1257.0)
+    d = field(xx.astype(np.float64))
+    for _ in range(30):
+        d = field(xx - d)
+    xr = xx - d
+    return np.where((xr >= 0) & (xr <= w - 1), d, 0.0).astype(np.float32)

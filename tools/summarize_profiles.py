@@ -24,7 +24,8 @@ DOMINANT = "conv_s3_kernel<3, 3, 1, ...>"
 
 
 def is_dom(name):
-    return name.startswith("conv_s3rbs_kernel") if FUSED else name.startswith("conv_s3_kernel<3, 3, 1,")
+    # (round 6: seven of a tower's eight blocks run conv_s3rbd_kernel -- pre-split tensors, LDS-DMA -- the first one conv_s3rbs_kernel)
+    return name.startswith(DOMINANT) if FUSED else name.startswith("conv_s3_kernel<3, 3, 1,")
 
 
 def kernel_sources_sha16(root):
@@ -55,14 +56,14 @@ def main():
     global FUSED, DOMINANT, DOMINANT_GRID, ALGO_READ, ALGO_WRITE, IMAGES
     run, tag = sys.argv[1], sys.argv[2]
     stats = open(os.path.join(run, "trace", "bench_kernel_stats.csv")).read()
-    if "conv_s3rbs_kernel" in stats:
-        FUSED, DOMINANT = True, "conv_s3rbs_kernel"
+    if "conv_s3rbs_kernel" in stats or "conv_s3rbd_kernel" in stats:
+        FUSED, DOMINANT = True, ("conv_s3rbd_kernel" if "conv_s3rbd_kernel" in stats else "conv_s3rbs_kernel")
         # the dominant launches are the largest grids of that kernel in the run: since round 3 a launch covers both towers (siamese
         # merge: grid z = 2) and walks 64-row segments in one-stream contexts, 32-row segments otherwise
         import re
         grids = collections.Counter()
         for r in csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))):
-            if short(r["Kernel_Name"]).startswith("conv_s3rbs_kernel"):
+            if short(r["Kernel_Name"]).startswith(DOMINANT):
                 grids[int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])] += 1
         DOMINANT_GRID = grids.most_common(1)[0][0]      # the timed configuration's (six one-stream contexts; the PMC passes run one such context)
         IMAGES = images = 2 if DOMINANT_GRID in (21 * 3 * 512 * 2, 21 * 6 * 512 * 2, 21 * 4 * 512 * 2, 21 * 2 * 512 * 2) else 1
