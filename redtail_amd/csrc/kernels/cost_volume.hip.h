@@ -45,7 +45,7 @@ __device__ static __forceinline__ float pack_half2(float lo, float hi) {
 template <int DT, bool FUSED, bool ISMIN, bool H2 = false, typename T = float>
 __global__ void __launch_bounds__(256)
 corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right, float* __restrict__ out, int C,
-                int H, int W, int D, int d_blocks, int64_t out_bstride, int in_pitch, int out_pitch) {
+                int H, int W, int D, int d_base, int64_t out_bstride, int in_pitch, int out_pitch) {
     constexpr int RY = kCorrRY, TX = kCorrTX, CC = kCorrCC, RS = kCorrRS;
     constexpr int DPAD = 4 * DT;          // disparities covered by the 4 waves of this workgroup
     constexpr int RW = DPAD + TX;         // R tile row width (floats), starts at x0 - d_base - DPAD + 1 - 1
@@ -59,11 +59,7 @@ corr_f32_kernel(const float* __restrict__ left, const float* __restrict__ right,
     const int tid = threadIdx.x;
     const int lane = tid & 63, dg = tid >> 6;
     const int r = lane >> 4, xg = lane & 15;
-    // grid.z = samples x blocks of DPAD disparities (round 6): a 4 x 128 tile over all 48 disparities of the Stereo DNN volume is 235
-    // workgroups -- one wave per SIMD, every load and LDS round trip exposed; three blocks of 16 disparities are 705 smaller workgroups
-    // (32 instead of 96 accumulators per lane), three per CU.  The tiles they share come from L2.  The fused form has one block.
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z / d_blocks;
-    const int d_base = (blockIdx.z - n * d_blocks) * DPAD;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * RY, n = blockIdx.z;
     const int64_t plane = (int64_t)H * in_pitch;         // row pitch >= W (dense: == W)
     const int cslots = H2 ? (C + 1) / 2 : C;              // planes per sample
     const T* __restrict__ lb = reinterpret_cast<const T*>(left) + (int64_t)n * cslots * plane;

@@ -297,21 +297,18 @@ template <bool FUSED, bool ISMIN, bool H2 = false, typename T = float>
 int launch_corr(const float* l, const float* r, float* out, int batch, int C, int H, int W, int D, int64_t obs,
                 hipStream_t st, int in_pitch = 0, int out_pitch = 0) {
     const int ip = in_pitch ? in_pitch : W, op = out_pitch ? out_pitch : W;
-    // disparities per wave (4 waves per workgroup).  The volume-writing form splits a deep volume into blocks of 16 disparities, all in
-    // one launch (see corr_f32_kernel); the fused form keeps the whole depth in one workgroup (its soft-argmax reduces over it).
-    int dt = std::min(16, rt::round_up((int)rt::cdiv(D, 4), 4));
+    const int dt = std::min(16, rt::round_up((int)rt::cdiv(D, 4), 4));
     if (FUSED && D > 4 * dt) return fail(RT_E_UNSUPPORTED, "fused corr+softargmax supports max_disp <= 64 (got %d)", D);
-    if (!FUSED && D > 16) dt = 4;
-    const int d_blocks = FUSED ? 1 : (int)rt::cdiv(D, 4 * dt);
-    RT_REQUIRE((int64_t)batch * d_blocks <= 65535, "corr cost volume: batch x disparity blocks exceeds the grid limit");
-    dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)(batch * d_blocks));
-    switch (dt) {
-        case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
-        case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
-        case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
-        default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_blocks, obs, ip, op); break;
+    dim3 grid((unsigned)rt::cdiv(W, rt::kCorrTX), (unsigned)rt::cdiv(H, rt::kCorrRY), (unsigned)batch);
+    for (int d_base = 0; d_base < D; d_base += 4 * dt) {
+        switch (dt) {
+            case 4: hipLaunchKernelGGL((rt::corr_f32_kernel<4, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 8: hipLaunchKernelGGL((rt::corr_f32_kernel<8, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            case 12: hipLaunchKernelGGL((rt::corr_f32_kernel<12, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+            default: hipLaunchKernelGGL((rt::corr_f32_kernel<16, FUSED, ISMIN, H2, T>), grid, dim3(256), 0, st, l, r, out, C, H, W, D, d_base, obs, ip, op); break;
+        }
+        RT_LAUNCH_CHECK("corr cost volume kernel");
     }
-    RT_LAUNCH_CHECK("corr cost volume kernel");
     return 0;
 }
 }  // namespace

@@ -67,10 +67,17 @@ def test_fp16_accuracy_guard_on_synthetic_ground_truth():
         torch.cuda.synchronize()
         maps[name] = out.cpu().numpy()[:, 0] * w          # the network's output is disparity / width (sample_app/main.cpp:325-327)
         net.destroy()
-    d1 = {k: float(np.mean([kitti.d1_all(m[i], gt) for i in range(n)])) for k, m in maps.items()}
+    # The trained network is no geometric estimator on these random textures: its disparity is a constant ~2.05 x the warp's (measured,
+    # every row and seed; the oracle says the same).  One scalar, fitted on the fp32 engine and applied to both, takes that out; what is
+    # guarded is the DIFFERENCE half2 makes: to D1 against the ground truth, and as D1 of half2 against the fp32 engine's own map.
+    valid = gt > 0
+    scale = float(np.median(maps["fp32"][:, valid] / gt[valid]))
+    d1 = {k: float(np.mean([kitti.d1_all(m[i] / scale, gt) for i in range(n)])) for k, m in maps.items()}
+    d1_rel = float(np.mean([kitti.d1_all(maps["half2"][i], np.where(valid, maps["fp32"][i], 0.0)) for i in range(n)]))
     diff = np.abs(maps["half2"] - maps["fp32"])
-    print("D1-all on synthetic ground truth, ResNet-18 2D 1257x369, 8 seeds: fp32 %.3f %%, half2 %.3f %%; |half2 - fp32| mean %.4f px, max %.3f px"
-          % (d1["fp32"], d1["half2"], diff.mean(), diff.max()))
+    print("D1-all on synthetic ground truth (network output / %.3f), ResNet-18 2D 1257x369, 8 seeds: fp32 %.3f %%, half2 %.3f %%; half2 against the fp32 "
+          "engine: D1 %.4f %%, |difference| mean %.4f px, max %.3f px" % (scale, d1["fp32"], d1["half2"], d1_rel, diff.mean(), diff.max()))
     assert not np.isnan(maps["fp32"]).any() and not np.isnan(maps["half2"]).any()
     assert abs(d1["half2"] - d1["fp32"]) <= 0.1, d1
+    assert d1_rel <= 0.1, d1_rel
     assert diff.mean() <= 0.05, diff.mean()
