@@ -569,7 +569,7 @@ def secondary_lines(lib, dev):
         line["wall_s"] = time.perf_counter() - t0
         out.append(line)
 
-    add("C3: ResNet-18 2D half2, 1257x369, batch 8", lambda: bench_2d_config(lib, dev, W, H, 8, True, 4, 2, 32, 8, False))
+    add("C3: ResNet-18 2D half2, 1257x369, batch 8", lambda: bench_2d_config(lib, dev, W, H, 8, True, 6, 1, 32, 8, False))
     add("ref513: ResNet-18 2D fp32, 513x257, batch 1, one context, synchronous (the reference's published configuration: stereoDNN/README.md:31)",
         lambda: bench_2d_config(lib, dev, 513, 257, 1, False, 1, 2, 100, 20, True))
 
@@ -659,7 +659,7 @@ def main():
                          "1948 / 2015 pairs/s after 5 / 20 / 100 warm-up steps).  0 = off; reported on the JSON line")
     args = ap.parse_args()
     if args.contexts <= 0:
-        args.contexts = 4 if args.half2 else 6
+        args.contexts = 6       # (half2: four two-stream contexts until round 6; with the tower blocks fused, 6 x 1: 6060 against 5634 pairs/s at batch 8)
 
     # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU through
     # torch.distributed.run on 127.0.0.1, exactly the command the driver uses -- instead of silently timing one GPU.
@@ -760,7 +760,7 @@ def main():
             blob = nets[0].weights_image()                      # (value_exact_fp32 etc. only run on one rank; kept for symmetry)
 
     net = nets[0]
-    spc = args.streams_per_context or (1 if (args.contexts > 1 and not args.half2) else 2)      # half2: 3978 (4 x 2) vs 3881 (6 x 1) pairs/s at batch 8
+    spc = args.streams_per_context or (1 if args.contexts > 1 else 2)      # (round 5, half2 layer by layer: 3978 (4 x 2) vs 3881 (6 x 1) pairs/s at batch 8; fused blocks: 5634 vs 6060)
     for n_ in nets:
         n_.set_streams(spc)
 

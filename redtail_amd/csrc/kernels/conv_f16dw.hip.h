@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(2) conv_f16dw_kernel(Conv
                 }
                 if constexpr (ELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : fast_exp(v[e]) - 1.f;
+                    for (int e = 0; e < 4; e++) v[e] = elu_fast(v[e]);
                 }
                 u32x2_t o;
 #pragma unroll

@@ -37,6 +37,19 @@ struct F16RBDCfg {
 
 // 128 registers and 71 KB of LDS: TWO workgroups per CU, four waves per SIMD -- a wave's 18 MFMAs of a row are one dependent chain (the
 // order of summation of the layer-by-layer kernel), and what hides that chain's latency is other waves.
+// element J of a packed fp16 pair + an fp32 value
+template <int J>
+__device__ static __forceinline__ float rbh_add16(unsigned h2, float b) {
+#ifdef HIPEMU
+    return b + (float)__builtin_bit_cast(_Float16, (unsigned short)(h2 >> (16 * J)));
+#else
+    float r;
+    if (J == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(b));
+    return r;
+#endif
+}
+
 __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(4) conv_f16rbd_kernel(RBArgs a) {
     using Cfg = F16RBDCfg;
     const ConvArgs& p = a.c;
@@ -238,8 +251,10 @@ __global__ void __launch_bounds__(512) RT_WAVES_PER_EU(4) conv_f16rbd_kernel(RBA
                 for (int g = 0; g < 2; g++) {
                     const u32x4_t sk = *reinterpret_cast<const u32x4_t*>(xs + g * (2 * GXB));
 #pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        init[8 * g + e] = biasv[8 * g + e] + (float)__builtin_bit_cast(_Float16, (unsigned short)(sk[e >> 1] >> (16 * (e & 1))));
+                    for (int e = 0; e < 4; e++) {       // bias + x: one v_fma_mix_f32 per value (x * 1 + bias, rounded once like the addition)
+                        init[8 * g + 2 * e] = rbh_add16<0>(sk[e], biasv[8 * g + 2 * e]);
+                        init[8 * g + 2 * e + 1] = rbh_add16<1>(sk[e], biasv[8 * g + 2 * e + 1]);
+                    }
                 }
                 acc = contract(std::false_type(), (4 * s + wr + 4) % RT, init);
                 prow = (row >= y0 && row < y1) ? row : -1;

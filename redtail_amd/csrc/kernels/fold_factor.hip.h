@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) fold_combine_kernel(FoldFactorArgs p) {
             if (kFoldAbl & 2) {
             } else if (elu) {
 #pragma unroll
-                for (int g = 0; g < G; g++) o[g] = o[g] > 0.f ? o[g] : fast_exp(o[g]) - 1.f;
+                for (int g = 0; g < G; g++) o[g] = elu_fast(o[g]);
             } else {
 #pragma unroll
                 for (int g = 0; g < G; g++) o[g] = apply_act_fast(o[g], act);

@@ -374,9 +374,10 @@ def test_split_resblock_presplit_tensors(backend, h, w, batch, pitch, x_split, y
             out = out[..., :w]
         outs.append(out)
     plan.destroy()
-    assert np.abs(outs[0] - ref).max() <= 6e-6, np.abs(outs[0] - ref).max()
+    # (fp32 accumulation of 2 x 288 products: relative to the largest value, which reaches 5 .. 10 on this data)
+    assert np.abs(outs[0] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), np.abs(outs[0] - ref).max()
     # the fp32-tensor form of the same block: same arithmetic up to the order of summation and the 22-bit input / output
-    assert np.abs(outs[0] - outs[1]).max() <= 1e-5, np.abs(outs[0] - outs[1]).max()
+    assert np.abs(outs[0] - outs[1]).max() <= 3e-6 * max(1.0, np.abs(ref).max()), np.abs(outs[0] - outs[1]).max()
 
 
 def test_split_resblock_refuses_presplit_tensors_where_it_has_no_kernel(backend):
