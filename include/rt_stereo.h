@@ -318,6 +318,13 @@ int rt_conv_enqueue(const rtConvPlan* plan, const void* x, void* y, const void* 
 #define RT_HINT_THROUGHPUT 1
 int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch,
                          rtStream stream, int hints);
+/* The first layer of both feature towers in one launch: samples 0 .. batch - 1 from x (left images), batch .. 2 batch - 1 from x2 (right
+ * images -- the reference's two input bindings, sample_app/main.cpp:290-300), y = 2 * batch samples.  The towers share their weights, so
+ * this is the [left | right] launch the executor makes of every tower layer; only first-layer plans (5x5 stride 2, <= 3 input channels,
+ * rt_conv_plan_supports_twin_input) have it. */
+int rt_conv_plan_supports_twin_input(const rtConvPlan* plan);
+int rt_conv_enqueue_twin_input(const rtConvPlan* plan, const void* x, const void* x2, void* y, int batch, rtStream stream, int hints);
+
 /* Scratch a plan's launches need for `batch` samples, in bytes (0 for most plans; the first Conv3D over a folded cost volume in its
  * factored form keeps four small maps per sample).  The caller owns it -- an execution context passes its workspace, as TensorRT hands a
  * plugin's getWorkspaceSize() bytes to enqueue (reference lib/conv3d_plugin.cpp:179-185, 187-190) -- so that contexts sharing a plan do

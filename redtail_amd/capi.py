@@ -99,6 +99,8 @@ KERNEL_SYMBOLS = {
     "rt_conv_plan_supports_il8": (c_int, [c_void_p]),
     "rt_conv_plan_set_layouts": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rt_conv_plan_set_softarg": (c_int, [c_void_p, c_int]),
+    "rt_conv_plan_supports_twin_input": (c_int, [c_void_p]),
+    "rt_conv_enqueue_twin_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "rt_resblock_plan_supports_split": (c_int, [c_void_p]),
     "rt_resblock_plan_set_split": (c_int, [c_void_p, c_int, c_int]),
     "rt_conv_enqueue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -308,6 +310,10 @@ class ConvPlan:
     def set_layouts(self, x_il8, y_il8, r_il8=False):
         """channel-interleaved (C/8, H, pitch, 8) fp16 tensors: input / output / residual"""
         self.klib.check(self.klib.lib.rt_conv_plan_set_layouts(self.handle, int(x_il8), int(y_il8), int(r_il8)), "rt_conv_plan_set_layouts")
+
+    def enqueue_twin_input(self, x, x2, y, batch=1, stream=None, hints=0):
+        """first layer of both towers: samples [0, batch) from x, [batch, 2 batch) from x2"""
+        self.klib.check(self.klib.lib.rt_conv_enqueue_twin_input(self.handle, _ptr(x), _ptr(x2), _ptr(y), batch, stream, hints), "rt_conv_enqueue_twin_input")
 
     def supports_split(self):
         return bool(self.klib.lib.rt_resblock_plan_supports_split(self.handle))

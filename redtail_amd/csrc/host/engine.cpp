@@ -335,6 +335,7 @@ struct Op {
     bool twin = false;
     std::vector<int> twin_in;          // right-tower tensors it reads (inputs, residual): dependencies for the stream schedule
     int twin_out = -1;                 // right-tower tensor it writes
+    bool twin_bind = false;            // ... whose INPUT is the other input binding (first layers: rt_conv_enqueue_twin_input), not a twin-placed tensor
 };
 
 class EngineImpl;
@@ -1272,19 +1273,25 @@ void EngineImpl::mergeSiamese() {
         }
         if (ib < 0) continue;
         const Op& b = ops_[ib];
+        // the towers' first layers read the two input bindings (through the identity scale layers of the generated networks: aliases) --
+        // separate buffers of the caller: the first-layer kernels take both pointers (round 6), everything else needs its inputs placed
+        // behind one another
+        const bool from_bindings = root(a.in[0]) == ins[0] && root(b.in[0]) == ins[1] && a.resid < 0 && !knob("RT_NO_TWIN_INPUT") &&
+                                   tensors_[a.in[0]]->alias_off == 0 && tensors_[b.in[0]]->alias_off == 0 && rt_conv_plan_supports_twin_input(a.plan) != 0;
         // the tensors as the ops see them (a tensor the op reads through an alias chain must be the plain buffer itself)
-        if (root(a.in[0]) != a.in[0] || root(b.in[0]) != b.in[0] || root(a.out) != a.out || root(b.out) != b.out) continue;
+        if ((!from_bindings && (root(a.in[0]) != a.in[0] || root(b.in[0]) != b.in[0])) || root(a.out) != a.out || root(b.out) != b.out) continue;
         if ((a.resid >= 0) != (b.resid >= 0) || (a.resid >= 0 && (root(a.resid) != a.resid || root(b.resid) != b.resid))) continue;
         auto ok_pair = [&](int l, int r) {       // already placed together, or can be
             return l >= 0 && r >= 0 && ((tensors_[r]->twin_of == l && tensors_[l]->has_twin) || pairable(l, r));
         };
-        if (!ok_pair(a.in[0], b.in[0]) || !ok_pair(a.out, b.out) || (a.resid >= 0 && !ok_pair(a.resid, b.resid))) continue;
+        if (!(from_bindings || ok_pair(a.in[0], b.in[0])) || !ok_pair(a.out, b.out) || (a.resid >= 0 && !ok_pair(a.resid, b.resid))) continue;
         auto place = [&](int l, int r) {
             tensors_[r]->twin_of = l;
             tensors_[l]->has_twin = true;
             tensors_[r]->cpad = tensors_[l]->cpad;         // same sample size as its twin (the host of an interleaved concatenation)
         };
-        place(a.in[0], b.in[0]);
+        if (!from_bindings) place(a.in[0], b.in[0]);
+        a.twin_bind = from_bindings;
         place(a.out, b.out);
         if (a.resid >= 0) place(a.resid, b.resid);
         a.twin = true;
@@ -2161,8 +2168,12 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
         switch (op.kind) {
             case OpKind::kConv:
                 // a merged siamese launch covers the left samples and, right behind them, the right samples
-                rc = rt_conv_enqueue_hint(op.plan, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,
-                                          op.twin ? 2 * batch : batch, st, streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
+                if (op.twin_bind)       // first layers of both towers: left images | right images from their own bindings
+                    rc = rt_conv_enqueue_twin_input(op.plan, addr(op.in[0], batch, bindings), addr(op.twin_in[0], batch, bindings), y, batch, st,
+                                                    streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
+                else
+                    rc = rt_conv_enqueue_hint(op.plan, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,
+                                              op.twin ? 2 * batch : batch, st, streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
                 break;
             case OpKind::kConv3D:
                 rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(8) conv_f16_first_kernel(
     }
 
     // ---- gather: fp32 image -> fp16 patch [row][col][channel]; a lane takes a column pair of one channel ------------
-    const buf_rsrc rs_x = make_buf(p.x + (int64_t)n * p.x_bstride);
+    const buf_rsrc rs_x = make_buf((p.x2 && n >= p.x2_from) ? p.x2 + (int64_t)(n - p.x2_from) * p.x_bstride : p.x + (int64_t)n * p.x_bstride);
     const int ix0 = tx0 * S - p.pad_x, iy0 = ty0 * S - p.pad_y;
 #pragma unroll
     for (int k = 0; k < Cfg::NK; k++) {

@@ -97,6 +97,11 @@ struct ConvArgs {
     // conv_f16dw_kernel / conv_s3dw_kernel (depth-walking Conv3D, conv_f16dw.hip.h): output slices per depth segment, segments per tile
     // pair, 16-channel chunks per input slice (C / 16), image tiles per sample (tiles_x * tiles_y of 12 x 32 pixels)
     int dw_seg, dw_nseg, dw_cpc, dw_ntiles;
+    // first layers (conv_s3_first_kernel, conv_f16_first_kernel): samples n >= x2_from are read from x2 (sample n - x2_from) -- the left and
+    // the right image of a stereo pair are two bindings, and one launch over [left samples | right samples] serves both towers' first layer
+    // (rt_conv_enqueue_twin_input).  x2 == nullptr: off.
+    const float* x2;
+    int x2_from;
 };
 
 // workgroup -> (tile of the output plane, z-slice, sample)

@@ -2494,6 +2494,23 @@ extern "C" int rt_conv_enqueue_hint(const rtConvPlan* plan, const void* x, void*
     return rt_conv_enqueue_ws(plan, x, y, residual, batch, nullptr, 0, s, hints);
 }
 
+// The first layer of BOTH feature towers in one launch: samples 0 .. batch - 1 are read from x (the left images), samples batch .. 2 batch - 1
+// from x2 (the right images, a separate binding: reference sample_app/main.cpp:290-300), y holds 2 * batch samples.  The towers share their
+// weights (resnet18_2D_513x257_net.cpp:48-64 / 320-336 read the same tensors), so this is the launch over [left | right] the executor's
+// siamese merge makes of every other tower layer.  Only the first-layer kernels have the form (5x5 stride 2 on <= 3 channels).
+namespace { thread_local const void* tl_twin_x2 = nullptr; thread_local int tl_twin_from = 0; }
+extern "C" int rt_conv_plan_supports_twin_input(const rtConvPlan* plan) {
+    return plan && plan->subs.size() == 1 && (plan->subs[0].s3first || plan->subs[0].f16first) && !plan->has_resid && env_int("RT_NO_TWIN_INPUT", 0) == 0;
+}
+extern "C" int rt_conv_enqueue_twin_input(const rtConvPlan* plan, const void* x, const void* x2, void* y, int batch, rtStream s, int hints) {
+    RT_REQUIRE(plan && x && x2 && y && batch > 0, "rt_conv_enqueue_twin_input: bad arguments");
+    if (!rt_conv_plan_supports_twin_input(plan)) return fail(RT_E_UNSUPPORTED, "rt_conv_enqueue_twin_input: only the first-layer kernels read two input tensors");
+    tl_twin_x2 = x2; tl_twin_from = batch;
+    const int rc = rt_conv_enqueue_ws(plan, x, y, nullptr, 2 * batch, nullptr, 0, s, hints);
+    tl_twin_x2 = nullptr; tl_twin_from = 0;
+    return rc;
+}
+
 extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y, const void* residual, int batch, void* workspace,
                                   size_t workspace_bytes, rtStream s, int hints) {
     RT_REQUIRE(plan && x && y, "rt_conv_enqueue: null pointer");
@@ -2583,6 +2600,7 @@ extern "C" int rt_conv_enqueue_ws(const rtConvPlan* plan, const void* x, void* y
         rt::ConvArgs a;
         a.z_inner = 0; a.nb_inner = 0;
         a.x = static_cast<const float*>(x);
+        a.x2 = static_cast<const float*>(tl_twin_x2); a.x2_from = tl_twin_from;      // rt_conv_enqueue_twin_input (first layers only)
         a.y = static_cast<float*>(y);
         a.w = sc.w_dev;
         a.bias = plan->bias_dev;

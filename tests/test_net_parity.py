@@ -89,13 +89,13 @@ def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
     w = O.synth_weights_resnet18_2d()
     l, r = pairs(1 if rt.kind == "emu" else 2, 41, 73)          # (one pair on the emulator: CPU tier time)
     base, (_, launches0) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-    assert launches0 == 48 - 17                            # siamese merge: 16 block convolutions + encoder2D_out of the two towers pair up
+    assert launches0 == 48 - 18                            # siamese merge: 16 block convolutions + encoder2D_out + (round 6) the first layers of the two towers pair up
     monkeypatch.setenv("RT_RB", "1")
     for seg in ("16", "32"):
         monkeypatch.setenv("RT_RBS_SEG", seg)
         out, (layers, launches) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
         # 16 blocks, two launches -> one; blocks 1-8 + encoder2D_out: two towers -> one
-        assert launches == 48 - 16 - 9
+        assert launches == 48 - 16 - 10
         assert not np.isnan(out).any()
         assert np.abs(out - base).max() <= 2e-5, np.abs(out - base).max()
     with torch.no_grad():
@@ -142,7 +142,7 @@ def test_resnet18_2d_siamese_merge_is_bit_identical(rt, monkeypatch):
     with torch.no_grad():
         ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w2, max_disp=8).numpy()
     assert np.abs(out - ref).max() <= 2e-4
-    assert launches == 48 - 4                              # only blocks 1 and 2 (before the differing layer) pair up: twins need twin inputs
+    assert launches == 48 - 5                              # only the first layers and blocks 1 and 2 (before the differing layer) pair up: twins need twin inputs
 
 
 @pytest.mark.parametrize("ksplit", [None, "0"])
@@ -423,7 +423,8 @@ def test_resnet18_2d_full_size(w, h, batch):
     # at 1257x369 the executor runs the 16 residual blocks as one (streaming) launch each (48 -> 32) and blocks 1-8 + encoder2D_out of
     # the two towers as one launch over both images (siamese merge: 32 -> 23; round 3: 25, the left tower's first block read a planar member
     # of conv2D_1's concatenation); at 513x257 no block is fused (too few strips) and the 16 block convolutions + encoder2D_out pair up (48 -> 31)
-    assert net.num_launches == (23 if w >= 1241 else 31), net.num_launches
+    # (round 6: the towers' first layers read the two bindings in one launch too: 22 / 30)
+    assert net.num_launches == (22 if w >= 1241 else 30), net.num_launches
     net.destroy()
 
 
@@ -684,7 +685,8 @@ def test_resnet18_2d_interleaved_equals_planar(rt, monkeypatch):
     il, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
     monkeypatch.setenv("RT_NO_IL8", "1")
     planar, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8)
-    assert n1 == n2 - 2       # (interleaved, the first member of conv2D_1's concatenation is a plain tensor: the left tower's first block merges too)
+    assert n1 == n2 - 3       # (interleaved, the first member of conv2D_1's concatenation is a plain tensor: the left tower's first block merges too,
+                              #  and -- round 6 -- so do the towers' first layers, whose outputs then pair up)
     assert np.abs(il - planar).max() <= 2e-6         # bit-identical convolutions; the correlation kernel differs (see above)
 
 
@@ -703,7 +705,7 @@ def test_development_knobs_need_opt_in(tmp_path):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         counts[dev] = int(out.stdout.split("LAUNCHES")[1].split()[0])
-    assert counts["0"] == 48 - 17 and counts["1"] > 100, counts      # ignored / honoured (one launch per layer)
+    assert counts["0"] == 48 - 18 and counts["1"] > 100, counts      # ignored / honoured (one launch per layer)
 
 
 def test_exact_fp32_is_an_api_option(rt, monkeypatch):
