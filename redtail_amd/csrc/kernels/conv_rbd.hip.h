@@ -67,7 +67,7 @@ __device__ static __forceinline__ float rbd_join(unsigned hi2, unsigned lo2, flo
 #endif
 }
 
-__device__ static __forceinline__ float rbd_elu(float v) { return elu_fast(v); }        // common.hip.h: ELU as a median
+__device__ static __forceinline__ float rbd_elu(float v) { return elu_fast(v); }        // common.hip.h
 
 // development switches (tools/r06/rbd_dev.sh builds variants; the product has the defaults)
 #ifndef RT_RBD_PRIO
