@@ -36,6 +36,12 @@ plan.set_layouts(1, 1, 1)
 x = torch.randn(b, 32, H, 640, device="cuda")
 if half2:
     x = x.half()
+elif kind == "block" and plan.supports_split() and not os.environ.get("ISO_NO_SPLIT"):
+    # the typical tower block reads and writes pre-split tensors (conv_s3rbd_kernel): (C/8, H, pitch, [8 hi | 8 lo]) fp16 pairs
+    plan.set_split(1, 1)
+    g = x.reshape(b, 4, 8, H, 640).permute(0, 1, 3, 4, 2)
+    hi = g.half()
+    x = torch.cat([hi, ((g - hi.float()) * 2048.0).half()], dim=-1).contiguous().view(torch.float32)
 y = torch.empty_like(x)
 r = x if kind == "block" else torch.randn_like(x)
 for _ in range(3):
