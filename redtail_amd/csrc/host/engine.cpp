@@ -892,8 +892,9 @@ void EngineImpl::assignPitch() {
     std::vector<char> il(tensors_.size(), 0);
     auto corr_takes_il = [&](const Op& op) {        // fused correlation + soft-argmax on the matrix cores (corr_mfma.hip.h)
         const Dims& f = tensors_[op.in[0]]->dims;
-        return op.kind == OpKind::kCorrSoftargmax && !f16 && f.d[0] % 4 == 0 && f.d[0] <= 32 && op.max_disp <= 64 &&
-               !knob("RT_NO_CORR_MFMA") && !knob("RT_NO_IL8");
+        // (half2 mode, round 6: fp16 maps in groups of 8 channels, corr_softargmax_mfma_f16_kernel -- the map stays an fp16 plane)
+        return op.kind == OpKind::kCorrSoftargmax && f.d[0] % (f16 ? 8 : 4) == 0 && f.d[0] <= 32 && op.max_disp <= 64 &&
+               !knob("RT_NO_CORR_MFMA") && !knob("RT_NO_IL8") && !(f16 && knob("RT_NO_CORR_MFMA_F16"));
     };
     // A concatenation that foldConcats() will fold can stay interleaved (fp32): every member but the last holds whole groups of 4
     // channels, the last one is padded to a group -- the 33-channel input of conv2D_1 is the 8 groups of left_conv1_act and a ninth
@@ -2224,7 +2225,10 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
             }
             case OpKind::kCorrSoftargmax: {
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
-                if (op.il_in)
+                if (op.il_in && eng_.tensors_[op.in[0]]->f16)
+                    rc = rt_corr_softargmax_il8_f16(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1], f.d[2],
+                                                    op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride, st);
+                else if (op.il_in)
                     rc = rt_corr_softargmax_il_slot(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
                                                     f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride,
                                                     op.il_out ? 4 : 1, st);

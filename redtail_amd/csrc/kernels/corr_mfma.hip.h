@@ -35,6 +35,96 @@ struct CorrMfmaArgs {
                                          // group (H, out_pitch, 4) -- the other three lanes are written as zeros
 };
 
+// half2 mode (round 6): fp16 feature maps, channel-interleaved (C/8, H, pitch, 8) -- the stored values ARE the operands: one 16-byte
+// load per pixel and 16-channel half-chunk, ONE MFMA per block and chunk (fp32 accumulation of exact fp16 products, what the planar fp16
+// kernel computes on the vector ALU), the map written as an fp16 plane.  Same Gram-band formulation and online soft-argmax as below.
+template <bool ISMIN>
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_f16_kernel(CorrMfmaArgs p) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t task = (int64_t)blockIdx.x * 4 + wv;
+    const int per_row = p.blocks_x;
+    const int64_t total = (int64_t)per_row * p.H * p.batch;
+    if (task >= total) return;
+    const int bx = (int)(task % per_row);
+    const int y = (int)((task / per_row) % p.H);
+    const int n = (int)(task / ((int64_t)per_row * p.H));
+    const int x0 = bx * 32;
+    const buf_rsrc rs_l = make_buf(elem_ptr(p.left, (int64_t)n * p.in_bstride, 2));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.right, (int64_t)n * p.in_bstride, 2));
+    const unsigned gstride = (unsigned)(8 * p.H * p.in_pitch) * 2u;        // bytes between groups of 8 channels
+    const int nchunks = (p.C + 15) / 16;
+    // operand of lane (pixel px, k-group kg), chunk c: channel group 2 c + kg of that pixel
+    auto load_px = [&](const buf_rsrc& rs, int px, f16x8 (&v)[2]) {
+        const bool ok = px >= 0 && px < p.W;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int g = 2 * c + kg;
+            v[c] = __builtin_bit_cast(f16x8, buf_load4(rs, (ok && c < nchunks && 8 * g < p.C) ? (unsigned)g * gstride + (unsigned)(y * p.in_pitch + px) * 16u : kBufOOB, 0u));
+        }
+    };
+    f16x8 lh[2], rh[3][2];
+    load_px(rs_l, x0 + l31, lh);
+#pragma unroll
+    for (int j = 0; j < 3; j++) load_px(rs_r, x0 - 64 + 32 * j + l31, rh[j]);
+    constexpr float kL2E = 1.44269504088896341f;
+    const bool d_ge32 = p.D >= 32;
+    float m_run = -1e30f, s_run = 0.f, w_run = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; c++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[j][c], lh[c], acc, 0, 0, 0);
+        const int dj = l31 + 64 - 32 * j - 4 * kg;
+        float v[16];
+        float bm = -1e30f;
+        auto gather = [&](auto lo_check, auto hi_check) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const float val = ISMIN ? -acc[r] : acc[r];
+                bool ok = true;
+                if constexpr (decltype(lo_check)::value) ok = ok && cr <= dj;             // d >= 0
+                if constexpr (decltype(hi_check)::value) ok = ok && dj - cr < p.D;        // d < D
+                v[r] = ok ? val : -1e30f;
+                bm = fmaxf(bm, v[r]);
+            }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (j == 2) {
+            if (d_ge32) gather(T_{}, F_{}); else gather(T_{}, T_{});
+        } else {
+            gather(F_{}, T_{});
+        }
+        const float m_new = fmaxf(m_run, bm);
+        const float sc = __builtin_amdgcn_exp2f((m_run - m_new) * kL2E);
+        const float mL = m_new < -1e29f ? 0.f : -m_new * kL2E;
+        float s_blk = 0.f, c_blk = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float cr = (float)((r & 3) + 8 * (r >> 2));
+            const float e = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, mL));
+            s_blk += e;
+            c_blk = fmaf(e, cr, c_blk);
+        }
+        s_run = fmaf(s_run, sc, s_blk);
+        w_run = fmaf(w_run, sc, fmaf((float)dj, s_blk, -c_blk));
+        m_run = m_new;
+    }
+    const float m2 = __shfl_xor(m_run, 32), s2 = __shfl_xor(s_run, 32), w2 = __shfl_xor(w_run, 32);
+    const float M = fmaxf(m_run, m2);
+    const float e1 = fast_exp(m_run - M), e2 = fast_exp(m2 - M);
+    const float s = s_run * e1 + s2 * e2, w = w_run * e1 + w2 * e2;
+    const int x = x0 + l31;
+    if (kg == 0 && x < p.W)
+        reinterpret_cast<_Float16*>(p.out)[(int64_t)n * p.out_bstride + (int64_t)y * p.out_pitch + x] = (_Float16)(w / s);
+}
+
 __device__ static __forceinline__ void corr_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
     const S3Split s0 = s3_split(a), s1 = s3_split(b);
 #pragma unroll

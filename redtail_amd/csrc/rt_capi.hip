@@ -378,6 +378,31 @@ extern "C" int rt_corr_softargmax_il_slot(const void* left, const void* right, v
     return 0;
 }
 
+// half2 mode: fp16 channel-interleaved feature maps (C/8, H, pitch, 8), fp16 map out (plane, out_pitch) -- corr_softargmax_mfma_f16_kernel
+extern "C" int rt_corr_softargmax_il8_f16(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
+                                          int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream s) {
+    RT_REQUIRE(left && right && out, "rt_corr_softargmax_il8_f16: null pointer");
+    RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax_il8_f16: bad dims");
+    if (C % 8 != 0 || C > 32 || D > 64) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_il8_f16: C must be a multiple of 8 up to 32 and max_disp <= 64 (C %d, D %d)", C, D);
+    RT_REQUIRE((in_pitch == 0 || in_pitch >= W) && (out_pitch == 0 || out_pitch >= W), "rt_corr_softargmax_il8_f16: pitch smaller than the row");
+    rt::CorrMfmaArgs a;
+    a.left = static_cast<const float*>(left); a.right = static_cast<const float*>(right); a.out = static_cast<float*>(out);
+    a.C = C; a.H = H; a.W = W; a.D = D;
+    a.in_pitch = in_pitch ? in_pitch : W; a.out_pitch = out_pitch ? out_pitch : W;
+    a.in_bstride = (int64_t)C * H * a.in_pitch;
+    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch;
+    a.out_slot = 1;
+    RT_REQUIRE(a.in_bstride < (1ll << 30), "rt_corr_softargmax_il8_f16: sample exceeds 2 GB (32-bit buffer offsets)");
+    a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
+    const int64_t tasks = (int64_t)a.blocks_x * H * batch;
+    RT_REQUIRE(rt::cdiv(tasks, 4) < (1ll << 31), "rt_corr_softargmax_il8_f16: grid too large");
+    dim3 grid((unsigned)rt::cdiv(tasks, 4));
+    if (is_min) hipLaunchKernelGGL((rt::corr_softargmax_mfma_f16_kernel<true>), grid, dim3(256), 0, S(s), a);
+    else hipLaunchKernelGGL((rt::corr_softargmax_mfma_f16_kernel<false>), grid, dim3(256), 0, S(s), a);
+    RT_LAUNCH_CHECK("corr_softargmax_mfma_f16_kernel");
+    return 0;
+}
+
 extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,
                                   int D, int is_min, int64_t out_bstride, int dtype, rtStream s) {
     RT_REQUIRE(left && right && out, "rt_corr_softargmax: null pointer");

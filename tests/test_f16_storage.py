@@ -108,6 +108,30 @@ def from_il8(a):
     return a.transpose(0, 1, 4, 2, 3).reshape(n, g * 8, h, p)
 
 
+@pytest.mark.parametrize("shape,D,is_min,pitch", [((2, 32, 9, 140), 48, False, 192), ((1, 32, 5, 129), 64, False, 192), ((1, 16, 7, 37), 6, True, 64),
+                                                  ((2, 8, 3, 33), 13, False, 64), ((1, 32, 4, 70), 33, True, 128)])
+def test_corr_softargmax_mfma_f16(backend, shape, D, is_min, pitch):
+    """half2 mode's correlation + soft-argmax on the matrix cores (corr_softargmax_mfma_f16_kernel): fp16 channel-interleaved maps
+    (C/8, H, pitch, 8), fp16 map out, against the oracle on the fp16-rounded maps evaluated in fp64 (reference
+    test_data_generator.py:242-259, 300-315; fp16 tolerance tests_main.cpp:1025) and against the planar fp16 kernel it replaces in the
+    engine -- the same exact products, another order of the fp32 sums: one fp16 ulp of the map at most."""
+    n, c, h, w = shape
+    l, r = rnd(*shape) * np.float32(0.5), rnd(*shape) * np.float32(0.5)
+    lq, rq = (a.astype(np.float16).astype(np.float32) for a in (l, r))
+    ref = O.softargmax(O.corr_cost_volume(torch.from_numpy(lq).double(), torch.from_numpy(rq).double(), D), is_min).numpy()
+    out = empty16(backend, (n, 1, h, pitch))
+    backend.klib.corr_softargmax_il8_f16(dev16(backend, to_il8(pitched(l, pitch))), dev16(backend, to_il8(pitched(r, pitch))), out, n, c, h, w, D,
+                                         is_min, pitch, pitch)
+    got = host(backend, out)
+    assert np.isnan(got[..., w:]).all(), "padding columns were written"
+    ulp = np.maximum(np.abs(ref), 1.0) * 2.0 ** -10                   # fp16 spacing at the value
+    assert (np.abs(got[..., :w] - ref) <= 0.6 * ulp + 2e-4 * max(1, D / 16)).all(), np.abs(got[..., :w] - ref).max()
+    planar = empty16(backend, (n, 1, h, pitch))
+    backend.klib.corr_softargmax_pitched(dev16(backend, pitched(l, pitch, 0.0)), dev16(backend, pitched(r, pitch, 0.0)), planar, n, c, h, w, D, is_min,
+                                         pitch, pitch, dtype=capi.RT_F16)
+    assert (np.abs(got[..., :w] - host(backend, planar)[..., :w]) <= ulp).all()
+
+
 @pytest.mark.parametrize("x_il8,y_il8,r_il8", [(1, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1), (1, 0, 0)])
 @pytest.mark.parametrize("cin,cout,h,w,resid", [(32, 32, 9, 37, True), (16, 72, 6, 70, True), (40, 24, 7, 33, False)])
 def test_conv2d_f16_interleaved(backend, cin, cout, h, w, resid, x_il8, y_il8, r_il8):

@@ -320,8 +320,14 @@ def test_resnet18_2d_half2_mode(rt, monkeypatch):
     monkeypatch.delenv("RT_NO_F16")
     monkeypatch.setenv("RT_NO_IL8", "1")                       # planar fp16 tensors everywhere
     planar, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
-    # the channel-interleaved tensors inside the towers change addressing only: same operands, same accumulation order
-    assert np.array_equal(planar, half)
+    # the channel-interleaved tensors inside the towers change addressing only: same operands, same accumulation order -- except (round 6)
+    # in the correlation, which runs on the matrix cores for interleaved fp16 maps: the same exact products in another order of summation,
+    # so the fp16 soft-argmax map may differ by an ulp, and the disparity by what follows from that
+    assert np.abs(planar - half).max() <= 2e-3, np.abs(planar - half).max()
+    monkeypatch.delenv("RT_NO_IL8")
+    monkeypatch.setenv("RT_NO_CORR_MFMA_F16", "1")             # interleaved towers, planar-style correlation: the bits of the planar engine
+    same, _ = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    assert np.array_equal(planar, same)
 
 
 def test_resnet18_2d_half2_fused_residual_blocks(rt, monkeypatch):
