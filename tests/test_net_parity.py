@@ -103,6 +103,38 @@ def test_resnet18_2d_fused_residual_blocks(rt, monkeypatch):
     assert np.abs(out - ref).max() <= 2e-4
 
 
+def test_resnet18_2d_presplit_tensors_between_tower_blocks(rt, monkeypatch):
+    """Round 6: the tensors that travel from one fused tower block to the next are stored pre-split (fp16 hi / lo operand pairs in the fp32
+    tensor's bytes, rt_resblock_plan_set_split; conv_rbd.hip.h) -- seven of the eight merged block launches of a pair write or read one.  Same
+    launches as with RT_NO_RBD=1 (fp32 tensors between the blocks), the stored bytes of exactly those tensors differ, the disparity agrees
+    to fp32 rounding (the skip connections carry 22 bits) and with the oracle."""
+    w = O.synth_weights_resnet18_2d()
+    l, r = pairs(1, 41, 73)
+    monkeypatch.setenv("RT_RB", "1")
+    monkeypatch.setenv("RT_RBS_SEG", "16")
+    res = {}
+    for no_rbd in ("0", "1"):
+        if no_rbd == "1":
+            monkeypatch.setenv("RT_NO_RBD", "1")
+        net = rt.lib.create("resnet18_2D", 73, 41, weights=w, max_disp=8)
+        net.set_launch_trace(True)
+        out = rt.empty(1, 1, 41, 73)
+        net.execute(rt.dev(l), rt.dev(r), out, 1)
+        res[no_rbd] = (np.array(rt.host(out)), net.read_launch_trace(), [net.launch_name(i) for i in range(net.num_launches)])
+        net.destroy()
+    (o_split, h_split, names), (o_f32, h_f32, names2) = res["0"], res["1"]
+    assert names == names2
+    differ = [n for n, a, b in zip(names, h_split, h_f32) if a != b]
+    # blocks 1 .. 7 of the merged towers write a pre-split tensor; block 8 (fp32 out) and everything behind it differ in rounding only
+    blocks = [n for n in names if "resblock" in n]
+    assert len(blocks) == 8 and all(n in differ for n in blocks[:7]), (blocks, differ)
+    assert not any(a != b for n, a, b in zip(names, h_split, h_f32) if names.index(n) < names.index(blocks[0]))
+    assert np.abs(o_split - o_f32).max() <= 5e-6, np.abs(o_split - o_f32).max()
+    with torch.no_grad():
+        ref = O.resnet18_2d(torch.from_numpy(l), torch.from_numpy(r), w, max_disp=8).numpy()
+    assert np.abs(o_split - ref).max() <= 2e-4
+
+
 def test_resnet18_2d_siamese_merge_is_bit_identical(rt, monkeypatch):
     """The two feature towers share their weights (left_* == right_* in the reference's weight files): launches of twin layers whose
     tensors are plain internal buffers run as ONE launch over [left samples | right samples] (EngineImpl::mergeSiamese).  Same bits
