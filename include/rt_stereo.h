@@ -122,9 +122,10 @@ int rt_corr_softargmax_il(const void* left, const void* right, void* out, int ba
 int rt_corr_softargmax_il_slot(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
                                int is_min, int in_pitch, int out_pitch, int64_t out_bstride, int out_slot, rtStream stream);
 /* ... in half2 mode: fp16 channel-interleaved feature maps (C/8, H, pitch, 8), the map as an fp16 plane; the stored values are the
- * operands of the matrix instructions (fp32 accumulation of exact fp16 products, lib/kernels.cu:203-250 computes the same in fp32). */
+ * operands of the matrix instructions (fp32 accumulation of exact fp16 products, lib/kernels.cu:203-250 computes the same in fp32).
+ * out_slot = 8: the map as lane 0 of the 16-byte slots of an interleaved group of 8 fp16 channels, zeros in lanes 1 .. 7. */
 int rt_corr_softargmax_il8_f16(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
-                               int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream stream);
+                               int is_min, int in_pitch, int out_pitch, int64_t out_bstride, int out_slot, rtStream stream);
 
 /* ---- layout glue of the 3-D models ------------------------------------------------------- */
 /* 4-D permute of a (N, d0,d1,d2,d3) tensor: out dim i = in dim order[i].  Replaces

@@ -70,7 +70,7 @@ KERNEL_SYMBOLS = {
     "rt_corr_softargmax_pitched": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_corr_softargmax_il": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_void_p]),
     "rt_corr_softargmax_il_slot": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
-    "rt_corr_softargmax_il8_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_void_p]),
+    "rt_corr_softargmax_il8_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_int64, c_int, c_void_p]),
     "rt_permute4d": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [POINTER(c_int), c_int, c_void_p]),
     "rt_convert_format": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "rt_pad_d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
@@ -205,10 +205,10 @@ class KernelLib:
         self.check(self.lib.rt_corr_softargmax_il_slot(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min), in_pitch, out_pitch,
                                                        out_bstride, out_slot, stream), "rt_corr_softargmax_il_slot")
 
-    def corr_softargmax_il8_f16(self, l, r, out, batch, C, H, W, D, is_min, in_pitch=0, out_pitch=0, out_bstride=0, stream=None):
-        """half2 mode: fp16 (C/8, H, pitch, 8) feature maps, fp16 map out"""
+    def corr_softargmax_il8_f16(self, l, r, out, batch, C, H, W, D, is_min, in_pitch=0, out_pitch=0, out_bstride=0, stream=None, out_slot=1):
+        """half2 mode: fp16 (C/8, H, pitch, 8) feature maps, fp16 map out (out_slot = 8: lane 0 of the 16-byte slots of a group of 8)"""
         self.check(self.lib.rt_corr_softargmax_il8_f16(_ptr(l), _ptr(r), _ptr(out), batch, C, H, W, D, int(is_min), in_pitch, out_pitch,
-                                                       out_bstride, stream), "rt_corr_softargmax_il8_f16")
+                                                       out_bstride, out_slot, stream), "rt_corr_softargmax_il8_f16")
 
     def cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, stream=None):
         self.check(self.lib.rt_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, stream),

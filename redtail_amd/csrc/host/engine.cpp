@@ -903,12 +903,15 @@ void EngineImpl::assignPitch() {
     std::vector<char> catpad(tensors_.size(), 0), cat_il(ops_.size(), 0);
     for (size_t ci = 0; ci < ops_.size(); ci++) {
         const Op& op = ops_[ci];
-        if (op.kind != OpKind::kConcat || f16 || knob("RT_NO_IL8") || knob("RT_NO_IL_CONCAT") || !concatFoldable(ci)) continue;
+        // (half2 mode, round 6: the same with groups of 8 fp16 channels -- conv_f16mma_kernel takes the padded input, the fp16 matrix-core
+        //  correlation writes lane 0 of a fifth group)
+        if (op.kind != OpKind::kConcat || knob("RT_NO_IL8") || knob("RT_NO_IL_CONCAT") || (f16 && knob("RT_NO_IL_CONCAT_F16")) || !concatFoldable(ci)) continue;
+        const int G = f16 ? 8 : 4;
         bool cand = ok[op.out] != 0;
         for (size_t k = 0; k < op.in.size(); k++) {
             const TensorImpl& t = *tensors_[op.in[k]];
-            cand = cand && ok[t.id] && (t.dims.d[0] % 4 == 0 || k + 1 == op.in.size());
-            if (t.dims.d[0] % 4 != 0)                                   // written as lane 0 of a group: the matrix-core correlation does that
+            cand = cand && ok[t.id] && (t.dims.d[0] % G == 0 || k + 1 == op.in.size());
+            if (t.dims.d[0] % G != 0)                                   // written as lane 0 of a group: the matrix-core correlation does that
                 for (const Op& pr : ops_)
                     if (pr.out == t.id) cand = cand && t.dims.d[0] == 1 && corr_takes_il(pr);
         }
@@ -2227,7 +2230,7 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
                 const Dims& f = eng_.tensors_[op.in[0]]->dims;
                 if (op.il_in && eng_.tensors_[op.in[0]]->f16)
                     rc = rt_corr_softargmax_il8_f16(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1], f.d[2],
-                                                    op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride, st);
+                                                    op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride, op.il_out ? 8 : 1, st);
                 else if (op.il_in)
                     rc = rt_corr_softargmax_il_slot(addr(op.in[0], batch, bindings), addr(op.in[1], batch, bindings), y, batch, f.d[0], f.d[1],
                                                     f.d[2], op.max_disp, op.is_min, eng_.tensors_[op.in[0]]->pitch, out.pitch, out.bstride,

@@ -121,8 +121,14 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_f
     const float e1 = fast_exp(m_run - M), e2 = fast_exp(m2 - M);
     const float s = s_run * e1 + s2 * e2, w = w_run * e1 + w2 * e2;
     const int x = x0 + l31;
-    if (kg == 0 && x < p.W)
-        reinterpret_cast<_Float16*>(p.out)[(int64_t)n * p.out_bstride + (int64_t)y * p.out_pitch + x] = (_Float16)(w / s);
+    if (kg == 0 && x < p.W) {
+        _Float16* o = reinterpret_cast<_Float16*>(p.out) + (int64_t)n * p.out_bstride;
+        const _Float16 dv = (_Float16)(w / s);
+        // out_slot 8: the map as lane 0 of the 16-byte pixel slots of a group of 8 fp16 channels (the 33rd channel of conv2D_1's input
+        // when its concatenation stays interleaved, resnet18_2D_513x257_net.cpp:601-615), zeros in lanes 1 .. 7
+        if (p.out_slot == 8) *reinterpret_cast<u32x4_t*>(o + ((int64_t)y * p.out_pitch + x) * 8) = u32x4_t{(unsigned)__builtin_bit_cast(unsigned short, dv), 0u, 0u, 0u};
+        else o[(int64_t)y * p.out_pitch + x] = dv;
+    }
 }
 
 __device__ static __forceinline__ void corr_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {

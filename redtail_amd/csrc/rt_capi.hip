@@ -380,8 +380,10 @@ extern "C" int rt_corr_softargmax_il_slot(const void* left, const void* right, v
 
 // half2 mode: fp16 channel-interleaved feature maps (C/8, H, pitch, 8), fp16 map out (plane, out_pitch) -- corr_softargmax_mfma_f16_kernel
 extern "C" int rt_corr_softargmax_il8_f16(const void* left, const void* right, void* out, int batch, int C, int H, int W, int D,
-                                          int is_min, int in_pitch, int out_pitch, int64_t out_bstride, rtStream s) {
+                                          int is_min, int in_pitch, int out_pitch, int64_t out_bstride, int out_slot, rtStream s) {
     RT_REQUIRE(left && right && out, "rt_corr_softargmax_il8_f16: null pointer");
+    RT_REQUIRE(out_slot == 1 || out_slot == 8, "rt_corr_softargmax_il8_f16: out_slot is 1 (plane) or 8 (lane 0 of an interleaved group of 8)");
+    RT_REQUIRE(out_slot == 1 || (reinterpret_cast<uintptr_t>(out) % 16 == 0 && out_bstride % 8 == 0), "rt_corr_softargmax_il8_f16: 16-byte slots need a 16-byte aligned output");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax_il8_f16: bad dims");
     if (C % 8 != 0 || C > 32 || D > 64) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax_il8_f16: C must be a multiple of 8 up to 32 and max_disp <= 64 (C %d, D %d)", C, D);
     RT_REQUIRE((in_pitch == 0 || in_pitch >= W) && (out_pitch == 0 || out_pitch >= W), "rt_corr_softargmax_il8_f16: pitch smaller than the row");
@@ -390,8 +392,8 @@ extern "C" int rt_corr_softargmax_il8_f16(const void* left, const void* right, v
     a.C = C; a.H = H; a.W = W; a.D = D;
     a.in_pitch = in_pitch ? in_pitch : W; a.out_pitch = out_pitch ? out_pitch : W;
     a.in_bstride = (int64_t)C * H * a.in_pitch;
-    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch;
-    a.out_slot = 1;
+    a.out_bstride = out_bstride ? out_bstride : (int64_t)H * a.out_pitch * out_slot;
+    a.out_slot = out_slot;
     RT_REQUIRE(a.in_bstride < (1ll << 30), "rt_corr_softargmax_il8_f16: sample exceeds 2 GB (32-bit buffer offsets)");
     a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
     const int64_t tasks = (int64_t)a.blocks_x * H * batch;
@@ -2327,7 +2329,9 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
     if (sc.rb) return (plan->cin % 4 == 0 ? 5 : 0) | (sc.Cout % 4 == 0 ? 2 : 0);      // the residual IS the input tensor
     if (sc.s3first) return sc.Cout % 4 == 0 ? 2 : 0;           // output only (its input is the image binding)
     if (sc.f16first) return sc.Cout % 8 == 0 ? 2 : 0;          // output only (its input is the fp32 image)
-    if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && plan->cin % 8 == 0 && sc.Cout % 8 == 0) ? 7 : 0;
+    // (bit 4: an interleaved input padded to a whole group of 8 -- conv2D_1's 33 channels in half2 mode; the gather loads whole groups,
+    //  the pad channels meet zero weights and must hold finite values, as for the fp32 kernel above)
+    if (sc.f16mma) return (sc.KH == 3 && sc.KW == 3 && sc.S == 1 && sc.Cout % 8 == 0) ? ((plan->cin % 8 == 0 ? 1 : 16) | 6) : 0;
     if (sc.x_f16 || sc.y_f16) return 0;
     // fp32 tensors: groups of 4 channels.  The Winograd kernel with the 4-wave tile takes all three.  (Round 3 took the interleaved
     // instantiations out of the product after tools/race_hunt.py saw one output in ~3000 of the exact engine deviate beside other contexts;

@@ -132,6 +132,49 @@ def test_corr_softargmax_mfma_f16(backend, shape, D, is_min, pitch):
     assert (np.abs(got[..., :w] - host(backend, planar)[..., :w]) <= ulp).all()
 
 
+def test_corr_f16_writes_the_fifth_group_and_conv_reads_33_interleaved_fp16_channels(backend):
+    """half2 mode's form of the interleaved concatenation in front of conv2D_1 (resnet18_2D_513x257_net.cpp:601-615): one buffer of 5 groups
+    of 8 fp16 channels per sample -- 4 groups of the left feature map and a fifth whose lane 0 is the soft-argmax map
+    (rt_corr_softargmax_il8_f16, out_slot = 8: zeros in lanes 1 .. 7) -- read by a 33 -> 32 convolution on fp16 operands as a PADDED
+    interleaved input (rt_conv_plan_supports_il8 bit 4).  Same bits as the planar concatenation through the same kernels."""
+    n, c, h, w, D, P = 2, 32, 7, 45, 12, 64
+    q16 = lambda a: a.astype(np.float16).astype(np.float32)
+    l, r = q16(rnd(n, c, h, w) * np.float32(0.5)), q16(rnd(n, c, h, w) * np.float32(0.5))
+    feat = q16(rnd(n, 32, h, w))
+    wt, b = q16(rnd(32, 33, 3, 3) * np.float32(1 / np.sqrt(33 * 9))), rnd(32)
+    lil, ril = dev16(backend, to_il8(pitched(l, P))), dev16(backend, to_il8(pitched(r, P)))
+    # planar reference of the same kernels: the map as a plane, the 33 channels planar
+    disp = empty16(backend, (n, 1, h, P))
+    backend.klib.corr_softargmax_il8_f16(lil, ril, disp, n, c, h, w, D, False, P, P)
+    dmap = host(backend, disp)[..., :w]
+    x33 = np.concatenate([feat, dmap], axis=1)
+    plan = backend.klib.conv2d_plan(wt, b, 33, 32, h, w, 3, 1, 1, act=capi.RT_ACT_ELU)
+    plan.set_pitch(P, P)
+    plan.set_io_types(capi.RT_F16, capi.RT_F16)
+    assert plan.il_caps() & 16 and not plan.il_caps() & 1
+    yp = empty16(backend, (n, 32, h, P))
+    plan.enqueue(dev16(backend, pitched(x33, P, 0.0)), yp, None, n)
+    planar = host(backend, yp)[..., :w]
+    # interleaved: [4 groups of feat | fifth group: lane 0 = map], 40 channels allocated per sample
+    buf = np.full((n, 5, h, P, 8), np.nan, np.float32)
+    buf[:, :4] = to_il8(pitched(feat, P))
+    bdev = dev16(backend, buf)
+    elems = 5 * h * P * 8
+    if backend.name == "gpu":
+        slot = bdev.view(-1)[4 * h * P * 8:]
+    else:
+        slot = bdev.reshape(-1)[4 * h * P * 8:]
+    backend.klib.corr_softargmax_il8_f16(lil, ril, slot, n, c, h, w, D, False, P, P, out_bstride=elems, out_slot=8)
+    got5 = host(backend, bdev)
+    assert np.array_equal(got5[:, 4, :, :w, 0], dmap[:, 0]) and (got5[:, 4, :, :w, 1:] == 0).all()
+    plan.set_layouts(1, 0, 0)
+    plan.set_batch_strides(elems, 0, 0)
+    yi = empty16(backend, (n, 32, h, P))
+    plan.enqueue(bdev, yi, None, n)
+    assert np.array_equal(host(backend, yi)[..., :w], planar)
+    plan.destroy()
+
+
 @pytest.mark.parametrize("x_il8,y_il8,r_il8", [(1, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 1), (0, 0, 1), (1, 0, 0)])
 @pytest.mark.parametrize("cin,cout,h,w,resid", [(32, 32, 9, 37, True), (16, 72, 6, 70, True), (40, 24, 7, 33, False)])
 def test_conv2d_f16_interleaved(backend, cin, cout, h, w, resid, x_il8, y_il8, r_il8):

@@ -375,6 +375,13 @@ def test_resnet18_2d_half2_fused_residual_blocks(rt, monkeypatch):
         out, (_, n1) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
         assert n1 == n0 - 8, (n0, n1)
         assert np.array_equal(out, base), np.abs(out - base).max()
+    # the concatenation in front of conv2D_1 stays interleaved in half2 mode too (round 6: groups of 8 fp16 channels, the map in lane 0 of a
+    # fifth group), which is what lets the left tower's first layer and first block join the right tower's launches: 22 launches as in the
+    # fp32 engine, 25 without -- addressing only, the same bits
+    assert n1 == 22, n1
+    monkeypatch.setenv("RT_NO_IL_CONCAT_F16", "1")
+    apart, (_, n2) = run_net(rt, "resnet18_2D", w, l, r, max_disp=8, fp16_weights=True)
+    assert n2 == 25 and np.array_equal(apart, base), (n2, np.abs(apart - base).max())
 
 
 def test_nvtiny_fp16_weight_file(rt, monkeypatch):
