@@ -16,7 +16,7 @@ share nothing but the weights: rank 0 builds the weight-file image and broadcast
 processes its own K pairs).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = conv_s3rbs_kernel, one launch per residual block of the feature towers over both images (the 32
+  roofline      dominant kernel = conv_s3rbd_kernel (round 6; conv_s3rbs_kernel with RT_NO_RBD=1), one launch per residual block of the feature towers over both images (the 32
                 3x3 32->32 convolutions at 629x185 = 79 % of the network's FLOPs, ~55-60 % of its GPU time; layer by layer with
                 RT_RB=0: conv_s3_kernel<3,3,1,il,il>): fp32 tensors, 3-term fp16 split on
                 v_mfma_f32_32x32x16_f16 with fp32 accumulation.  At 16x the fp32 matrix rate the layer is bound by moving its
@@ -1052,9 +1052,10 @@ def main():
             mfma_exec = DOMINANT_FLOPS * 16.0 / 36.0
         else:
             nbytes = BLOCK_BYTES if fused else DOMINANT_BYTES
-            kernel = ("conv_s3rbs_kernel: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
-                      "streaming down 30-column strips, intermediate rows in an LDS ring; fp32 tensors, 3-term fp16 split on "
-                      "v_mfma_f32_32x32x16_f16, fp32 accumulate" if fused else
+            kernel = ("conv_s3rbd_kernel: residual block = two 3x3 32->32 convolutions @629x185 (+bias,+ELU / +bias,+skip,+ELU) in one launch, "
+                      "streaming down 30-column strips, intermediate rows in an LDS ring; tower tensors stored as the fp16 (hi, lo) pairs of the "
+                      "3-term split and moved HBM -> LDS by DMA, v_mfma_f32_32x32x16_f16, fp32 accumulate (conv_s3rbs_kernel: the same from fp32 "
+                      "tensors, on a block's first / last tensor and with RT_NO_RBD=1)" if fused else
                       "conv_s3_kernel<3,3,1,il,il> 3x3 32->32 @629x185 (+bias,+residual,+ELU): fp32 tensors, 3-term fp16 split on v_mfma_f32_32x32x16_f16, fp32 accumulate")
             if fused:
                 # executed matrix work of the streaming kernel per image: 21 strips x segments, every step computes 4 rows x 32 columns
@@ -1127,11 +1128,11 @@ def main():
                     "hbm_gbs": nbytes * tot_imgs / tot_s / 1e9, "frac_hbm": nbytes * tot_imgs / tot_s / 1e9 / HBM_PEAK_GBS,
                     "frac_hbm_note": "algorithmic bytes of the same launches / in-situ duration / 8 TB/s"}
         if fused and not args.half2:
-            roofline["bound_note"] = ("bound by the SIMD's vector issue port: a v_mfma_f32_32x32x16_f16 holds it ~14.6 of its 32 cycles, the VALU work of a 4-row "
-                                      "step (ELU, fp16 splits, addressing: ~1.5 k cycles per SIMD) needs the rest, and two in-order waves per SIMD reach 66-73 % "
-                                      "of it (tools/micro/mfma_interleave.hip, tools/dev/README.md: a rebuild with every wave's vector work sliced into "
-                                      "its own MFMA stream measured 4.7 k instead of 5.0 k cycles per step, one step more per segment, no gain); the rest "
-                                      "of `frac` is the 2.5 PFLOP/s peak assuming 2.4 GHz (sustained: 2.0-2.2), the prologue and the pipeline's fill / drain steps")
+            roofline["bound_note"] = ("a 4-row step takes ~4.1 k cycles against 3.36 k for its MFMAs alone (two waves per SIMD share the "
+                                      "matrix pipe; measured with the operand reads, the epilogue and the DMA switched off one by one, "
+                                      "profiles/r06_rbs_dev.txt): within 20 % of the matrix pipe's floor for three fp16 products per multiply; the rest "
+                                      "of `frac` is the 2.5 PFLOP/s peak assuming 2.4 GHz (sustained: 2.0-2.2), the 30-of-32 strip, the prologue and "
+                                      "the pipeline's fill / drain steps (`frac_executed` counts those rows)")
         if fused and not args.half2:
             # continuity with the layer-by-layer kernel (the roofline object of earlier benches; still runs the other convolutions)
             g_us = isolated_dominant(lib.kernels, b, args.half2, fused=False)
