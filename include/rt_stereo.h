@@ -89,6 +89,12 @@ int rt_activation(const void* x, void* y, int64_t n, int act, int dtype, rtStrea
  * words, fp32 accumulate, output planes packed in disparity pairs. */
 int rt_corr_cost_volume(const void* left, const void* right, void* cost_vol, int batch, int C, int H, int W,
                         int max_disp, int dtype, int format, rtStream stream);
+/* The same with flags.  fp32 NCHW maps of a network's size (W >= 64, 16 <= C <= 32, max_disp <= 64) are correlated on the matrix
+ * cores through the 3-term fp16 split of the convolutions (relative error <= 2^-21 of sum |l r|, inputs |x| < 65504);
+ * RT_CONV_EXACT_FP32 keeps the fp32 fmaf chain of corrCostVolumeKernel for them too (CostVolumePlugin::enqueue passes it in engines
+ * built with IBuilder::setExactFp32Mode). */
+int rt_corr_cost_volume_flags(const void* left, const void* right, void* cost_vol, int batch, int C, int H, int W,
+                              int max_disp, int dtype, int format, unsigned flags, rtStream stream);
 
 /* Default (concatenation) cost volume: cv[n,d,0:C]=L ; cv[n,d,C:2C,y,x]=R[n,:,y,x-d] (0 for x<d).
  * (N,C,H,W) x2 -> (N,D,2C,H,W).  Replaces CudaKernels::computeCostVolume (lib/kernels.cu:50-97,136-161). */

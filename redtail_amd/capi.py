@@ -64,6 +64,7 @@ KERNEL_SYMBOLS = {
     "rt_add_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rt_activation": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rt_corr_cost_volume": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rt_corr_cost_volume_flags": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [ctypes.c_uint, c_void_p]),
     "rt_cost_volume": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rt_softargmax": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rt_corr_softargmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int64, c_int, c_void_p]),
@@ -183,8 +184,9 @@ class KernelLib:
     def activation(self, x, y, n, act, dtype=RT_F32, stream=None):
         self.check(self.lib.rt_activation(_ptr(x), _ptr(y), n, act, dtype, stream), "rt_activation")
 
-    def corr_cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, fmt=RT_NCHW, stream=None):
-        self.check(self.lib.rt_corr_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, stream),
+    def corr_cost_volume(self, l, r, cv, batch, C, H, W, D, dtype=RT_F32, fmt=RT_NCHW, stream=None, flags=0):
+        self.check(self.lib.rt_corr_cost_volume_flags(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, flags, stream)
+                   if flags else self.lib.rt_corr_cost_volume(_ptr(l), _ptr(r), _ptr(cv), batch, C, H, W, D, dtype, fmt, stream),
                    "rt_corr_cost_volume")
 
     def preprocess_bgr8(self, src, src_h, src_w, dst, dst_h, dst_w, batch=1, stream=None):

@@ -792,6 +792,7 @@ bool EngineImpl::lower() {
                 }
                 op.kind = OpKind::kPlugin;
                 op.plugin = l->plugin;
+                if (sp) sp->setExactFp32(exact_fp32_);
                 if (l->out.size() != 1) return fail(l->name + ": multi-output plugins are not supported");
                 if (l->in.size() > 8) return fail(l->name + ": plugins with more than 8 inputs are not supported");
                 ops_.push_back(op);

@@ -29,6 +29,8 @@ public:
     // cost volume / soft-argmax
     virtual CostVolumeType costVolumeType() const { return CostVolumeType::kDefault; }
     virtual int maxDisparity() const { return 0; }
+    // engines built with IBuilder::setExactFp32Mode keep a stand-alone correlation on the fp32 fmaf kernel (rt_corr_cost_volume_flags)
+    virtual void setExactFp32(bool) {}
     virtual SoftargmaxType softargmaxType() const { return SoftargmaxType::kMax; }
     // transform
     virtual Permutation permutation() const { return Permutation{{0, 1, 2, 3}}; }

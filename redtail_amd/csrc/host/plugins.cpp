@@ -164,6 +164,7 @@ public:
     const std::string& pluginName() const override { return name_; }
     CostVolumeType costVolumeType() const override { return cv_; }
     int maxDisparity() const override { return max_disp_; }
+    void setExactFp32(bool on) override { exact_ = on; }
 
     bool supportsFormat(DataType type, PluginFormat format) const override {
         bool ok = (type == DataType::kFLOAT && format == PluginFormat::kNCHW) ||
@@ -197,8 +198,9 @@ public:
             rc = rt_cost_volume(inputs[0], inputs[1], outputs[0], batchSize, in_.d[0], in_.d[1], in_.d[2], max_disp_,
                                 rtType(type_), stream);
         else
-            rc = rt_corr_cost_volume(inputs[0], inputs[1], outputs[0], batchSize, in_.d[0], in_.d[1], in_.d[2], max_disp_,
-                                     rtType(type_), format_ == PluginFormat::kNC2HW2 ? RT_NC2HW2 : RT_NCHW, stream);
+            rc = rt_corr_cost_volume_flags(inputs[0], inputs[1], outputs[0], batchSize, in_.d[0], in_.d[1], in_.d[2], max_disp_,
+                                           rtType(type_), format_ == PluginFormat::kNC2HW2 ? RT_NC2HW2 : RT_NCHW,
+                                           exact_ ? RT_CONV_EXACT_FP32 : 0u, stream);
         RT_CHECKL(rc, log_);
         return rc;
     }
@@ -221,6 +223,7 @@ private:
     PluginFormat format_ = PluginFormat::kNCHW;
     CostVolumeType cv_ = CostVolumeType::kDefault;
     int max_disp_ = 0;
+    bool exact_ = false;           // (an engine setting, not part of the blob)
     Dims in_{}, out_{};
     ILogger& log_;
     std::string name_;

@@ -117,6 +117,7 @@ static inline void sload2_i64(const void* base, int off0, int off1, long long& a
     b = *reinterpret_cast<const long long*>(static_cast<const char*>(base) + off1);
 }
 __device__ static __forceinline__ void lds_barrier() { __syncthreads(); }
+__device__ static __forceinline__ void wave_lds_sync() { (void)__shfl(0.f, 0); }      // (a rendezvous of the wave's fibers)
 __device__ static __forceinline__ unsigned pack_f16(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16);
 }
@@ -133,6 +134,13 @@ __device__ static __forceinline__ void sload2_i64(const void* base, int off0, in
 __device__ static __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N> __device__ static __forceinline__ void wait_vmem_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ static __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS written by some lanes of a wave and read by others of the SAME wave: its LDS operations complete in order, so only the compiler
+// has to be kept from moving them across this point
+__device__ static __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ static __forceinline__ unsigned pack_f16(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

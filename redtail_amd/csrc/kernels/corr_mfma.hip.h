@@ -254,4 +254,104 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_k
     }
 }
 
+// Stand-alone CostVolumePlugin(kCorrelation) on PLANAR fp32 NCHW maps (the reference plugin's own tensors, lib/kernels.cu:168-200;
+// round 6): the same Gram band on the matrix cores, with
+//   * the operand of a lane -- 8 consecutive channels of one pixel -- gathered as 8 dword loads, each of them 128 contiguous bytes per
+//     half wave (a channel plane's row segment): 64 loads in flight per lane for C = 32, no LDS staging, no workgroup barrier;
+//   * the band written as a volume: accumulator register r of lane (x, kg) is cv[d = dj - c_r, y, x] -- 32 planes per instruction, so
+//     the wave transposes through ITS OWN part of the LDS (d, x) and stores plane rows, two per instruction (LDS operations of one
+//     wave complete in order: no barrier);
+//   * workgroups renumbered so that each XCD (its L2) gets a contiguous eighth of the rows: the cache lines that neighbouring blocks
+//     and rows share are completed in one L2 instead of being evicted half written from two (measured: 14.6 -> 13.0 us).
+// One wave per (row, 32 output pixels) -- the op is a single round of waves at batch 1, so occupancy is what it runs on: a wave that
+// walks several blocks and keeps the older R blocks in registers (half the loads) measured 18-22 us (profiles/r06_corr_dev.txt).
+// D <= 64 (three R blocks), C <= 32.  fp32 maps through the 3-term fp16 split: the product the engines' correlation runs on; small maps
+// and RT_CONV_EXACT_FP32 keep corr_f32_kernel (cost_volume.hip.h).
+struct CorrPlanarArgs {
+    const float* left;      // (C, H, W) per sample
+    const float* right;
+    float* out;             // (D, H, W) per sample
+    int C, H, W, D;
+    int blocks_x;           // ceil(W / 32)
+    int batch;
+};
+
+// NT: streaming (non-temporal) stores -- a volume larger than the caches (batch 8: 178 MB) is written 8 % faster with them, one that fits
+// (batch 1: 22 MB) 3 % slower; the launch chooses.
+template <bool NT>
+__global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_mfma_planar_kernel(CorrPlanarArgs p) {
+    __shared__ __attribute__((aligned(16))) float sm_all[4][64 * 32];     // per wave: (D, 32)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kg = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned nb8 = gridDim.x >> 3;                                   // (the grid is a multiple of 8)
+    const int64_t vb = (int64_t)(blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    const int64_t task = vb * 4 + wv;
+    const int per_row = p.blocks_x;
+    const int64_t total = (int64_t)per_row * p.H * p.batch;
+    if (task >= total) return;
+    const int bx = (int)(task % per_row);
+    const int y = (int)((task / per_row) % p.H);
+    const int n = (int)(task / ((int64_t)per_row * p.H));
+    const int x0 = bx * 32;
+    float* sm = sm_all[wv];
+
+    const unsigned plane = (unsigned)(p.H * p.W) * 4u;                      // bytes per channel / disparity plane
+    const buf_rsrc rs_l = make_buf(elem_ptr(p.left, (int64_t)n * p.C * p.H * p.W, 4));
+    const buf_rsrc rs_r = make_buf(elem_ptr(p.right, (int64_t)n * p.C * p.H * p.W, 4));
+    // operand of lane (pixel px, k-group kg), chunk c: channels 16 c + 8 kg .. + 7 of that pixel
+    auto load_px = [&](const buf_rsrc& rs, int px, f32x4 (&v)[2][2]) {
+        const unsigned at = (px >= 0 && px < p.W) ? (unsigned)(y * p.W + px) * 4u : kBufOOB;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ch = 16 * c + 8 * kg + 4 * h + e;
+                    v[c][h][e] = buf_load(rs, ch < p.C ? at + (unsigned)ch * plane : kBufOOB, 0u);
+                }
+    };
+    f32x4 lraw[2][2], rraw[3][2][2];
+    const bool blk0 = p.D > 33;                                            // block 0 holds d >= 33 only (wave-uniform)
+    load_px(rs_l, x0 + l31, lraw);
+#pragma unroll
+    for (int j = 2; j >= 0; j--)
+        if (j > 0 || blk0) load_px(rs_r, x0 - 64 + 32 * j + l31, rraw[j]);
+
+    f16x8 lh[2], ll[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) corr_split8(lraw[c][0], lraw[c][1], lh[c], ll[c]);
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+        if (j == 0 && !blk0) break;
+        f32x16 acc_m, acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc_m[r] = 0.f; acc_c[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            f16x8 rh, rl;
+            corr_split8(rraw[j][c][0], rraw[j][c][1], rh, rl);
+            acc_m = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, lh[c], acc_m, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl, lh[c], acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, ll[c], acc_c, 0, 0, 0);
+        }
+        // register r: R pixel c_r + 4 kg of the block, i.e. disparity d = dj - c_r of output pixel l31
+        const int dj = l31 + 64 - 32 * j - 4 * kg;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int d = dj - ((r & 3) + 8 * (r >> 2));
+            if (d >= 0 && d < p.D) sm[d * 32 + l31] = fmaf(acc_c[r], kSplitInv, acc_m[r]);
+        }
+    }
+    wave_lds_sync();
+    // plane rows out: lane (x, kg) stores disparities kg, kg + 2, ...
+    const buf_rsrc rs_o = make_buf(elem_ptr(p.out, (int64_t)n * p.D * p.H * p.W, 4));
+    const int x = x0 + l31;
+    const unsigned oat = x < p.W ? (unsigned)(y * p.W + x) * 4u : kBufOOB;
+    for (int d = kg; d < p.D; d += 2)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sm[d * 32 + l31]), rs_o, oat + (unsigned)d * plane, 0u, NT ? 2 : 0);
+}
+
 }  // namespace rt

@@ -313,8 +313,15 @@ int launch_corr(const float* l, const float* r, float* out, int batch, int C, in
 }
 }  // namespace
 
+namespace { int env_int(const char* name, int dflt); }      // (development knobs, defined with the convolution plans below)
+
 extern "C" int rt_corr_cost_volume(const void* left, const void* right, void* cv, int batch, int C, int H, int W,
                                    int D, int dtype, int format, rtStream s) {
+    return rt_corr_cost_volume_flags(left, right, cv, batch, C, H, W, D, dtype, format, 0u, s);
+}
+
+extern "C" int rt_corr_cost_volume_flags(const void* left, const void* right, void* cv, int batch, int C, int H, int W,
+                                         int D, int dtype, int format, unsigned flags, rtStream s) {
     RT_REQUIRE(left && right && cv, "rt_corr_cost_volume: null pointer");
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_cost_volume: bad dims");
     // the two combinations the reference plugin accepts (lib/cost_volume_plugin.cpp:60-66): fp32 NCHW, fp16 NC2HW2
@@ -323,6 +330,22 @@ extern "C" int rt_corr_cost_volume(const void* left, const void* right, void* cv
                                                static_cast<float*>(cv), batch, C, H, W, D, (int64_t)((D + 1) / 2) * H * W, S(s));
     if (dtype != RT_F32 || format != RT_NCHW)
         return fail(RT_E_UNSUPPORTED, "rt_corr_cost_volume: fp32 NCHW or fp16 NC2HW2 (dtype %d format %d)", dtype, format);
+    // maps of a network's size: the Gram band on the matrix cores (corr_mfma_planar_kernel, 3-term fp16 split as in the engines'
+    // correlation: |x| < 65504, see rt_check_range); small maps, D > 64, C > 32 and RT_CONV_EXACT_FP32 keep the fp32 fmaf kernel
+    if (C >= 16 && C <= 32 && W >= 64 && D <= 64 && (int64_t)std::max(C, D) * H * W < (1ll << 29) && !(flags & RT_CONV_EXACT_FP32) && env_int("RT_CONV_EXACT_FP32", 0) == 0 &&
+        env_int("RT_NO_CORR_MFMA_PLANAR", 0) == 0) {
+        rt::CorrPlanarArgs a;
+        a.left = static_cast<const float*>(left); a.right = static_cast<const float*>(right); a.out = static_cast<float*>(cv);
+        a.C = C; a.H = H; a.W = W; a.D = D;
+        a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
+        const int64_t tasks = (int64_t)a.blocks_x * H * batch;
+        RT_REQUIRE(rt::cdiv(tasks, 4) < (1ll << 31), "rt_corr_cost_volume: grid too large");
+        const dim3 grid((unsigned)(rt::cdiv(rt::cdiv(tasks, 4), 8) * 8));        // a multiple of 8: the kernel renumbers workgroups per XCD
+        if ((int64_t)batch * D * H * W * 4 >= (64ll << 20)) hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<true>, grid, dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<false>, grid, dim3(256), 0, S(s), a);
+        RT_LAUNCH_CHECK("corr_mfma_planar_kernel");
+        return 0;
+    }
     return launch_corr<false, false>(static_cast<const float*>(left), static_cast<const float*>(right),
                                      static_cast<float*>(cv), batch, C, H, W, D, (int64_t)D * H * W, S(s));
 }
@@ -417,8 +440,6 @@ extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out
     return is_min ? launch_corr<true, true>(l, r, o, batch, C, H, W, D, out_bstride, S(s))
                   : launch_corr<true, false>(l, r, o, batch, C, H, W, D, out_bstride, S(s));
 }
-
-namespace { int env_int(const char* name, int dflt); }      // (development knobs, defined with the convolution plans below)
 
 extern "C" int rt_cost_volume(const void* left, const void* right, void* cv, int batch, int C, int H, int W, int D,
                               int dtype, rtStream s) {

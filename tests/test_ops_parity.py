@@ -86,6 +86,30 @@ def test_corr_random(backend, shape, D):
     near(run_corr(backend, l, r, D), O.corr_cost_volume(T(l), T(r), D).numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("shape,D", [((2, 32, 5, 140), 48), ((1, 16, 3, 64), 64), ((1, 24, 4, 97), 33), ((1, 32, 2, 161), 20),
+                                     ((3, 20, 2, 70), 34)])
+def test_corr_planar_on_the_matrix_cores(backend, shape, D, monkeypatch):
+    """maps of a network's size take corr_mfma_planar_kernel (Gram band, 3-term fp16 split, transposed through the wave's LDS):
+    bounded against the fp64 volume like the split convolutions, every element written, and the fp32 fmaf kernel still there"""
+    l, r = rnd(*shape), rnd(*shape)
+    r[:, :, :, :3] *= np.float32(40.0)                     # large products at the left edge, where x - d < 0 must give exact zeros
+    got = run_corr(backend, l, r, D)
+    ref = O.corr_cost_volume(T(l).double(), T(r).double(), D).numpy()
+    mag = O.corr_cost_volume(T(np.abs(l)).double(), T(np.abs(r)).double(), D).numpy()
+    assert np.all(np.abs(got - ref) <= 2.0 ** -21 * mag + 1e-30), float(np.max(np.abs(got - ref) / np.maximum(mag, 1e-30)))
+    for d in range(1, D):
+        assert not got[:, d, :, :min(d, shape[3])].any()
+    # RT_CONV_EXACT_FP32 (what CostVolumePlugin::enqueue passes in an exact-fp32 engine) keeps the fp32 fmaf kernel
+    n, c, h, w = shape
+    cv = backend.empty((n, D, h, w))
+    backend.klib.corr_cost_volume(backend.dev(l), backend.dev(r), cv, n, c, h, w, D, flags=capi.RT_CONV_EXACT_FP32)
+    exact = backend.host(cv)
+    near(exact, ref, 2e-5 * float(np.abs(ref).max()))
+    assert (exact != got).any()                              # (two kernels, two summation orders)
+    monkeypatch.setenv("RT_NO_CORR_MFMA_PLANAR", "1")
+    assert np.array_equal(run_corr(backend, l, r, D), exact)
+
+
 @pytest.mark.parametrize("shape,D,is_min", [((1, 5, 7, 37), 6, False), ((2, 32, 9, 140), 48, False),
                                             ((1, 8, 5, 129), 13, True), ((1, 4, 6, 6), 2, False)])
 def test_corr_softargmax_fused(backend, shape, D, is_min):

@@ -106,6 +106,10 @@ def main():
         if want("corr"):
             t = timeit(lambda: k.corr_cost_volume(l, r, cv, b, C, H, W, D))
             report("corr cost volume C32 D48 @185x629 b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + D) * H * W)
+            os.environ["RT_NO_CORR_MFMA_PLANAR"] = "1"      # the fp32 fmaf kernel (small maps, D > 64, RT_CONV_EXACT_FP32)
+            t = timeit(lambda: k.corr_cost_volume(l, r, cv, b, C, H, W, D))
+            del os.environ["RT_NO_CORR_MFMA_PLANAR"]
+            report("  the same on the vector ALU (corr_f32_kernel) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + D) * H * W)
             if b == 1:
                 # the op-level CPU baseline of BASELINE.md section 2: the reference's kernel as a plain single-thread C loop
                 # (oracle/corr_cpu.c restates lib/kernels.cu:168-200), same tensors, one core, result checked against the GPU's
