@@ -2049,10 +2049,15 @@ bool ContextImpl::checkInputRange(const Op& op, int batch, void** bindings, rtSt
         const TensorImpl& ti = *eng_.tensors_[t];
         if (ti.alias_of >= 0 || ti.bstride != 0 || ti.dims.nbDims != 3) continue;       // a channel range of another buffer: checked where it is produced
         // (a pre-split tensor is scanned as the fp16 values it holds: 16 per pixel and group of 8 channels)
-        const int C = ti.split ? 2 * ti.dims.d[0] : ti.dims.d[0], H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W, G = ti.split ? 16 : (ti.il8 ? (ti.f16 ? 8 : 4) : 1);
+        // the host of an interleaved concatenation: a reader of the host itself is checked on the host's own channels (the groups behind
+        // them belong to other members and may not be written yet), a reader of the WHOLE on every group (the disparity map of conv2D_1's
+        // input is produced by the correlation, which no other check sees; padding lanes are zeros)
+        const bool whole = ti.cpad && tin != t && eng_.tensors_[tin]->dims.d[0] > ti.dims.d[0];
+        const int C = whole ? ti.cpad : (ti.split ? 2 * ti.dims.d[0] : ti.dims.d[0]), H = ti.dims.d[1], W = ti.dims.d[2], P = ti.pitch ? ti.pitch : W,
+                  G = ti.split ? 16 : (ti.il8 ? (ti.f16 ? 8 : 4) : 1);
         float mx = 0.f;
         int64_t bad = 0;
-        // (the host of an interleaved concatenation: its own channels sample by sample -- the groups behind them belong to other members)
+        // (sample by sample: the samples of a padded tensor are cpad channels apart)
         const int calls = ti.cpad ? batch : 1;
         const int64_t rows = (int64_t)(ti.cpad ? 1 : batch) * (C / G) * H;
         for (int n = 0; n < calls; n++) {

@@ -788,7 +788,7 @@ def test_debug_mode_reports_the_fp16_split_domain(rt):
     l, r = pairs(1, 25, 41)
     big = l.copy()
     big[0, 1, 5, 7] = 7e4                                     # one pixel just outside the fp16 range
-    net = rt.lib.create("resnet18_2D", 41, 25, weights=w, max_disp=8)
+    net = rt.lib.create("resnet18_2D", 41, 25, max_batch=2, weights=w, max_disp=8)
     out = rt.empty(1, 1, 25, 41)
     net.execute(rt.dev(big), rt.dev(r), out, 1)               # default: runs, and the damage is visible
     assert not np.isfinite(np.array(rt.host(out))).all()
@@ -798,6 +798,12 @@ def test_debug_mode_reports_the_fp16_split_domain(rt):
     with pytest.raises(capi.RtError) as e:
         net.execute(rt.dev(big), rt.dev(r), out, 1)
     assert "left_conv1" in str(e.value) and "fp16-split" in str(e.value), str(e.value)
+    # batch 2: the checks step through the padded samples of conv2D_1's interleaved 33-channel input (every group of it, the
+    # disparity map's included) without a false alarm
+    l2, r2 = pairs(2, 25, 41)
+    out2 = rt.empty(2, 1, 25, 41)
+    net.execute(rt.dev(l2), rt.dev(r2), out2, 2)
+    assert np.isfinite(np.array(rt.host(out2))).all()
     net.destroy()
     exact = rt.lib.create("resnet18_2D", 41, 25, weights=w, max_disp=8, flags=capi.RT_CONV_EXACT_FP32)
     exact.set_debug(True)
