@@ -7,7 +7,7 @@
 One rank per GPU.  A "step" = one IExecutionContext::enqueue of one stereo pair through the whole
 network (23 launches at this size) with the inputs already resident in HBM (the reference times
 context->execute the same way, sample_app/main.cpp:303-309).  Steps are issued round-robin over
---contexts execution contexts of the same engine configuration, each on its own stream (default 6 with one
+--contexts execution contexts of the same engine configuration, each on its own stream (default 3 with one
 HIP stream each, the TensorRT throughput set-up `trtexec --streams`): the serial low-resolution tail of one pair
 then overlaps the encoder of the next.  "single_context" on the JSON line is the same workload through one
 context with two streams (the latency set-up), "synchronous_execute" the reference's own loop.  Stereo pairs are independent, so ranks
@@ -575,7 +575,7 @@ def secondary_lines(lib, dev):
         line["wall_s"] = time.perf_counter() - t0
         out.append(line)
 
-    add("C3: ResNet-18 2D half2, 1257x369, batch 8", lambda: bench_2d_config(lib, dev, W, H, 8, True, 6, 1, 32, 8, False))
+    add("C3: ResNet-18 2D half2, 1257x369, batch 8", lambda: bench_2d_config(lib, dev, W, H, 8, True, 3, 1, 32, 8, False))
     add("ref513: ResNet-18 2D fp32, 513x257, batch 1, one context, synchronous (the reference's published configuration: stereoDNN/README.md:31)",
         lambda: bench_2d_config(lib, dev, 513, 257, 1, False, 1, 2, 100, 20, True))
 
@@ -642,8 +642,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("RT_BENCH_CONTEXTS", "0")),
                     help="IExecutionContexts per GPU, each with its own stream; steps are issued round-robin "
-                         "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop; 0 (default) = 6 "
-                         "(fp32) / 4 (--half2), the best measured of 3..12")
+                         "(the TensorRT throughput set-up, trtexec --streams).  1 = the reference's synchronous loop; 0 (default) = 3 "
+                         "(end of round 6, 22 launches per pair: the driver's 20 steps give 2695-2820 pairs/s with 3 contexts, 2643-2666 with 6 -- "
+                         "less to fill and drain in a 7 ms timed region; 200 steps 2814 / 2802; 4 and 8 contexts 2350-2420; half2 batch 8: "
+                         "6550-6566 with 2, 3 or 6; profiles/r06_contexts.txt)")
     ap.add_argument("--streams-per-context", type=int, default=0, choices=[0, 1, 2],
                     help="HIP streams a context issues on (IExecutionContext::setExecutionStreams): 2 = right-image encoder on a second "
                          "stream, 1 = everything on the context's stream; 0 (default) = 1 with several fp32 contexts, 2 with one or with --half2.  Measured "
@@ -665,7 +667,7 @@ def main():
                          "1948 / 2015 pairs/s after 5 / 20 / 100 warm-up steps).  0 = off; reported on the JSON line")
     args = ap.parse_args()
     if args.contexts <= 0:
-        args.contexts = 6       # (half2: four two-stream contexts until round 6; with the tower blocks fused, 6 x 1: 6060 against 5634 pairs/s at batch 8)
+        args.contexts = 3       # (six until the end of round 6: see --contexts; half2 used four two-stream contexts until its tower blocks were fused)
 
     # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU through
     # torch.distributed.run on 127.0.0.1, exactly the command the driver uses -- instead of silently timing one GPU.
