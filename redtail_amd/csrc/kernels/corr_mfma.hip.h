@@ -276,9 +276,6 @@ struct CorrPlanarArgs {
     int batch;
 };
 
-// NT: streaming (non-temporal) stores -- a volume larger than the caches (batch 8: 178 MB) is written 8 % faster with them, one that fits
-// (batch 1: 22 MB) 3 % slower; the launch chooses.
-template <bool NT>
 __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_mfma_planar_kernel(CorrPlanarArgs p) {
     __shared__ __attribute__((aligned(16))) float sm_all[4][64 * 32];     // per wave: (D, 32)
     const int tid = threadIdx.x;
@@ -351,7 +348,7 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_mfma_planar_kerne
     const int x = x0 + l31;
     const unsigned oat = x < p.W ? (unsigned)(y * p.W + x) * 4u : kBufOOB;
     for (int d = kg; d < p.D; d += 2)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sm[d * 32 + l31]), rs_o, oat + (unsigned)d * plane, 0u, NT ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sm[d * 32 + l31]), rs_o, oat + (unsigned)d * plane, 0u, 0);
 }
 
 }  // namespace rt

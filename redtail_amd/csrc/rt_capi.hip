@@ -341,8 +341,7 @@ extern "C" int rt_corr_cost_volume_flags(const void* left, const void* right, vo
         const int64_t tasks = (int64_t)a.blocks_x * H * batch;
         RT_REQUIRE(rt::cdiv(tasks, 4) < (1ll << 31), "rt_corr_cost_volume: grid too large");
         const dim3 grid((unsigned)(rt::cdiv(rt::cdiv(tasks, 4), 8) * 8));        // a multiple of 8: the kernel renumbers workgroups per XCD
-        if ((int64_t)batch * D * H * W * 4 >= (64ll << 20)) hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<true>, grid, dim3(256), 0, S(s), a);
-        else hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<false>, grid, dim3(256), 0, S(s), a);
+        hipLaunchKernelGGL(rt::corr_mfma_planar_kernel, grid, dim3(256), 0, S(s), a);
         RT_LAUNCH_CHECK("corr_mfma_planar_kernel");
         return 0;
     }

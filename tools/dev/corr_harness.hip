@@ -32,8 +32,7 @@ int main(int argc, char** argv) {
         rt::CorrPlanarArgs a;
         a.left = dl; a.right = dr; a.out = dcv; a.C = C; a.H = H; a.W = W; a.D = D; a.blocks_x = (W + 31) / 32; a.batch = b;
         const unsigned nwg = (unsigned)(((long)a.blocks_x * H * b + 3) / 4);
-        if (b >= 4) hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<true>, dim3((nwg + 7u) / 8u * 8u), dim3(256), 0, 0, a);
-        else hipLaunchKernelGGL(rt::corr_mfma_planar_kernel<false>, dim3((nwg + 7u) / 8u * 8u), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(rt::corr_mfma_planar_kernel, dim3((nwg + 7u) / 8u * 8u), dim3(256), 0, 0, a);
     };
     for (int tp : {1, 1, 1}) {
     tpw = tp;
