@@ -1037,6 +1037,8 @@ def main():
         launches = cnt // prof_runs
         step_s = elapsed / args.steps
         traffic, traffic_src = measured_traffic(args.half2, None if args.half2 else fused) if b == 1 else (None, None)
+        if traffic is None and (args.half2 or b > 1):              # the per-launch passes over the configuration as timed (tools/pmc_3d.sh)
+            traffic, traffic_src = measured_traffic_launches("resnet18_2D %dx%d%s batch %d" % (W, H, " half2" if args.half2 else "", b), sorted({n for n, _ in sel}))
         exact = os.environ.get("RT_CONV_EXACT_FP32", "0") != "0"
         b_iso = int(round(avg_imgs)) if avg_imgs > 1.5 * b else b  # the typical dominant launch: both towers when they are merged
         hints = capi.RT_HINT_THROUGHPUT if spc == 1 else 0
