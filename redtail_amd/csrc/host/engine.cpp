@@ -335,6 +335,7 @@ struct Op {
     bool twin = false;
     std::vector<int> twin_in;          // right-tower tensors it reads (inputs, residual): dependencies for the stream schedule
     int twin_out = -1;                 // right-tower tensor it writes
+    int softarg = 0;                   // kConv3D: the launch ends in the soft-argmax (1) / soft-argmin (2) that followed it (fuseSoftargmax3D)
     bool twin_bind = false;            // ... whose INPUT is the other input binding (first layers: rt_conv_enqueue_twin_input), not a twin-placed tensor
 };
 
@@ -1578,7 +1579,13 @@ void EngineImpl::fuseSoftargmax3D() {
         if (uses != 0 || producer < 0 || producer > (int)si) continue;
         Op& conv = ops_[producer];
         if (conv.kind != OpKind::kConv3D || !conv.splugin || conv.splugin->kind() != Kind::kConv3DTranspose || conv.stream != sa.stream) continue;
-        if (!conv.splugin->setSoftarg(sp->softargmaxType() == SoftargmaxType::kMin ? 2 : 1)) continue;     // no fused form for this plan
+        // the soft-argmax must reduce exactly the volume this launch produces, (D, 1, H, W): root() also passes through reshaping aliases
+        const Dims vd = tensors_[conv.out]->dims, sd = tensors_[sa.in[0]]->dims, md = tensors_[sa.out]->dims;
+        if (vd.nbDims != 4 || vd.d[1] != 1 || sd.nbDims != 4 || sd.d[0] != vd.d[0] || sd.d[1] != 1 || sd.d[2] != vd.d[2] || sd.d[3] != vd.d[3] ||
+            md.d[md.nbDims - 2] != vd.d[2] || md.d[md.nbDims - 1] != vd.d[3]) continue;
+        const int mode = sp->softargmaxType() == SoftargmaxType::kMin ? 2 : 1;
+        if (!conv.splugin->setSoftarg(mode)) continue;     // no fused form for this plan
+        conv.softarg = mode;
         conv.out = sa.out;
         for (int w : sa.wait_on) conv.wait_on.push_back(root(w));
         conv.lays.insert(conv.lays.end(), sa.lays.begin(), sa.lays.end());
@@ -1651,6 +1658,9 @@ void EngineImpl::assignInterleaved3D() {
             if (!(caps & 2)) drop(y);
             if (!(caps & 4)) drop(r);
             if ((caps & 8) && !il[x]) drop(y);          // this launch writes an interleaved tensor only when it reads one
+            // a Conv3D on fp16 tensors reads an interleaved skip tensor only on fp16 operands, i.e. with an interleaved input
+            // (rt_conv_plan_set_layouts refuses the combination: negotiate it away instead of failing the engine)
+            if (f16_mode && op.splugin->kind() == Kind::kConv3D && !il[x]) drop(r);
         }
     }
     int n = 0;
@@ -2186,6 +2196,10 @@ bool ContextImpl::issue(int batch, void** bindings, cudaStream_t stream, bool sy
                                               op.twin ? 2 * batch : batch, st, streams_ == 1 ? RT_HINT_THROUGHPUT : 0);
                 break;
             case OpKind::kConv3D:
+                if (op.softarg != op.splugin->softarg()) {      // (the plan was rebuilt and lost the reduction: its output would not fit the map's buffer)
+                    eng_.log_.log(ILogger::Severity::kERROR, (op.name + ": the plan no longer ends in the soft-argmax the executor planned for").c_str());
+                    return false;
+                }
                 rc = op.splugin->enqueueFused(batch, addr(op.in[0], batch, bindings), y, op.resid >= 0 ? addr(op.resid, batch, bindings) : nullptr,
                                               wsOf(st == side_stream_ && two), workspace_bytes_, (cudaStream_t)st);
                 break;

@@ -50,6 +50,7 @@ public:
     // Conv3DTranspose: end the launch in the soft-argmax (1) / soft-argmin (2) over the output depth that follows it (rt_conv_plan_set_softarg;
     // declared after the types and layouts, which reset it); false = the plan has no such form
     virtual bool setSoftarg(int) { return false; }
+    virtual int softarg() const { return 0; }       // what the plan currently ends in (the executor checks it against what it planned for)
     // (workspace: getWorkspaceSize(maxBatchSize) bytes private to the stream, or null -- the plan then uses a block of its own)
     virtual int enqueueFused(int, const void*, void*, const void*, void*, size_t, cudaStream_t) { return -1; }
     virtual ~IStereoPlugin() {}

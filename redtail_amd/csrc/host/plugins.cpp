@@ -364,6 +364,7 @@ public:
         softarg_ = mode;
         return true;
     }
+    int softarg() const override { return softarg_; }
     size_t getSerializationSize() override { return 0; }        // not serialisable, as in the reference
     void serialize(void*) override {}
 
@@ -381,10 +382,14 @@ protected:
         d.dtype = kernel_.type == DataType::kHALF ? RT_F16 : RT_F32;   // storage type of the weight blob
         int rc = createPlan(d);
         RT_CHECKL(rc, log_);
-        if (rc == 0 && (x16_ || y16_) && rt_conv_plan_set_io_types(plan_, x16_ ? RT_F16 : RT_F32, y16_ ? RT_F16 : RT_F32) != 0) x16_ = y16_ = false;
-        if (rc == 0 && (xil_ || yil_ || ril_) && rt_conv_plan_set_layouts(plan_, xil_, yil_, ril_) != 0) xil_ = yil_ = ril_ = false;
-        if (rc == 0 && softarg_ && rt_conv_plan_set_softarg(plan_, softarg_) != 0) softarg_ = 0;
-        return rc == 0;
+        // The executor sized its tensors for these settings: a rebuilt plan that does not take them again is an error, not a fallback
+        // (a plan without its fused soft-argmax would write the whole volume into the map's buffer).  The mirrors say what the plan has.
+        bool kept = true;
+        if (rc == 0 && (x16_ || y16_) && rt_conv_plan_set_io_types(plan_, x16_ ? RT_F16 : RT_F32, y16_ ? RT_F16 : RT_F32) != 0) { x16_ = y16_ = false; kept = false; }
+        if (rc == 0 && (xil_ || yil_ || ril_) && rt_conv_plan_set_layouts(plan_, xil_, yil_, ril_) != 0) { xil_ = yil_ = ril_ = false; kept = false; }
+        if (rc == 0 && softarg_ && rt_conv_plan_set_softarg(plan_, softarg_) != 0) { softarg_ = 0; kept = false; }
+        if (rc == 0 && !kept) RT_CHECKL(RT_E_UNSUPPORTED, log_);
+        return rc == 0 && kept;
     }
     virtual void fillDesc(rtConv3dDesc& d) const = 0;
     virtual int createPlan(const rtConv3dDesc& d) = 0;

@@ -2367,8 +2367,14 @@ extern "C" int rt_conv_plan_supports_il8(const rtConvPlan* plan) {
 extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, int r_il8) {
     RT_REQUIRE(plan, "rt_conv_plan_set_layouts: null plan");
     ExactScope exact_scope(plan->flags);
-    plan->softarg = 0;                  // (a fused soft-argmax is declared last, on the final tensor types and layouts)
-    plan->x_split = plan->y_split = 0;  // (so are pre-split tensors: rt_resblock_plan_set_split)
+    // A fused soft-argmax and pre-split tensors (rt_resblock_plan_set_split) are declared last, on the final types and layouts: a
+    // SUCCESSFUL change of the layouts resets them; a refused one leaves the plan as it was.
+    struct KeepOnFailure {
+        rtConvPlan* p; int softarg, xs, ys; bool ok = false;
+        ~KeepOnFailure() { if (!ok) { p->softarg = softarg; p->x_split = xs; p->y_split = ys; } }
+    } keep{plan, plan->softarg, plan->x_split, plan->y_split};
+    plan->softarg = 0;
+    plan->x_split = plan->y_split = 0;
     if (!x_il8 && !y_il8 && !r_il8) {
         if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].f16mma)
             if (int rc = switch_conv3d_f16mma(plan, false)) return rc;
@@ -2378,16 +2384,19 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
             for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
         }
         for (SubConv& sc : plan->subs) sc.x_il8 = sc.y_il8 = sc.r_il8 = 0;
+        keep.ok = true;
         return 0;
     }
     const int caps = rt_conv_plan_supports_il8(plan);
     if (plan->is_conv3d && plan->subs.size() == 1 && plan->subs[0].x_f16 && plan->subs[0].y_f16) {
         if ((caps & 8) && y_il8 && !x_il8) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D writes an interleaved tensor only when it reads one");
         if ((x_il8 && !(caps & 1)) || (y_il8 && !(caps & 2))) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D plan takes no interleaved tensors");
-        if (int rc = switch_conv3d_f16mma(plan, x_il8 != 0)) return rc;           // interleaved input: fp16 operands; planar input: the split kernel
+        // (every capability check before the plan is re-packed)
         if (r_il8 && (!(caps & 4) || !x_il8)) return fail(RT_E_UNSUPPORTED, "rt_conv_plan_set_layouts: this Conv3D reads an interleaved skip tensor only on fp16 operands (interleaved input)");
+        if (int rc = switch_conv3d_f16mma(plan, x_il8 != 0)) return rc;           // interleaved input: fp16 operands; planar input: the split kernel
         SubConv& sc = plan->subs[0];
         sc.x_il8 = x_il8 != 0; sc.y_il8 = y_il8 != 0; sc.r_il8 = r_il8 != 0;
+        keep.ok = true;
         return 0;
     }
     if (plan->is_deconv3d && !plan->subs.empty()) {
@@ -2436,6 +2445,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
                 RT_HIP(hipMemcpy(sc.small_il_dev, slab.data(), slab.size() * 2, hipMemcpyHostToDevice));
             }
             sc.x_il8 = x_il8 != 0;
+            keep.ok = true;
             return 0;
         }
         const bool f32 = !plan->subs[0].x_f16 && !plan->subs[0].y_f16;
@@ -2446,6 +2456,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
             for (SubConv& q : plan->subs) { q.x_f16 = xf; q.y_f16 = yf; }
         }
         for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }
+        keep.ok = true;
         return 0;
     }
     if ((x_il8 && !(caps & (1 | 16))) || (y_il8 && !(caps & 2)) || (r_il8 && !(caps & 4)))
@@ -2456,6 +2467,7 @@ extern "C" int rt_conv_plan_set_layouts(rtConvPlan* plan, int x_il8, int y_il8, 
     SubConv& sc = plan->subs[0];
     RT_REQUIRE(!sc.rb || (x_il8 != 0) == (r_il8 != 0), "rt_conv_plan_set_layouts: a residual block's residual is its input tensor");
     for (SubConv& q : plan->subs) { q.x_il8 = x_il8 != 0; q.y_il8 = y_il8 != 0; q.r_il8 = r_il8 != 0; }     // (3-D transposed plans have one sub per depth class)
+    keep.ok = true;
     return 0;
 }
 

@@ -309,6 +309,11 @@ def test_last_deconv3d_ends_in_softargmax(backend, ydims, dfull, dkeep, pad_d, a
     tol = 2e-4 * dkeep * max(1.0, float(np.abs(vol.numpy()).max()))
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
     assert np.abs(got - two).max() <= 2e-5 * dkeep, np.abs(got - two).max()
+    with pytest.raises(capi.RtError):
+        plan.set_layouts(1, 0, 1)                                        # refused (no skip tensor): the plan stays as it was, reduction included
+    again = empty(backend, ref.shape, False)
+    plan.enqueue(dev16(backend, il_cm(y)), again, None, n)
+    assert np.array_equal(host(backend, again), got)
     plan.set_softarg(0)                                                  # ... and off again: the volume, bit for bit
     v2 = empty(backend, vol.shape, False)
     plan.enqueue(dev16(backend, il_cm(y)), v2, None, n)
