@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     const std::string model_name = argv[1];
     const int width = atoi(argv[2]), height = atoi(argv[3]);
     const char* path = argv[4];
-    int gpus = 0, pairs = 240, batch = 1, contexts = 6, warmup = 12, fp16 = 0;
+    int gpus = 0, pairs = 240, batch = 1, contexts = 3, warmup = 12, fp16 = 0;      // (three contexts: profiles/r06_contexts.txt)
     for (int i = 5; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() { return i + 1 < argc ? atoi(argv[++i]) : 0; };
