@@ -7,6 +7,9 @@
 //                         (foldConcats() erased the concatenation after the stream pass -- the consumer's event was never recorded)
 //   2. siamese_custom   : twin towers with shared weights on a graph of our own, maxBatchSize 3, batches 1..3 (EngineImpl::mergeSiamese)
 //   3. siamese_unequal  : the same with one differing bias -- nothing downstream of it may be merged, results still right
+//   4. standalone_corr  : CostVolumePlugin(kCorrelation) as a launch of its own on maps of a network's width: the default engine runs it
+//                         on the matrix cores (3-term fp16 split), an engine built with IBuilder::setExactFp32Mode on the fp32 kernel
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -75,7 +78,8 @@ struct Result {
     std::vector<std::string> info;
 };
 
-Result run(const GraphFn& graph, int C, int H, int W, int max_batch, int batch, const std::vector<float>& l, const std::vector<float>& r, int out_c) {
+Result run(const GraphFn& graph, int C, int H, int W, int max_batch, int batch, const std::vector<float>& l, const std::vector<float>& r, int out_c,
+           bool exact_fp32 = false) {
     Result res;
     Logger log;
     auto plugins = IPluginContainer::create(log);
@@ -84,6 +88,7 @@ Result run(const GraphFn& graph, int C, int H, int W, int max_batch, int batch, 
     WeightPool pool;
     graph(*net, *plugins, pool);
     builder->setMaxBatchSize(max_batch);
+    if (exact_fp32) builder->setExactFp32Mode(true);
     ICudaEngine* engine = builder->buildCudaEngine(*net);
     net->destroy();
     builder->destroy();
@@ -236,6 +241,48 @@ void siamese(bool unequal) {
     printf("[  OK  ] %s\n", name);
 }
 
+// ---- 4 ---------------------------------------------------------------------------------------------------------------------
+void standalone_corr() {
+    g_ran++;
+    printf("[ RUN ] standalone_corr\n");
+    const int C = 16, H = 3, W = 70, D = 12;
+    GraphFn g = [&](INetworkDefinition& net, IPluginContainer& pc, WeightPool&) {
+        ITensor* L = net.addInput("left", DataType::kFLOAT, DimsCHW{C, H, W});
+        ITensor* R = net.addInput("right", DataType::kFLOAT, DimsCHW{C, H, W});
+        auto* cv = addCostVolume(pc, net, *L, *R, CostVolumeType::kCorrelation, D, DataType::kFLOAT, "corr");
+        cv->setName("corr");
+        cv->getOutput(0)->setName("out");
+        net.markOutput(*cv->getOutput(0));
+    };
+    const auto l = image(2, C, H, W, 31), r = image(2, C, H, W, 32);
+    Result mm = run(g, C, H, W, 2, 2, l, r, D), exact = run(g, C, H, W, 2, 2, l, r, D, true), valu;
+    const char* env[] = {"RT_NO_CORR_MFMA_PLANAR", nullptr};
+    with_env(env, [&] { valu = run(g, C, H, W, 2, 2, l, r, D); });
+    CHECK(mm.ok && exact.ok && valu.ok, "engine did not build / run");
+    // fp64 reference and the sum of magnitudes the split product's error is relative to
+    double worst = 0, worst_exact = 0;
+    for (int n = 0; n < 2; n++)
+        for (int d = 0; d < D; d++)
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    double ref = 0, mag = 0;
+                    if (x >= d)
+                        for (int c = 0; c < C; c++) {
+                            const double a = l[(((size_t)n * C + c) * H + y) * W + x], b = r[(((size_t)n * C + c) * H + y) * W + x - d];
+                            ref += a * b; mag += std::fabs(a * b);
+                        }
+                    const size_t o = (((size_t)n * D + d) * H + y) * W + x;
+                    const double e = std::fabs(mm.out[o] - ref), ee = std::fabs(exact.out[o] - ref);
+                    if (mag > 0) { worst = std::max(worst, e / mag); worst_exact = std::max(worst_exact, ee / mag); }
+                    else CHECK(mm.out[o] == 0.f && exact.out[o] == 0.f, "x < d must be exactly zero");
+                }
+    CHECK(worst <= 4.8e-7, "matrix-core correlation: |err| / sum |l r| = %g", worst);
+    CHECK(worst_exact <= 4.8e-7, "fp32 correlation: |err| / sum |l r| = %g", worst_exact);
+    CHECK(max_diff(exact.out, valu.out) == 0.0, "the exact-fp32 engine did not run the fp32 kernel");
+    CHECK(max_diff(mm.out, valu.out) > 0.0, "the default engine did not run the matrix-core kernel (same bits as the fp32 kernel)");
+    printf("[  OK  ] standalone_corr: |err| / sum |l r| %.3g (matrix cores), %.3g (exact fp32)\n", worst, worst_exact);
+}
+
 }  // namespace
 
 int main() {
@@ -243,6 +290,7 @@ int main() {
     two_tower_concat();
     siamese(false);
     siamese(true);
+    standalone_corr();
     printf("%s %d of %d engine graph tests\n", g_failed ? "FAILED" : "PASSED", g_failed ? g_failed : g_ran, g_ran);
     return g_failed ? 1 : 0;
 }

@@ -16,7 +16,7 @@ def _run(binary, quick=False):
     res = subprocess.run([binary], capture_output=True, text=True, timeout=1200, env=env)
     out = res.stdout + res.stderr
     assert res.returncode == 0, out[-4000:]
-    assert "PASSED 3 of 3 engine graph tests" in out, out[-2000:]
+    assert "PASSED 4 of 4 engine graph tests" in out, out[-2000:]
 
 
 def test_engine_graphs_on_emulator():
