@@ -113,8 +113,11 @@ int rt_softargmax(const void* vol, void* out, int batch, int D, int H, int W, in
  * (sample_app/resnet18_2D_513x257_net.cpp:601-615). */
 int rt_corr_softargmax(const void* left, const void* right, void* out, int batch, int C, int H, int W,
                        int max_disp, int is_min, int64_t out_batch_stride, int dtype, rtStream stream);
-/* Same with row pitches (elements, 0 = dense) for the feature maps and for the output plane; see
- * rt_conv_plan_set_pitch. */
+/* (fp32 maps of a network's size -- W >= 64, 16 <= C <= 32, max_disp <= 64 -- are correlated on the matrix cores through the 3-term fp16
+ * split of the convolutions, inputs |x| < 65504; smaller ones by the fp32 fmaf chain of the reference kernel.)
+ * Same with row pitches (elements, 0 = dense) for the feature maps and for the output plane; see
+ * rt_conv_plan_set_pitch.  This entry always computes the fp32 chain: it is what engines built with
+ * IBuilder::setExactFp32Mode call. */
 int rt_corr_softargmax_pitched(const void* left, const void* right, void* out, int batch, int C, int H, int W,
                                int max_disp, int is_min, int in_pitch, int out_pitch, int64_t out_batch_stride,
                                int dtype, rtStream stream);

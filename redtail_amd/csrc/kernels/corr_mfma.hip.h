@@ -137,7 +137,9 @@ __device__ static __forceinline__ void corr_split8(const f32x4 a, const f32x4 b,
     for (int j = 0; j < 4; j++) { hi[j] = s0.hi[j]; hi[4 + j] = s1.hi[j]; lo[j] = s0.lo[j]; lo[4 + j] = s1.lo[j]; }
 }
 
-template <bool ISMIN>
+// PLANAR (round 6): the feature maps are planar (C, H, pitch) fp32 -- rt_corr_softargmax on a client's NCHW maps; the operand of a lane is
+// gathered as 8 dword loads, 128 contiguous bytes per half wave each (corr_mfma_planar_kernel below has the same gather).
+template <bool ISMIN, bool PLANAR = false>
 __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_kernel(CorrMfmaArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,7 +168,14 @@ __global__ void __launch_bounds__(256) RT_WAVES_PER_EU(4) corr_softargmax_mfma_k
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int g = 4 * c + 2 * kg + h;
-                v[c][h] = buf_load4(rs, (ok && c < nchunks && 4 * g < p.C) ? (unsigned)g * gstride + (unsigned)(y * p.in_pitch + px) * 16u : kBufOOB, 0u);
+                if constexpr (PLANAR) {
+                    // channel 4 g + e: plane offset 4 g x (H x pitch) elements = g x gstride / 4 bytes ... gstride counts 4 planes
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        v[c][h][e] = buf_load(rs, (ok && 4 * g + e < p.C) ? (unsigned)g * gstride + (unsigned)e * (gstride >> 2) + (unsigned)(y * p.in_pitch + px) * 4u : kBufOOB, 0u);
+                } else {
+                    v[c][h] = buf_load4(rs, (ok && c < nchunks && 4 * g < p.C) ? (unsigned)g * gstride + (unsigned)(y * p.in_pitch + px) * 16u : kBufOOB, 0u);
+                }
             }
     };
 

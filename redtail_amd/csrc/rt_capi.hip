@@ -433,6 +433,27 @@ extern "C" int rt_corr_softargmax(const void* left, const void* right, void* out
     RT_REQUIRE(batch > 0 && C > 0 && H > 0 && W > 0 && D > 0, "rt_corr_softargmax: bad dims");
     if (dtype != RT_F32) return fail(RT_E_UNSUPPORTED, "rt_corr_softargmax: only fp32 in this build");
     if (out_bstride == 0) out_bstride = (int64_t)H * W;
+    // maps of a network's size: the Gram band on the matrix cores from planar maps (corr_softargmax_mfma_kernel<.., PLANAR>, the 3-term
+    // fp16 split of the engines' correlation: |x| < 65504).  Small maps, D > 64, C > 32 and RT_CONV_EXACT_FP32 keep the fp32 fmaf kernel --
+    // as does rt_corr_softargmax_pitched, the entry exact-fp32 engines call.
+    if (C >= 16 && C <= 32 && W >= 64 && D <= 64 && (int64_t)C * H * W < (1ll << 29) && env_int("RT_CONV_EXACT_FP32", 0) == 0 &&
+        env_int("RT_NO_CORR_MFMA_PLANAR", 0) == 0) {
+        rt::CorrMfmaArgs a;
+        a.left = static_cast<const float*>(left); a.right = static_cast<const float*>(right); a.out = static_cast<float*>(out);
+        a.C = C; a.H = H; a.W = W; a.D = D;
+        a.in_pitch = W; a.out_pitch = W;
+        a.in_bstride = (int64_t)C * H * W;
+        a.out_bstride = out_bstride;
+        a.out_slot = 1;
+        a.blocks_x = (int)rt::cdiv(W, 32); a.batch = batch;
+        const int64_t tasks = (int64_t)a.blocks_x * H * batch;
+        RT_REQUIRE(rt::cdiv(tasks, 4) < (1ll << 31), "rt_corr_softargmax: grid too large");
+        dim3 grid((unsigned)rt::cdiv(tasks, 4));
+        if (is_min) hipLaunchKernelGGL((rt::corr_softargmax_mfma_kernel<true, true>), grid, dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((rt::corr_softargmax_mfma_kernel<false, true>), grid, dim3(256), 0, S(s), a);
+        RT_LAUNCH_CHECK("corr_softargmax_mfma_kernel<planar>");
+        return 0;
+    }
     auto l = static_cast<const float*>(left);
     auto r = static_cast<const float*>(right);
     auto o = static_cast<float*>(out);

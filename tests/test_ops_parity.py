@@ -110,6 +110,29 @@ def test_corr_planar_on_the_matrix_cores(backend, shape, D, monkeypatch):
     assert np.array_equal(run_corr(backend, l, r, D), exact)
 
 
+@pytest.mark.parametrize("shape,D,is_min", [((2, 32, 5, 140), 48, False), ((1, 16, 3, 64), 64, True), ((1, 24, 4, 97), 33, False),
+                                            ((3, 20, 2, 70), 34, True)])
+def test_corr_softargmax_planar_on_the_matrix_cores(backend, shape, D, is_min, monkeypatch):
+    """rt_corr_softargmax on a client's planar maps of a network's size: the Gram band on the matrix cores (3-term fp16 split), the same map
+    as the fp32 chain to the accuracy of the split; rt_corr_softargmax_pitched -- what exact-fp32 engines call -- stays on the fp32 chain"""
+    l, r = rnd(*shape) * np.float32(0.5), rnd(*shape) * np.float32(0.5)
+    n, c, h, w = shape
+    ref = O.softargmax(O.corr_cost_volume(T(l).double(), T(r).double(), D), is_min).numpy()
+    out = backend.empty((n, 1, h, w))
+    backend.klib.corr_softargmax(backend.dev(l), backend.dev(r), out, n, c, h, w, D, is_min)
+    got = backend.host(out)
+    near(got, ref, 2e-4)
+    fp32 = backend.empty((n, 1, h, w))
+    backend.klib.corr_softargmax_pitched(backend.dev(l), backend.dev(r), fp32, n, c, h, w, D, is_min, 0, 0)
+    fp32 = backend.host(fp32)
+    near(fp32, ref, 2e-4)
+    assert (fp32 != got).any()                               # (two kernels)
+    monkeypatch.setenv("RT_NO_CORR_MFMA_PLANAR", "1")
+    again = backend.empty((n, 1, h, w))
+    backend.klib.corr_softargmax(backend.dev(l), backend.dev(r), again, n, c, h, w, D, is_min)
+    assert np.array_equal(backend.host(again), fp32)
+
+
 @pytest.mark.parametrize("shape,D,is_min", [((1, 5, 7, 37), 6, False), ((2, 32, 9, 140), 48, False),
                                             ((1, 8, 5, 129), 13, True), ((1, 4, 6, 6), 2, False)])
 def test_corr_softargmax_fused(backend, shape, D, is_min):

@@ -132,7 +132,9 @@ def main():
                 results.append(dict(name="cpu corr cost volume C32 D48 @185x629 b1 (oracle/corr_cpu.c, 1 core)", us=tc * 1e6, kind="port", cores=1,
                                     max_abs_diff_vs_gpu=err))
             t = timeit(lambda: k.corr_softargmax(l, r, sa, b, C, H, W, D, False))
-            report("corr+softargmax fused, planar fp32 (corr_f32_kernel) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
+            report("corr+softargmax fused, planar fp32 maps (corr_softargmax_mfma_kernel<planar>) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
+            t = timeit(lambda: k.corr_softargmax_pitched(l, r, sa, b, C, H, W, D, False, 0, 0))
+            report("  the same on the vector ALU (corr_f32_kernel: exact-fp32 engines) b%d" % b, t, 2.0 * b * C * D * H * W, 4.0 * b * (2 * C + 1) * H * W)
             # the form the engine runs: channel-interleaved (C/4, H, pitch, 4) feature maps, Gram band on the matrix cores (corr_mfma.hip.h)
             P = (W + 31) // 32 * 32
             li, ri = rnd(b, C // 4, H, P, 4), rnd(b, C // 4, H, P, 4)
