@@ -65,7 +65,14 @@ def main():
         for r in csv.DictReader(open(os.path.join(run, "trace", "bench_kernel_trace.csv"))):
             if short(r["Kernel_Name"]).startswith(DOMINANT):
                 grids[int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])] += 1
-        DOMINANT_GRID = grids.most_common(1)[0][0]      # the timed configuration's (six one-stream contexts; the PMC passes run one such context)
+        # the timed configuration's grid: the one the PMC passes (one one-stream context, i.e. the throughput hint) launch -- the trace also
+        # holds the latency set-up's launches of the same kernel (32-row segments), and which of the two is more numerous depends on the step counts
+        pmc_grids = set()
+        fpmc = os.path.join(run, "pmc_FETCH_SIZE", "p_counter_collection.csv")
+        if os.path.exists(fpmc):
+            pmc_grids = {int(r["Grid_Size"]) for r in csv.DictReader(open(fpmc)) if short(r["Kernel_Name"]).startswith(DOMINANT)}
+        cands = [(n, g) for g, n in grids.items() if not pmc_grids or g in pmc_grids]
+        DOMINANT_GRID = max(cands or [(n, g) for g, n in grids.items()])[1]
         IMAGES = images = 2 if DOMINANT_GRID in (21 * 3 * 512 * 2, 21 * 6 * 512 * 2, 21 * 4 * 512 * 2, 21 * 2 * 512 * 2) else 1
         ALGO_READ = images * 4.0 * (32 * 185 * 629) + 4.0 * 2 * (32 * 32 * 9 + 32)   # x of every image + both layers' weights and biases
         ALGO_WRITE = images * 4.0 * 32 * 185 * 629
